@@ -1,0 +1,250 @@
+/*
+ * otter_gpu.h — C-ABI of the MI355X-native drop-in for otter's per-region hot path.
+ *
+ * Every entry point is `extern "C"`, takes plain pointers + sizes, and replaces a named
+ * interface of the reference (holstegelab/otter @ 2024_10_08, paths relative to the
+ * reference root).  The library behind it (libotter_gpu.so) is hand-written HIP for gfx950;
+ * there is NO CPU fallback inside: when no HIP device is usable every call returns
+ * OTG_ERR_NO_DEVICE and otg_last_error() says why.
+ *
+ * Layers
+ *   L1  batched aligners        — replace wfa::WFAligner (WFA2-lib, absent submodule) as used at
+ *                                 src/analignments.cpp:25,31,37,70-71,88-97,268-280
+ *   L2  per-region operators    — replace DistMatrix/otter_hclust/PPOA/anallele_cluster
+ *                                 (src/andistmat.cpp, src/otterclust.cpp:20-320,463-527, src/anppoa.hpp)
+ *   L3  region-batch pipeline   — replaces the five calls inside the region loop of
+ *                                 assemble_process (src/assemble.cpp:74,126,129,137,141)
+ *
+ * Ownership: the caller owns every input buffer until the call returns (the library copies
+ * to HBM); output buffers are caller-allocated.  No C++ types or exceptions cross the ABI.
+ * Threading: an otg_ctx is single-threaded (one per host worker / GPU); distinct contexts are
+ * independent.  Results are independent of batch composition.
+ */
+#ifndef OTTER_GPU_H
+#define OTTER_GPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- status codes */
+#define OTG_OK               0
+#define OTG_ERR_NO_DEVICE   -1   /* no usable HIP device / kernels missing                 */
+#define OTG_ERR_ARG         -2   /* bad argument (null pointer, inconsistent sizes)        */
+#define OTG_ERR_HIP         -3   /* a HIP runtime call failed (message in otg_last_error)  */
+#define OTG_ERR_CAPACITY    -4   /* caller-provided output buffer too small                */
+#define OTG_ERR_FATAL       -5   /* a condition on which the reference exit(1)s            */
+
+/* per-region status, mirrors the reference's warnings / omissions (src/assemble.cpp:71,94,120) */
+#define OTG_REGION_OK            0
+#define OTG_REGION_SKIP_MAXCOV   1   /* reads > max_cov: "[WARNING] Skipping region with abnormal coverage" */
+#define OTG_REGION_NO_SPANNING   2   /* "[WARNING] No spanning reads"                                         */
+#define OTG_REGION_EMPTY         3   /* no reads at all                                                       */
+#define OTG_REGION_HAP_CONFLICT  4   /* "ERROR: conflicting haplotag information" (reference exit(1)s)       */
+
+typedef struct otg_ctx otg_ctx;
+
+/* ---------------------------------------------------------------- parameters
+ * Defaults = reference CLI defaults (src/command_assemble.cpp:34-45, src/command_genotype.cpp:25-27). */
+typedef struct otg_params {
+  int32_t max_alleles;          /* -a  2                                  */
+  int32_t ignore_haps;          /* !--haps  => 1                          */
+  int32_t max_cov;              /* -c  200                                */
+  int32_t flank;                /* -f  100                                */
+  int32_t bandwidth_length;     /* -h  second field, 500                  */
+  int32_t min_cov_fraction2_l;  /* -A  first field, 500                   */
+  int32_t mismatch;             /* WFAlignerGapAffine(4,6,2): 4           */
+  int32_t gap_open;             /*                            6           */
+  int32_t gap_ext;              /*                            2           */
+  int32_t realign;              /* 1 iff -r <reference> was given (flanks present in the batch) */
+  double  bandwidth_short;      /* -h  0.01                               */
+  double  bandwidth_long;       /* -h  0.015                              */
+  double  max_error;            /* -e  0.01                               */
+  double  min_cov_fraction;     /* -F  0.2                                */
+  double  min_cov_fraction2_f;  /* -A  0.1                                */
+  double  min_sim;              /* -s  0.9                                */
+  double  gt_max_error;         /* genotype -e 0.025                      */
+  double  gt_max_cosdis;        /* genotype -c 0.025                      */
+} otg_params;
+
+void otg_params_default(otg_params* p);
+
+/* ---------------------------------------------------------------- context */
+int         otg_create(int device, otg_ctx** out);
+void        otg_destroy(otg_ctx* ctx);
+const char* otg_last_error(otg_ctx* ctx);     /* ctx may be NULL: last global error           */
+int         otg_device_count(void);           /* number of visible HIP devices (0 if none)    */
+/* Which libm exp() rounding variant the device KDE mirrors (1 = glibc FMA build, 0 = non-FMA).
+ * Chosen at otg_create by probing the host libm so cluster labels match the reference
+ * running on this host (SURVEY.md §7.2 "FP determinism"). */
+int         otg_exp_variant(otg_ctx* ctx);
+
+/* ================================================================= L1: batched aligners
+ * One task = one wfa::WFAligner call.  Sequences live in one byte arena (raw bytes, compared
+ * raw: 'N'=='N', case-sensitive, as WFA2 does).
+ *   all four *_free == 0 and endsfree == 0  -> alignEnd2End(pattern, text)
+ *   endsfree == 1 -> alignEndsFree(pattern, pattern_begin_free, pattern_end_free,
+ *                                  text, text_begin_free, text_end_free)                      */
+typedef struct otg_align_task {
+  uint64_t pattern_off;
+  uint64_t text_off;
+  uint32_t pattern_len;
+  uint32_t text_len;
+  int32_t  pattern_begin_free;
+  int32_t  pattern_end_free;
+  int32_t  text_begin_free;
+  int32_t  text_end_free;
+  int32_t  endsfree;
+  int32_t  _pad;
+} otg_align_task;
+
+/* Replaces WFAlignerEdit(Score, MemoryMed)::alignEnd2End/alignEndsFree + getAlignmentScore()
+ * (src/assemble.cpp:49, src/analignments.cpp:70-71,88-97).  scores_out[i] = unit-cost edit distance
+ * (>= 0).  cells_out (nullable): wavefront cells W_p evaluated.                */
+int otg_edit_distance_batch(otg_ctx* ctx,
+                            const uint8_t* seq_arena, uint64_t arena_bytes,
+                            const otg_align_task* tasks, uint32_t n_tasks,
+                            int32_t* scores_out, uint64_t* cells_out);
+
+/* Replaces WFAlignerGapAffine(x,o,e, Alignment, MemoryMed)::alignEnd2End/alignEndsFree +
+ * getAlignmentCigar() (src/assemble.cpp:50, src/analignments.cpp:25,31,37,268-280).
+ * scores_out[i] = gap-affine penalty (>= 0; WFA2 reports its negative).  The op string of task i
+ * (alphabet M X I D, one char per column, free end gaps explicit) is written at
+ * cigar_arena + cigar_off_out[i], length cigar_len_out[i].  Returns OTG_ERR_CAPACITY (and the
+ * needed size in *cigar_bytes_used) if cigar_capacity is too small.                            */
+int otg_affine_align_batch(otg_ctx* ctx,
+                           const uint8_t* seq_arena, uint64_t arena_bytes,
+                           const otg_align_task* tasks, uint32_t n_tasks,
+                           int32_t mismatch, int32_t gap_open, int32_t gap_ext,
+                           int32_t* scores_out,
+                           uint64_t* cigar_off_out, uint32_t* cigar_len_out,
+                           uint8_t* cigar_arena, uint64_t cigar_capacity, uint64_t* cigar_bytes_used,
+                           uint64_t* cells_out);
+
+/* ================================================================= L2: per-region operators */
+
+/* Replaces otter_hclust (src/otterclust.cpp:118-320) incl. otter_find_clustering_dist (:20-116),
+ * KDE (src/ankde.cpp), hclust_fast / cutree_cdist / cutree_k (include/hclust-cpp/fastcluster.cpp).
+ * Region r has n_valid[r] valid reads, its condensed FP64 matrix (DistMatrix layout,
+ * src/andistmat.cpp:20) starts at dist + dist_off[r], its read lengths at read_len + len_off[r].
+ * Outputs: labels (same indexing as read_len), ic/fc per region, bounds = 3 doubles per region
+ * (dist0, dist1, cut0; NaN when the KDE was not evaluated).                                    */
+int otg_cluster_batch(otg_ctx* ctx, const otg_params* params,
+                      const double* dist, const uint64_t* dist_off,
+                      const uint32_t* read_len, const uint64_t* len_off,
+                      const uint32_t* n_valid, uint32_t n_regions,
+                      int32_t* labels_out, int32_t* ic_out, int32_t* fc_out, double* bounds_out);
+
+/* Replaces PPOA (src/anppoa.hpp:64-380) as driven by rapid_consensus (src/analignments.cpp:261-292):
+ * graph g has backbone = task `backbone`, then members inserted in order; each member is a
+ * sequence + its op string + spanning flags.  c/t are the adjust_weights arguments.
+ * Output consensus strings in out_arena (same off/len convention as cigars).                   */
+typedef struct otg_poa_member {
+  uint64_t seq_off;   uint32_t seq_len;   uint32_t cigar_len;
+  uint64_t cigar_off;
+  uint8_t  spanning_l, spanning_r; uint8_t _pad[6];
+} otg_poa_member;
+
+typedef struct otg_poa_graph {
+  uint64_t backbone_off; uint32_t backbone_len;
+  uint32_t first_member; uint32_t n_members;
+  float    c, t; uint32_t _pad;
+} otg_poa_graph;
+
+int otg_poa_consensus_batch(otg_ctx* ctx,
+                            const uint8_t* seq_arena, uint64_t arena_bytes,
+                            const uint8_t* cigar_arena, uint64_t cigar_bytes,
+                            const otg_poa_member* members, uint32_t n_members,
+                            const otg_poa_graph* graphs, uint32_t n_graphs,
+                            uint64_t* out_off, uint32_t* out_len,
+                            uint8_t* out_arena, uint64_t out_capacity, uint64_t* out_bytes_used);
+
+/* Replaces anallele_cluster (src/otterclust.cpp:463-527) for `otter genotype`.
+ * Region r has n_alleles[r] allele sequences described by (seq_off,seq_len) entries starting at
+ * allele index first_allele[r].  Outputs per allele: gt, gt_l, gt_k, hsd; per region: n_gt and
+ * representative allele indices (region-local) written at reps_out + first_allele[r].           */
+int otg_genotype_cluster_batch(otg_ctx* ctx, const otg_params* params,
+                               const uint8_t* seq_arena, uint64_t arena_bytes,
+                               const uint64_t* seq_off, const uint32_t* seq_len,
+                               const uint32_t* first_allele, const uint32_t* n_alleles, uint32_t n_regions,
+                               int32_t* gt_out, int32_t* gt_l_out, int32_t* gt_k_out, double* hsd_out,
+                               int32_t* n_gt_out, int32_t* reps_out);
+
+/* ================================================================= L3: region-batch pipeline
+ * SoA image of std::vector<ANREAD> (src/anseqs.hpp:56-76) for a batch of regions.               */
+typedef struct otg_read {
+  uint64_t seq_off;          /* into seq_arena                                   */
+  uint32_t seq_len;
+  uint8_t  spanning_l;       /* ANREAD::is_spanning_l                            */
+  uint8_t  spanning_r;       /* ANREAD::is_spanning_r                            */
+  uint16_t _pad;
+  int32_t  ps, hp;           /* HAPLOTAG (-1 = undefined)                        */
+  int32_t  ccoord_first;     /* ANREAD::ccoords                                  */
+  int32_t  ccoord_second;
+} otg_read;
+
+typedef struct otg_region {
+  uint32_t first_read;       /* index into reads[]                               */
+  uint32_t n_reads;
+  uint64_t flank_l_off;      /* reference flank [start-flank,start], upper-cased  */
+  uint64_t flank_r_off;      /* reference flank [end,end+flank]                   */
+  uint32_t flank_l_len;      /* 0 when -r not given                              */
+  uint32_t flank_r_len;
+} otg_region;
+
+/* image of ANALLELE (src/anseqs.hpp:40-54) */
+typedef struct otg_allele {
+  uint64_t seq_off;          /* into the output arena                            */
+  uint32_t seq_len;
+  int32_t  scov, acov, tcov;
+  float    se;
+  int32_t  ic;
+  int32_t  ps, hp;
+  uint32_t region;           /* batch-local region index                         */
+  int32_t  label;            /* allele index within the region (0..fc-1)         */
+} otg_allele;
+
+typedef struct otg_region_result {
+  uint32_t first_allele;
+  uint32_t n_alleles;        /* = fc for OK regions, else 0                      */
+  int32_t  status;           /* OTG_REGION_*                                     */
+  int32_t  ic, fc;
+  int32_t  n_valid;
+} otg_region_result;
+
+/* Workload statistics of the last otg_assemble_run (for the roofline figure). */
+typedef struct otg_run_stats {
+  uint64_t n_regions, n_regions_ok;
+  uint64_t edit_tasks,   edit_cells,   edit_seq_bytes;
+  uint64_t affine_tasks, affine_cells, affine_seq_bytes;
+  uint64_t allele_bytes;
+  uint64_t algorithmic_bytes;         /* Σ (a+b) + 4·W (+ W/2 for CIGAR scope) + Σ(len+40) */
+  double   ms_edit, ms_cluster, ms_reassign, ms_affine, ms_poa, ms_realign, ms_total;
+  double   ms_edit_kernel;            /* dominant kernel: HIP-event time of the edit WFA launches */
+  uint64_t edit_kernel_launches;
+} otg_run_stats;
+
+/* Upload a batch (H2D).  After it returns the inputs are resident in HBM.                       */
+int otg_assemble_submit(otg_ctx* ctx, const otg_params* params,
+                        const uint8_t* seq_arena, uint64_t arena_bytes,
+                        const otg_read* reads, uint32_t n_reads,
+                        const otg_region* regions, uint32_t n_regions);
+/* Run the whole hot path on the resident batch: [local_realignment] -> fill_dist_matrix ->
+ * otter_hclust -> invalid_reassignment -> rapid_consensus.  Results stay resident.             */
+int otg_assemble_run(otg_ctx* ctx);
+/* Sizes needed by otg_assemble_collect for the last run.                                        */
+int otg_assemble_result_sizes(otg_ctx* ctx, uint32_t* n_alleles, uint64_t* seq_bytes);
+/* D2H of the results.  labels_out (nullable) gets the final per-read label (-1 unassigned).     */
+int otg_assemble_collect(otg_ctx* ctx,
+                         otg_region_result* region_out,
+                         otg_allele* alleles_out, uint32_t allele_capacity,
+                         uint8_t* seq_out, uint64_t seq_capacity,
+                         int32_t* labels_out);
+int otg_assemble_stats(otg_ctx* ctx, otg_run_stats* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OTTER_GPU_H */

@@ -1,0 +1,1449 @@
+/*
+ * otter_oracle.cpp — CPU ORACLE.  TEST INFRASTRUCTURE ONLY.
+ *
+ * A plain restatement, in C-style C++ (g++, no GPU, no torch), of the reference's per-region hot
+ * path (holstegelab/otter @ 2024_10_08).  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this library; the product (otter_amd/, libotter_gpu.so) never does.
+ *
+ * Each function cites the reference file:line it follows (paths relative to /root/reference).
+ *
+ * PARITY PINNING:
+ *   pinned by running the reference's own sources (oracle/_ref, built from /root/reference):
+ *       DistMatrix (src/andistmat.cpp), KDE (src/ankde.cpp), hclust_fast/cutree_* (include/hclust-cpp),
+ *       PPOA (src/anppoa.hpp), KUSAGE/seq2kcounts (src/anseqs.cpp:111-166 is NOT buildable alone -> restated)
+ *   pinned by mathematics: WFA edit / affine SCORES (checked against O(nm) DP in this file)
+ *   pinned by the reference's 4 known-answer tests (test/ppoa_test.cpp:39-105): affine-WFA CIGAR ∘ PPOA
+ *   PARITY UNPINNED: the affine CIGAR tie-breaking beyond those 4 KATs.  The engine is the third-party
+ *       smarco/WFA2-lib (un-vendored submodule include/WFA2-lib, API era v2.3.0–2.3.3, commit not
+ *       recoverable); its published algorithm (Marco-Sola et al. 2021/2023) is restated here with the
+ *       piggy-back provenance rule recalled in SURVEY.md Appendix A.3.  Also unpinned (no reference
+ *       test, source not buildable without the absent WFA header): the control flow of
+ *       otter_hclust / otter_find_clustering_dist / invalid_reassignment / rapid_consensus /
+ *       local_realignment / anallele_cluster — restated line by line from the cited sources.
+ */
+#include "../include/otter_gpu.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <list>
+#include <map>
+#include <set>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace oto {
+
+static const int NULL_OFF = -(1 << 30);
+
+struct Form {
+  int endsfree, pbf, pef, tbf, tef;
+};
+
+/* ------------------------------------------------------------------------------------------
+ * WFA, unit-cost edit distance, score only.  Replaces WFAlignerEdit(Score, MemoryMed)
+ * (constructed src/assemble.cpp:49; called src/analignments.cpp:70-71,88-97).
+ * Algorithm: WFA2-lib wavefront_compute_edit + wavefront_extend_* (SURVEY Appendix A.3 items 1,2,4):
+ *   geometry k = h - v, offset stores h (text position);
+ *   M[s][k] = max(M[s-1][k-1]+1, M[s-1][k]+1, M[s-1][k+1]), nulled when h>tlen or v>plen,
+ *   then greedy match extension; end2end ends when M[s][tlen-plen]==tlen; ends-free scans k
+ *   ascending and ends at the first diagonal reaching a permitted boundary.
+ * cells: Σ_s |{k in [max(lo,-plen), min(hi,tlen)]}| (SURVEY §8d W_p).
+ * ------------------------------------------------------------------------------------------ */
+int wfa_edit(const uint8_t* p, int pl, const uint8_t* t, int tl, const Form& f, uint64_t* cells)
+{
+  int lo = f.endsfree ? -f.pbf : 0, hi = f.endsfree ? f.tbf : 0;
+  if (lo < -pl) lo = -pl;
+  if (hi > tl) hi = tl;
+  const int kend = tl - pl;
+  /* diagonals indexed k + pl + 1, with a null sentinel either side */
+  std::vector<int> cur(pl + tl + 3, NULL_OFF), nxt(pl + tl + 3, NULL_OFF);
+  const int B = pl + 1;
+  for (int k = lo; k <= hi; ++k) cur[k + B] = k > 0 ? k : 0;
+  uint64_t W = 0;
+  for (int s = 0;; ++s) {
+    W += (uint64_t)(hi - lo + 1);
+    for (int k = lo; k <= hi; ++k) {
+      int h = cur[k + B];
+      if (h < 0) continue;
+      int v = h - k;
+      while (v < pl && h < tl && p[v] == t[h]) { ++v; ++h; }
+      cur[k + B] = h;
+      if (f.endsfree) {
+        if ((h >= tl && pl - v <= f.pef) || (v >= pl && tl - h <= f.tef)) {
+          if (cells) *cells = W;
+          return s;
+        }
+      }
+    }
+    if (!f.endsfree && kend >= lo && kend <= hi && cur[kend + B] >= tl) {
+      if (cells) *cells = W;
+      return s;
+    }
+    int nlo = lo - 1 < -pl ? -pl : lo - 1, nhi = hi + 1 > tl ? tl : hi + 1;
+    for (int k = nlo; k <= nhi; ++k) {
+      int ins = (k - 1 >= lo && k - 1 <= hi) ? cur[k - 1 + B] + 1 : NULL_OFF;
+      int mis = (k >= lo && k <= hi) ? cur[k + B] + 1 : NULL_OFF;
+      int del = (k + 1 >= lo && k + 1 <= hi) ? cur[k + 1 + B] : NULL_OFF;
+      int mx = std::max(del, std::max(mis, ins));
+      if (mx < 0 || mx > tl || mx - k > pl) mx = NULL_OFF;
+      nxt[k + B] = mx;
+    }
+    for (int k = lo; k <= hi; ++k) cur[k + B] = NULL_OFF;
+    std::swap(cur, nxt);
+    lo = nlo; hi = nhi;
+  }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * WFA, gap-affine (match 0, mismatch x, gap of n = o + n*e), full op string.
+ * Replaces WFAlignerGapAffine(4,6,2, Alignment, MemoryMed) (src/assemble.cpp:50;
+ * src/analignments.cpp:25,31,37,268-280).  Restates WFA2-lib wavefront_compute_affine with the
+ * piggy-back provenance (SURVEY Appendix A.3 items 3,4,6,7):
+ *   I[s][k] = max(M[s-o-e][k-1], I[s-e][k-1]) + 1     provenance: ext if ext >= open
+ *   D[s][k] = max(M[s-o-e][k+1], D[s-e][k+1])         provenance: ext if ext >= open
+ *   M[s][k] = max(M[s-x][k]+1, I[s][k], D[s][k])      provenance assigned by three sequential tests
+ *             in the order ins, del, mism  => on ties mismatch wins over deletion wins over insertion;
+ *   M nulled when h>tlen or v>plen; matches are re-derived by greedy forward extension when the op
+ *   list is unpacked (pcigar_unpack_affine), free end gaps are explicit leading/trailing I/D runs.
+ * ------------------------------------------------------------------------------------------ */
+struct WF {
+  int lo = 1, hi = 0; /* empty */
+  std::vector<int> off;
+  bool null() const { return hi < lo; }
+  int get(int k) const { return (k < lo || k > hi) ? NULL_OFF : off[k - lo]; }
+};
+
+int wfa_affine(const uint8_t* p, int pl, const uint8_t* t, int tl, int x, int o, int e, const Form& f,
+               std::string* cigar, uint64_t* cells)
+{
+  std::vector<WF> M, I, D;
+  /* provenance bits per (s,k): bits0-1 M origin (0 mism,1 del,2 ins), bit2 I ext, bit3 D ext */
+  std::vector<std::vector<uint8_t>> BT;
+  const int kend = tl - pl;
+  uint64_t W = 0;
+  int s_end = -1, k_end = 0;
+  for (int s = 0;; ++s) {
+    M.emplace_back(); I.emplace_back(); D.emplace_back(); BT.emplace_back();
+    WF& m = M[s]; WF& iw = I[s]; WF& dw = D[s];
+    if (s == 0) {
+      m.lo = f.endsfree ? std::max(-f.pbf, -pl) : 0;
+      m.hi = f.endsfree ? std::min(f.tbf, tl) : 0;
+      m.off.resize(m.hi - m.lo + 1);
+      for (int k = m.lo; k <= m.hi; ++k) m.off[k - m.lo] = k > 0 ? k : 0;
+      BT[s].assign(m.off.size(), 0);
+    } else {
+      const WF* mm = s - x >= 0 ? &M[s - x] : nullptr;
+      const WF* mo = s - o - e >= 0 ? &M[s - o - e] : nullptr;
+      const WF* ie = s - e >= 0 ? &I[s - e] : nullptr;
+      const WF* de = s - e >= 0 ? &D[s - e] : nullptr;
+      if (mm && mm->null()) mm = nullptr;
+      if (mo && mo->null()) mo = nullptr;
+      if (ie && ie->null()) ie = nullptr;
+      if (de && de->null()) de = nullptr;
+      if (!mm && !mo && !ie && !de) continue; /* null wavefront: score not reachable */
+      int lo = 1 << 30, hi = -(1 << 30);
+      if (mm) { lo = std::min(lo, mm->lo); hi = std::max(hi, mm->hi); }
+      if (mo) { lo = std::min(lo, mo->lo - 1); hi = std::max(hi, mo->hi + 1); }
+      if (ie) { lo = std::min(lo, ie->lo + 1); hi = std::max(hi, ie->hi + 1); }
+      if (de) { lo = std::min(lo, de->lo - 1); hi = std::max(hi, de->hi - 1); }
+      if (lo < -pl) lo = -pl;
+      if (hi > tl) hi = tl;
+      if (hi < lo) continue;
+      m.lo = iw.lo = dw.lo = lo; m.hi = iw.hi = dw.hi = hi;
+      m.off.resize(hi - lo + 1); iw.off.resize(hi - lo + 1); dw.off.resize(hi - lo + 1);
+      BT[s].resize(hi - lo + 1);
+      for (int k = lo; k <= hi; ++k) {
+        int io = mo ? mo->get(k - 1) : NULL_OFF, ix = ie ? ie->get(k - 1) : NULL_OFF;
+        int dop = mo ? mo->get(k + 1) : NULL_OFF, dx = de ? de->get(k + 1) : NULL_OFF;
+        uint8_t bits = 0;
+        int ins, del;
+        if (ix >= io) { ins = ix; bits |= 4; } else ins = io;
+        ins = ins + 1;
+        if (dx >= dop) { del = dx; bits |= 8; } else del = dop;
+        int mis = (mm ? mm->get(k) : NULL_OFF) + 1;
+        int mx = std::max(del, std::max(mis, ins));
+        uint8_t org = 0;
+        if (mx == ins) org = 2;
+        if (mx == del) org = 1;
+        if (mx == mis) org = 0;
+        bits |= org;
+        if (ins < 0) ins = NULL_OFF;
+        if (del < 0) del = NULL_OFF;
+        if (mx < 0 || mx > tl || mx - k > pl) mx = NULL_OFF;
+        iw.off[k - lo] = ins; dw.off[k - lo] = del; m.off[k - lo] = mx;
+        BT[s][k - lo] = bits;
+      }
+    }
+    W += 3ull * (uint64_t)(m.hi - m.lo + 1);
+    /* extend + termination */
+    bool done = false;
+    for (int k = m.lo; k <= m.hi && !done; ++k) {
+      int h = m.off[k - m.lo];
+      if (h < 0) continue;
+      int v = h - k;
+      while (v < pl && h < tl && p[v] == t[h]) { ++v; ++h; }
+      m.off[k - m.lo] = h;
+      if (f.endsfree) {
+        if ((h >= tl && pl - v <= f.pef) || (v >= pl && tl - h <= f.tef)) { done = true; s_end = s; k_end = k; }
+      }
+    }
+    if (!f.endsfree && kend >= m.lo && kend <= m.hi && m.off[kend - m.lo] >= tl) { done = true; s_end = s; k_end = kend; }
+    if (done) break;
+  }
+  if (cells) *cells = W;
+  if (!cigar) return s_end;
+  /* backtrace: reverse op list with 'c' = gap close marker (WFA2's fake X) */
+  std::string rev;
+  {
+    int s = s_end, k = k_end, comp = 0; /* 0 M, 1 I, 2 D */
+    while (s > 0 || comp != 0) {
+      uint8_t bits = BT[s][k - M[s].lo];
+      if (comp == 0) {
+        int org = bits & 3;
+        if (org == 0) { rev.push_back('X'); s -= x; }
+        else if (org == 1) { rev.push_back('c'); comp = 2; }
+        else { rev.push_back('c'); comp = 1; }
+      } else if (comp == 1) {
+        rev.push_back('I');
+        if (bits & 4) s -= e; else { s -= o + e; comp = 0; }
+        k -= 1;
+      } else {
+        rev.push_back('D');
+        if (bits & 8) s -= e; else { s -= o + e; comp = 0; }
+        k += 1;
+      }
+    }
+    /* forward unpack (pcigar_unpack_affine semantics) */
+    int h = k > 0 ? k : 0, v = k < 0 ? -k : 0;
+    cigar->clear();
+    cigar->append(h, 'I');
+    cigar->append(v, 'D');
+    int state = 0;
+    for (int i = (int)rev.size() - 1; i >= 0; --i) {
+      if (state == 0) {
+        while (v < pl && h < tl && p[v] == t[h]) { cigar->push_back('M'); ++v; ++h; }
+      }
+      char op = rev[i];
+      if (op == 'I') { cigar->push_back('I'); ++h; state = 1; }
+      else if (op == 'D') { cigar->push_back('D'); ++v; state = 2; }
+      else if (op == 'c') { state = 0; }
+      else { cigar->push_back('X'); ++v; ++h; }
+    }
+    while (v < pl && h < tl && p[v] == t[h]) { cigar->push_back('M'); ++v; ++h; }
+    while (h < tl) { cigar->push_back('I'); ++h; }
+    while (v < pl) { cigar->push_back('D'); ++v; }
+  }
+  return s_end;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * O(nm) dynamic-programming checkers (mathematical pin for the WFA scores; tests only).
+ * ------------------------------------------------------------------------------------------ */
+int dp_edit(const uint8_t* p, int pl, const uint8_t* t, int tl, const Form& f)
+{
+  std::vector<int> prev(tl + 1), cur(tl + 1);
+  const int pbf = f.endsfree ? f.pbf : 0, pef = f.endsfree ? f.pef : 0;
+  const int tbf = f.endsfree ? f.tbf : 0, tef = f.endsfree ? f.tef : 0;
+  int best = 1 << 30;
+  for (int j = 0; j <= tl; ++j) prev[j] = j <= tbf ? 0 : j - tbf;
+  auto endcheck = [&](int i, const std::vector<int>& row) {
+    if (pl - i <= pef) best = std::min(best, row[tl]);
+    if (i == pl) for (int j = 0; j <= tl; ++j) if (tl - j <= tef) best = std::min(best, row[j]);
+  };
+  endcheck(0, prev);
+  for (int i = 1; i <= pl; ++i) {
+    cur[0] = i <= pbf ? 0 : i - pbf;
+    for (int j = 1; j <= tl; ++j) {
+      int sub = prev[j - 1] + (p[i - 1] == t[j - 1] ? 0 : 1);
+      cur[j] = std::min(sub, std::min(prev[j] + 1, cur[j - 1] + 1));
+    }
+    endcheck(i, cur);
+    std::swap(prev, cur);
+  }
+  return best;
+}
+
+int dp_affine(const uint8_t* p, int pl, const uint8_t* t, int tl, int x, int o, int e, const Form& f)
+{
+  const int INF = 1 << 29;
+  const int pbf = f.endsfree ? f.pbf : 0, pef = f.endsfree ? f.pef : 0;
+  const int tbf = f.endsfree ? f.tbf : 0, tef = f.endsfree ? f.tef : 0;
+  /* H: best ending in match/mismatch state (or origin), E: ending with insertion (text gap, consumes text),
+     F: ending with deletion (consumes pattern) */
+  std::vector<int> Hp(tl + 1), Ep(tl + 1), Fp(tl + 1), Hc(tl + 1), Ec(tl + 1), Fc(tl + 1);
+  int best = INF;
+  auto cell_best = [&](int h, int ee, int ff) { return std::min(h, std::min(ee, ff)); };
+  for (int j = 0; j <= tl; ++j) {
+    Fp[j] = INF;
+    if (j == 0) { Hp[j] = 0; Ep[j] = INF; }
+    else if (j <= tbf) { Hp[j] = 0; Ep[j] = INF; }
+    else { Hp[j] = INF; Ep[j] = std::min(Ep[j - 1] + e, Hp[j - 1] + o + e); }
+  }
+  auto endcheck = [&](int i, std::vector<int>& H, std::vector<int>& E, std::vector<int>& F) {
+    if (pl - i <= pef) best = std::min(best, cell_best(H[tl], E[tl], F[tl]));
+    if (i == pl) for (int j = 0; j <= tl; ++j) if (tl - j <= tef) best = std::min(best, cell_best(H[j], E[j], F[j]));
+  };
+  endcheck(0, Hp, Ep, Fp);
+  for (int i = 1; i <= pl; ++i) {
+    Ec[0] = INF;
+    if (i <= pbf) { Hc[0] = 0; Fc[0] = INF; }
+    else { Hc[0] = INF; Fc[0] = std::min(Fp[0] + e, Hp[0] + o + e); }
+    for (int j = 1; j <= tl; ++j) {
+      int bp = cell_best(Hp[j - 1], Ep[j - 1], Fp[j - 1]);
+      Hc[j] = bp + (p[i - 1] == t[j - 1] ? 0 : x);
+      int bl = std::min(Hc[j - 1], Fc[j - 1]);
+      Ec[j] = std::min(Ec[j - 1] + e, bl + o + e);
+      int bu = std::min(Hp[j], Ep[j]);
+      Fc[j] = std::min(Fp[j] + e, bu + o + e);
+    }
+    endcheck(i, Hc, Ec, Fc);
+    std::swap(Hp, Hc); std::swap(Ep, Ec); std::swap(Fp, Fc);
+  }
+  return best;
+}
+
+/* Re-score an op string (validity check): returns penalty, or -1 if it does not consume both
+ * sequences exactly / M,X disagree with the bytes.  Leading/trailing gap runs are free up to the form's
+ * allowances. */
+int cigar_score(const uint8_t* p, int pl, const uint8_t* t, int tl, int x, int o, int e, const Form& f,
+                const char* cig, int n)
+{
+  int a = 0, b = n;
+  int lead_i = 0, lead_d = 0, trail_i = 0, trail_d = 0;
+  if (f.endsfree) {
+    while (a < b && cig[a] == 'I' && lead_i < f.tbf) { ++a; ++lead_i; }
+    if (lead_i == 0) while (a < b && cig[a] == 'D' && lead_d < f.pbf) { ++a; ++lead_d; }
+    while (b > a && cig[b - 1] == 'D' && trail_d < f.pef) { --b; ++trail_d; }
+    if (trail_d == 0) while (b > a && cig[b - 1] == 'I' && trail_i < f.tef) { --b; ++trail_i; }
+  }
+  int v = lead_d, h = lead_i, sc = 0; char last = 0;
+  for (int i = a; i < b; ++i) {
+    char c = cig[i];
+    if (c == 'M') { if (v >= pl || h >= tl || p[v] != t[h]) return -1; ++v; ++h; }
+    else if (c == 'X') { if (v >= pl || h >= tl || p[v] == t[h]) return -1; ++v; ++h; sc += x; }
+    else if (c == 'I') { if (h >= tl) return -1; ++h; sc += (last == 'I') ? e : o + e; }
+    else if (c == 'D') { if (v >= pl) return -1; ++v; sc += (last == 'D') ? e : o + e; }
+    else return -1;
+    last = c;
+  }
+  v += trail_d; h += trail_i;
+  if (v != pl || h != tl) return -1;
+  return sc;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * DistMatrix (src/andistmat.cpp:8-50): condensed upper triangle, default 1.0, medoid.
+ * ------------------------------------------------------------------------------------------ */
+struct DistMatrix {
+  uint32_t n;
+  std::vector<double> values;
+  explicit DistMatrix(uint32_t _n) : n(_n) { values.resize(((size_t)n * (n - 1)) / 2, 1.0); } /* :8-11 */
+  size_t idx(uint32_t i, uint32_t j) const {                                                  /* :18-20 */
+    int a = i < j ? i : j, b = i > j ? i : j;
+    return (size_t)((static_cast<std::ptrdiff_t>(2 * n - 3 - a) * a >> 1) + b - 1);
+  }
+  void set_dist(uint32_t i, uint32_t j, double d) { values[idx(i, j)] = d; }
+  double get_dist(uint32_t i, uint32_t j) const { return values[idx(i, j)]; }
+  uint32_t get_medoid(const std::vector<uint32_t>& ind) const {                               /* :36-50 */
+    uint32_t min_i = ind.front();
+    double min_dist_sum = 100000000.0;
+    for (const auto& i : ind) {
+      double dist_sum = 0.0;
+      for (const auto& j : ind) if (i != j) dist_sum += get_dist(i, j);
+      if (dist_sum < min_dist_sum) { min_i = i; min_dist_sum = dist_sum; }
+    }
+    return min_i;
+  }
+};
+
+/* ------------------------------------------------------------------------------------------
+ * KDE (src/ankde.cpp:8-62) and otter_find_clustering_dist (src/otterclust.cpp:20-116).
+ * ------------------------------------------------------------------------------------------ */
+struct KDE {
+  double h;
+  double pi = 3.14159265358979323846;
+  const std::vector<double>* values;
+  double k(double x) const { return (1 / std::sqrt(2 * pi)) * (std::exp(-(x * x / 2))); }   /* :8-11 */
+  double k_h(double x) const { return (1 / h) * (k(x / h)); }                                 /* :13-16 */
+  double f(double x) const {                                                                 /* :18-23 */
+    double total = 0.0;
+    for (const auto& v : *values) total += k_h(x - v);
+    return total / values->size();
+  }
+};
+
+static void kde_maximas(int radius, const std::vector<double>& densities,
+                        std::vector<std::pair<int, double>>& maxs, std::vector<std::pair<int, double>>& mins)
+{ /* src/ankde.cpp:25-62 */
+  bool find_maxima = true;
+  double last_sum = 0.0;
+  int last_sum_i = 1;
+  for (int i = 1; i < (int)densities.size() - 1; ++i) {
+    double sum = 0.0;
+    sum += densities[i];
+    for (int j = 1; j < radius && (i - j) >= 0; ++j) sum += densities[i - j];
+    for (int j = 1; j < radius && (i + j) < (int)densities.size(); ++j) sum += densities[i + j];
+    if (find_maxima) {
+      if (sum < last_sum) { find_maxima = false; maxs.emplace_back(std::make_pair(last_sum_i, last_sum)); }
+    } else {
+      if (sum > last_sum) { find_maxima = true; mins.emplace_back(std::make_pair(last_sum_i, last_sum)); }
+    }
+    last_sum = sum;
+    last_sum_i = i;
+  }
+  if (find_maxima) maxs.emplace_back(std::make_pair(last_sum_i, last_sum));
+}
+
+struct DecisionBound { double dist0, dist1, cut0; int err; };
+
+static DecisionBound find_clustering_dist(int radius, double dinterval, double bandwidth,
+                                          const std::vector<double>& dvalues, std::vector<double>* dens_out)
+{ /* src/otterclust.cpp:20-116 */
+  KDE kde; kde.h = bandwidth; kde.values = &dvalues;
+  std::vector<double> densities;
+  for (double x = 0.0; x <= 1.0; x += dinterval) densities.emplace_back(kde.f(x));
+  double total = 0.0;
+  for (const auto& d : densities) total += d;
+  for (int i = 0; i < (int)densities.size(); ++i) densities[i] = densities[i] / total;
+  if (dens_out) *dens_out = densities;
+  std::vector<std::pair<int, double>> maximas, minimas;
+  kde_maximas(radius, densities, maximas, minimas);
+  if (maximas.empty()) return DecisionBound{0, 0, 0, 1};                                       /* :39-42 exit(1) */
+  if (maximas.size() == 1) return DecisionBound{maximas[0].first * dinterval, maximas[0].first * dinterval, -1.0, 0};
+  if (minimas.empty()) return DecisionBound{0, 0, 0, 2};                                       /* :53-56 */
+  if (maximas.size() == 2)
+    return DecisionBound{maximas[0].first * dinterval, maximas[1].first * dinterval, minimas[0].first * dinterval, 0};
+  std::vector<int> sorted_maximas(maximas.size());
+  for (int i = 0; i < (int)sorted_maximas.size(); ++i) sorted_maximas[i] = i;
+  std::sort(sorted_maximas.begin(), sorted_maximas.end(), [&maximas](const int& a, const int& b) {   /* :61-66 */
+    double diff = maximas[a].second - maximas[b].second;
+    diff = diff > 0 ? diff : -diff;
+    if (diff <= 0.01) return maximas[a].first < maximas[b].first;
+    else return maximas[a].second > maximas[b].second;
+  });
+  int last_i = 0, acc_i = 1;                                                                   /* :73-87 */
+  while (acc_i < (int)sorted_maximas.size()) {
+    int index_diff = acc_i > last_i ? acc_i - last_i : last_i - acc_i;
+    double f_diff = maximas[sorted_maximas[acc_i]].second - maximas[sorted_maximas[last_i]].second;
+    f_diff = f_diff < 0 ? -f_diff : f_diff;
+    if (index_diff == 1 && f_diff <= 0.01) {
+      sorted_maximas.erase(sorted_maximas.begin() + acc_i);
+      last_i = acc_i;
+    }
+    ++acc_i;
+  }
+  if (sorted_maximas.size() < 2)
+    return DecisionBound{maximas[0].first * dinterval, maximas[1].first * dinterval, minimas[0].first * dinterval, 0};
+  int m_first_i = sorted_maximas[0], m_second_i = sorted_maximas[1];
+  if (m_first_i > m_second_i) std::swap(m_first_i, m_second_i);
+  int boundary_i = m_second_i - 1;
+  if (boundary_i < 0 || boundary_i >= (int)minimas.size()) return DecisionBound{0, 0, 0, 3};   /* :99-102 */
+  if (m_second_i - m_first_i > 1 && m_second_i - 2 >= 0 &&
+      (maximas[m_second_i].first * dinterval - minimas[boundary_i].first * dinterval <= 0.01)) {
+    boundary_i = m_second_i - 2;
+    if (boundary_i < 0 || boundary_i >= (int)minimas.size()) return DecisionBound{0, 0, 0, 4};
+  }
+  return DecisionBound{maximas[m_first_i].first * dinterval, maximas[m_second_i].first * dinterval,
+                       minimas[m_first_i + (m_second_i - m_first_i) / 2].first * dinterval, 0};  /* :112 */
+}
+
+/* ------------------------------------------------------------------------------------------
+ * hclust-cpp: NN_chain_core<AVERAGE> (include/hclust-cpp/fastcluster_dm.hpp:563-766),
+ * generate_R_dendrogram<false> (fastcluster_R_dm.hpp:68-115), cutree_k / cutree_cdist
+ * (fastcluster.cpp:33-105).
+ * ------------------------------------------------------------------------------------------ */
+struct HNode { int node1, node2; double dist; };
+
+static void hclust_average(int N, double* D, int* merge, double* height)
+{
+#define D_(r_, c_) (D[(static_cast<std::ptrdiff_t>(2 * N - 3 - (r_)) * (r_) >> 1) + (c_)-1])
+  std::vector<int> NN_chain(N), succ(N + 1), pred(N + 1);
+  std::vector<double> members(N, 1.0);
+  std::vector<HNode> Z;
+  Z.reserve(N - 1);
+  int start = 0;
+  for (int i = 0; i < N; ++i) { pred[i + 1] = i; succ[i] = i + 1; }
+  auto remove_node = [&](int idx) {
+    if (idx == start) start = succ[idx];
+    else { succ[pred[idx]] = succ[idx]; pred[succ[idx]] = pred[idx]; }
+    succ[idx] = 0;
+  };
+  int NN_chain_tip = 0, idx1 = 0, idx2 = 0, i;
+  double size1, size2, min = 0;
+  for (int j = 0; j < N - 1; ++j) {
+    if (NN_chain_tip <= 3) {
+      NN_chain[0] = idx1 = start;
+      NN_chain_tip = 1;
+      idx2 = succ[idx1];
+      min = D_(idx1, idx2);
+      for (i = succ[idx2]; i < N; i = succ[i]) {
+        if (D_(idx1, i) < min) { min = D_(idx1, i); idx2 = i; }
+      }
+    } else {
+      NN_chain_tip -= 3;
+      idx1 = NN_chain[NN_chain_tip - 1];
+      idx2 = NN_chain[NN_chain_tip];
+      min = idx1 < idx2 ? D_(idx1, idx2) : D_(idx2, idx1);
+    }
+    do {
+      NN_chain[NN_chain_tip] = idx2;
+      for (i = start; i < idx2; i = succ[i]) {
+        if (D_(i, idx2) < min) { min = D_(i, idx2); idx1 = i; }
+      }
+      for (i = succ[idx2]; i < N; i = succ[i]) {
+        if (D_(idx2, i) < min) { min = D_(idx2, i); idx1 = i; }
+      }
+      idx2 = idx1;
+      idx1 = NN_chain[NN_chain_tip++];
+    } while (idx2 != NN_chain[NN_chain_tip - 2]);
+    Z.push_back(HNode{idx1, idx2, min});
+    if (idx1 > idx2) std::swap(idx1, idx2);
+    size1 = members[idx1]; size2 = members[idx2];
+    members[idx2] += members[idx1];
+    remove_node(idx1);
+    double s = size1 / (size1 + size2), t = size2 / (size1 + size2);
+    for (i = start; i < idx1; i = succ[i]) D_(i, idx2) = s * D_(i, idx1) + t * D_(i, idx2);
+    for (; i < idx2; i = succ[i]) D_(i, idx2) = s * D_(idx1, i) + t * D_(i, idx2);
+    for (i = succ[idx2]; i < N; i = succ[i]) D_(idx2, i) = s * D_(idx1, i) + t * D_(idx2, i);
+  }
+#undef D_
+  /* generate_R_dendrogram<false> */
+  std::stable_sort(Z.begin(), Z.end(), [](const HNode& a, const HNode& b) { return a.dist < b.dist; });
+  std::vector<int> parent(2 * N - 1, 0);
+  int nextparent = N;
+  auto Find = [&](int idx) {
+    if (parent[idx] != 0) {
+      int p = idx;
+      idx = parent[idx];
+      if (parent[idx] != 0) {
+        do { idx = parent[idx]; } while (parent[idx] != 0);
+        do { int tmp = parent[p]; parent[p] = idx; p = tmp; } while (parent[p] != idx);
+      }
+    }
+    return idx;
+  };
+  for (int k = 0; k < N - 1; ++k) {
+    int node1 = Find(Z[k].node1), node2 = Find(Z[k].node2);
+    parent[node1] = parent[node2] = nextparent++;
+    if (node1 > node2) std::swap(node1, node2);
+    merge[k] = (node1 < N) ? -node1 - 1 : node1 - N + 1;
+    merge[k + N - 1] = (node2 < N) ? -node2 - 1 : node2 - N + 1;
+    height[k] = Z[k].dist;
+  }
+}
+
+static void cutree_k(int n, const int* merge, int nclust, int* labels)
+{ /* fastcluster.cpp:33-81 */
+  int k, m1, m2, j, l;
+  if (nclust > n || nclust < 2) { for (j = 0; j < n; j++) labels[j] = 0; return; }
+  std::vector<int> last_merge(n, 0);
+  for (k = 1; k <= (n - nclust); k++) {
+    m1 = merge[k - 1];
+    m2 = merge[n - 1 + k - 1];
+    if (m1 < 0 && m2 < 0) { last_merge[-m1 - 1] = last_merge[-m2 - 1] = k; }
+    else if (m1 < 0 || m2 < 0) {
+      if (m1 < 0) { j = -m1; m1 = m2; } else j = -m2;
+      for (l = 0; l < n; l++) if (last_merge[l] == m1) last_merge[l] = k;
+      last_merge[j - 1] = k;
+    } else {
+      for (l = 0; l < n; l++) if (last_merge[l] == m1 || last_merge[l] == m2) last_merge[l] = k;
+    }
+  }
+  int label = 0;
+  std::vector<int> z(n, -1);
+  for (j = 0; j < n; j++) {
+    if (last_merge[j] == 0) labels[j] = label++;
+    else {
+      if (z[last_merge[j]] < 0) z[last_merge[j]] = label++;
+      labels[j] = z[last_merge[j]];
+    }
+  }
+}
+
+static void cutree_cdist(int n, const int* merge, const double* height, double cdist, int* labels)
+{ /* fastcluster.cpp:95-105 */
+  int k;
+  for (k = 0; k < (n - 1); k++) if (height[k] >= cdist) break;
+  cutree_k(n, merge, n - k, labels);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * otter_hclust (src/otterclust.cpp:118-320).  lens[i] = reads[indeces[i]].seq.size().
+ * Returns 0, or >0 where the reference would exit(1).
+ * ------------------------------------------------------------------------------------------ */
+struct Clustering { int ic = 0, fc = 0; std::vector<int> labels; double b0 = NAN, b1 = NAN, bc = NAN; };
+
+static int otter_hclust(const otg_params& P, const std::vector<uint32_t>& lens, const DistMatrix& dm, Clustering& cl)
+{
+  const int n = (int)lens.size();
+  cl.labels.assign(n, -1);
+  if (n == 1) { cl.labels[0] = 0; cl.ic = cl.fc = 1; return 0; }
+  if (n == 2) {
+    cl.labels[0] = cl.labels[1] = 0;
+    if (P.max_alleles == 1) { cl.ic = cl.fc = 1; }
+    else {
+      double dist = dm.get_dist(0, 1);
+      if (dist <= P.max_error) { cl.ic = cl.fc = 1; }
+      else { cl.labels[1] = 1; cl.ic = cl.fc = 2; }
+    }
+    return 0;
+  }
+  if (P.max_alleles == 1) { std::fill(cl.labels.begin(), cl.labels.end(), 0); cl.ic = cl.fc = 1; return 0; }
+  const double error_intervals = 0.0025;
+  int radius = int(P.max_error / error_intervals);
+  radius = radius < 1 ? 1 : radius;
+  double bandwidth = P.bandwidth_short;
+  for (int i = 0; i < n; ++i) if ((int)lens[i] >= P.bandwidth_length) { bandwidth = P.bandwidth_long; break; }
+  DecisionBound dists = find_clustering_dist(radius, error_intervals, bandwidth, dm.values, nullptr);
+  if (dists.err) return dists.err;
+  cl.b0 = dists.dist0; cl.b1 = dists.dist1; cl.bc = dists.cut0;
+  if (dists.dist1 - dists.dist0 <= P.max_error) { std::fill(cl.labels.begin(), cl.labels.end(), 0); cl.ic = cl.fc = 1; return 0; }
+  std::vector<int> labels(n), merge(2 * (n - 1));
+  std::vector<double> height(n - 1);
+  std::vector<double> cpy = dm.values;
+  hclust_average(n, cpy.data(), merge.data(), height.data());
+  double dist_final = dists.dist1 == bandwidth ? dists.dist1 : dists.cut0 + 0.0025;             /* :184 */
+  cutree_cdist(n, merge.data(), height.data(), dist_final, labels.data());
+  int total_alleles = 0;
+  for (int i = 0; i < n; ++i) if (labels[i] > total_alleles) total_alleles = labels[i];
+  ++total_alleles;
+  cl.ic = total_alleles;
+  int min_cov1 = int(n * P.min_cov_fraction + 0.5);
+  int min_cov2 = int(n * P.min_cov_fraction2_f + 0.5);
+  if (P.max_alleles != 0) {
+    std::vector<int> label_counts(total_alleles), label_max_sizes(total_alleles), label_required_covs(total_alleles);
+    for (int i = 0; i < n; ++i) {
+      ++label_counts[labels[i]];
+      if ((int)lens[i] > label_max_sizes[labels[i]]) label_max_sizes[labels[i]] = lens[i];
+    }
+    for (int l = 0; l < total_alleles; ++l) {
+      if (label_max_sizes[l] < P.min_cov_fraction2_l) label_required_covs[l] = min_cov1;
+      else label_required_covs[l] = min_cov2;
+    }
+    bool is_only_singletons = true;
+    for (int l = 0; l < total_alleles; ++l) if (label_counts[l] >= label_required_covs[l]) { is_only_singletons = false; break; }
+    if (is_only_singletons) {
+      std::vector<int> labels2(n);
+      cutree_k(n, merge.data(), P.max_alleles, labels2.data());
+      cl.fc = P.max_alleles;
+      labels = labels2;
+    } else {
+      int outlier_clusters_n = 0, seed_clusters_n = 0;
+      for (int l = 0; l < total_alleles; ++l) { if (label_counts[l] < label_required_covs[l]) ++outlier_clusters_n; else ++seed_clusters_n; }
+      if (seed_clusters_n == 0 || seed_clusters_n > P.max_alleles) {
+        cutree_k(n, merge.data(), P.max_alleles, labels.data());
+        cl.fc = P.max_alleles;
+      } else {
+        std::vector<int> outlier_clusters, seed_clusters;
+        for (int l = 0; l < total_alleles; ++l) { if (label_counts[l] < label_required_covs[l]) outlier_clusters.push_back(l); else seed_clusters.push_back(l); }
+        for (int i = 0; i < n; ++i) for (int ol : outlier_clusters) if (labels[i] == ol) { labels[i] = -1; break; }
+        for (int i = 0; i < n; ++i) for (int j = 0; j < (int)seed_clusters.size(); ++j) if (labels[i] == seed_clusters[j]) { labels[i] = j; break; }
+        for (int i = 0; i < n; ++i) {
+          if (labels[i] == -1) {
+            int closest_j = 0;
+            double min_dist = 100000.0;
+            for (int j = 0; j < n; ++j) {
+              if (i != j && labels[j] != -1) {
+                double j_dist = dm.get_dist(i, j);
+                if (j_dist < min_dist) { closest_j = j; min_dist = j_dist; }
+              }
+            }
+            labels[i] = labels[closest_j];
+          }
+        }
+        cl.fc = seed_clusters_n;
+      }
+    }
+  }
+  for (int i = 0; i < n; ++i) cl.labels[i] = labels[i];
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * PPOA (src/anppoa.hpp:64-380) — same graph, same ids, O(N+E) heaviest path with the reference's
+ * three tie-breaks (incoming scan order = source id asc then insertion order :259-263; strict '>'
+ * :278; lowest-id ending node on equal weight :356-367).
+ * ------------------------------------------------------------------------------------------ */
+struct PEdge { uint32_t source, sink; float weight; };
+struct PPOA {
+  std::string backbone;
+  std::vector<char> nodes;      /* '\0' = empty string (uninitialised backbone node) */
+  std::vector<std::vector<PEdge>> edges;
+  uint32_t last_id = 0;
+  std::vector<uint32_t> starting_nodes;
+  std::set<uint32_t> ending_nodes;
+
+  void insert_node(uint32_t id, char c) {                                                     /* :86-94 */
+    if (id < last_id) nodes[id] = c;
+    else { nodes.push_back(c); edges.emplace_back(); last_id = id + 1; }
+  }
+  void insert_edge(uint32_t source, uint32_t sink) {                                          /* :96-110 */
+    auto& le = edges[source];
+    for (auto& ed : le) if (ed.sink == sink) { ed.weight += 1.0f; return; }
+    le.push_back(PEdge{source, sink, 1.0f});
+  }
+  void init(const std::string& b) {                                                           /* :64-84 */
+    backbone = b;
+    nodes.assign(b.size(), 0);
+    edges.assign(b.size(), {});
+    last_id = b.size();
+    for (uint32_t i = 1; i < b.size(); ++i) {
+      if (i == 1) { insert_node(0, b[0]); starting_nodes.push_back(0); }
+      insert_node(i, b[i]);
+      insert_edge(i - 1, i);
+      if (b.size() - i <= 10) ending_nodes.insert(i);
+    }
+  }
+  void insert_alignment(const std::string& sequence, const std::string& cigar, bool spl, bool spr) { /* :112-241 */
+    int previous_node = 0, ref_i = 0, target_i = 0, cigar_i = 0;
+    bool is_first_node = true;
+    const int bsz = (int)backbone.size();
+    if (!spl) {
+      is_first_node = false;
+      while (cigar_i < (int)cigar.size()) {
+        char c = cigar[cigar_i];
+        if (c != 'D' && c != 'I') break;
+        if (c == 'D') { ++ref_i; previous_node = ref_i; }
+        else ++target_i;
+        ++cigar_i;
+      }
+    }
+    while (cigar_i < (int)cigar.size()) {
+      char c = cigar[cigar_i];
+      char tc = target_i < (int)sequence.size() ? sequence[target_i] : 0;
+      if (c == 'M' || c == 'X') {
+        if (c == 'M') {
+          if (is_first_node || previous_node == ref_i) is_first_node = false;
+          else insert_edge(previous_node, ref_i);
+          previous_node = ref_i;
+        } else {
+          if (is_first_node) {
+            bool need_new = true;
+            for (auto nd : starting_nodes) if (nodes[nd] == tc) { need_new = false; break; }
+            if (need_new) { insert_node(last_id, tc); previous_node = last_id - 1; starting_nodes.push_back(previous_node); }
+            is_first_node = false;
+          } else {
+            auto& og = edges[previous_node];
+            int mi = -1;
+            for (int i = 0; i < (int)og.size(); ++i) if (nodes[og[i].sink] == tc && (int)og[i].sink >= bsz) { mi = i; break; }
+            if (mi >= 0) { og[mi].weight += 1.0f; previous_node = og[mi].sink; }
+            else { uint32_t nn = last_id; insert_node(nn, tc); insert_edge(previous_node, nn); previous_node = nn; }
+          }
+        }
+        ++ref_i; ++target_i;
+      }
+      if (c == 'D') {
+        if (!is_first_node) ++ref_i;
+        else { ++ref_i; previous_node = ref_i; }
+      } else if (c == 'I') {
+        if (is_first_node) {
+          insert_node(last_id, tc); previous_node = last_id - 1; starting_nodes.push_back(previous_node); is_first_node = false;
+        } else {
+          auto& og = edges[previous_node];
+          int mi = -1;
+          for (int i = 0; i < (int)og.size(); ++i) if ((int)og[i].sink >= bsz && nodes[og[i].sink] == tc) { mi = i; break; }
+          if (mi >= 0) { og[mi].weight += 1.0f; previous_node = og[mi].sink; }
+          else { uint32_t nn = last_id; insert_node(nn, tc); insert_edge(previous_node, nn); previous_node = nn; }
+        }
+        ++target_i;
+      }
+      if (bsz - ref_i <= 10 && spr) ending_nodes.insert(previous_node);
+      ++cigar_i;
+    }
+  }
+  void adjust_weights(float c, float t) {                                                     /* :243-252 */
+    for (auto& le : edges) for (auto& ed : le) {
+      float t_applied = t * ed.weight;
+      float final_weight = c > t_applied ? c : t_applied;
+      ed.weight = ed.weight - final_weight;
+    }
+  }
+  void consensus(std::string& out) const {                                                    /* :254-380 */
+    const uint32_t N = nodes.size();
+    /* incoming edges in the reference's scan order: by source id, then insertion order */
+    std::vector<uint32_t> indeg(N, 0);
+    for (uint32_t s = 0; s < N; ++s) for (auto& ed : edges[s]) ++indeg[ed.sink];
+    std::vector<uint32_t> instart(N + 1, 0);
+    for (uint32_t i = 0; i < N; ++i) instart[i + 1] = instart[i] + indeg[i];
+    std::vector<PEdge> inc(instart[N]);
+    { std::vector<uint32_t> pos(instart.begin(), instart.end() - 1);
+      for (uint32_t s = 0; s < N; ++s) for (auto& ed : edges[s]) inc[pos[ed.sink]++] = ed; }
+    /* Kahn order; result is order-independent (each node's value depends only on its sources) */
+    std::vector<uint32_t> remaining(indeg), order;
+    order.reserve(N);
+    for (uint32_t i = 0; i < N; ++i) if (!remaining[i]) order.push_back(i);
+    for (size_t q = 0; q < order.size(); ++q) for (auto& ed : edges[order[q]]) if (--remaining[ed.sink] == 0) order.push_back(ed.sink);
+    std::vector<float> hw(N, 0.0f);
+    std::vector<int64_t> pred(N, -1);
+    for (uint32_t nd : order) {
+      bool not_h_defined = true;
+      float h_weight = 0.0f;
+      for (uint32_t q = instart[nd]; q < instart[nd + 1]; ++q) {
+        const PEdge& ed = inc[q];
+        float cand = hw[ed.source] + ed.weight;
+        if (not_h_defined || cand > h_weight) { not_h_defined = false; h_weight = cand; pred[nd] = ed.source; }
+      }
+      hw[nd] = h_weight;
+    }
+    uint32_t h_node = 0; bool not_init = true; float best = 0.0f;
+    for (uint32_t nd = 0; nd < N; ++nd) {
+      if (ending_nodes.count(nd)) {
+        if (not_init || hw[nd] > best) { not_init = false; h_node = nd; best = hw[nd]; }
+      }
+    }
+    std::string rev;
+    if (N == 0) return;
+    int64_t cur = h_node;
+    while (cur >= 0) { if (nodes[cur]) rev.push_back(nodes[cur]); cur = pred[cur]; }
+    out.append(rev.rbegin(), rev.rend());
+  }
+};
+
+/* ------------------------------------------------------------------------------------------
+ * Region-level restatement: align_anreads / get_dist_anreads (src/analignments.cpp:62-115),
+ * fill_dist_matrix (:117-124), invalid_reassignment (:126-177), compute_se (:179-190),
+ * rapid_consensus (:192-298), local_realignment (:11-60), and the region loop body of
+ * assemble_process (src/assemble.cpp:71-150).
+ * ------------------------------------------------------------------------------------------ */
+struct Read {
+  std::string seq;
+  bool spl, spr;
+  int ps, hp;
+  int cc1, cc2;
+  bool spanning() const { return spl && spr; }
+  bool hap_defined() const { return ps >= 0 && hp >= 0; }
+};
+
+struct Stats { uint64_t edit_tasks = 0, edit_cells = 0, edit_bytes = 0, aff_tasks = 0, aff_cells = 0, aff_bytes = 0; };
+
+static int edit_call(const std::string& pat, const std::string& txt, const Form& f, Stats* st)
+{
+  uint64_t c = 0;
+  int s = wfa_edit((const uint8_t*)pat.data(), pat.size(), (const uint8_t*)txt.data(), txt.size(), f, &c);
+  if (st) { st->edit_tasks++; st->edit_cells += c; st->edit_bytes += pat.size() + txt.size(); }
+  return s;
+}
+
+static double align_anreads(const Read& x, const Read& y, Stats* st)
+{ /* src/analignments.cpp:62-101 */
+  const Form e2e{0, 0, 0, 0, 0};
+  if (x.seq == y.seq) return 0.0;
+  else if ((x.spanning() && y.spanning()) || (y.spanning() && x.seq.size() >= y.seq.size())) {
+    bool x_is_smallest = x.seq.size() < y.seq.size();
+    double largest = x_is_smallest ? (double)y.seq.size() : (double)x.seq.size();
+    int dist = x_is_smallest ? edit_call(y.seq, x.seq, e2e, st) : edit_call(x.seq, y.seq, e2e, st);
+    return dist / largest;
+  } else if (y.spanning()) {
+    int length_diff = (int)y.seq.size() - (int)x.seq.size();
+    /* :86-92 unreachable (length_diff < 0 is caught above) */
+    Form f{1, 0, 0, 0, 0};
+    if (x.spl) { f.pbf = 0; f.pef = length_diff; }
+    else if (x.spr) { f.pbf = length_diff; f.pef = 0; }
+    else { f.pbf = length_diff / 2; f.pef = length_diff / 2; }
+    int sc = edit_call(y.seq, x.seq, f, st);
+    return sc / (double)x.seq.size();
+  } else return -1.0;
+}
+
+static double get_dist_anreads(bool ignore_haps, const Read& x, const Read& y, Stats* st)
+{ /* :103-115 */
+  if (ignore_haps) return align_anreads(x, y, st);
+  if (x.hap_defined() && y.hap_defined()) return (x.ps == y.ps && x.hp == y.hp) ? 0 : 1.0;
+  return 1.0;
+}
+
+static double compute_se(const std::vector<double>& values)
+{ /* :179-190 */
+  if (values.empty()) return -1.0;
+  double u = 0.0, n = 0.0;
+  for (const auto& v : values) u += v;
+  u /= values.size();
+  for (const auto& v : values) n += (v - u) * (v - u); /* std::pow(v-u, 2.0) is folded to x*x by g++ -O2 */
+  return std::sqrt(n / (values.size() - 1)) / std::sqrt(values.size());
+}
+
+struct Allele { std::string seq; int scov = 0, acov = 0, tcov = 0; float se = 0; int ic = 0, ps = -1, hp = -1; };
+
+static void local_realignment(const otg_params& P, std::vector<Read>& reads, const std::string& ref_left,
+                              const std::string& ref_right, Stats* st)
+{ /* src/analignments.cpp:11-60 (reference flanks are fetched by the caller) */
+  for (auto& r : reads) {
+    if (!r.spanning() && (r.spl || r.spr)) {
+      bool left_re = r.spr && r.cc1 >= P.flank;
+      bool right_re = r.spl && (int)r.seq.size() - r.cc2 >= P.flank;
+      std::string subseq, cig;
+      const Form e2e{0, 0, 0, 0, 0};
+      if (left_re) {
+        subseq = r.seq.substr(0, r.cc1);
+        uint64_t c = 0;
+        wfa_affine((const uint8_t*)subseq.data(), subseq.size(), (const uint8_t*)ref_left.data(), ref_left.size(),
+                   P.mismatch, P.gap_open, P.gap_ext, e2e, &cig, &c);
+        if (st) { st->aff_tasks++; st->aff_cells += c; st->aff_bytes += subseq.size() + ref_left.size(); }
+      } else if (right_re) {
+        subseq = r.seq.substr(r.cc2);
+        uint64_t c = 0;
+        wfa_affine((const uint8_t*)subseq.data(), subseq.size(), (const uint8_t*)ref_right.data(), ref_right.size(),
+                   P.mismatch, P.gap_open, P.gap_ext, e2e, &cig, &c);
+        if (st) { st->aff_tasks++; st->aff_cells += c; st->aff_bytes += subseq.size() + ref_right.size(); }
+      }
+      if (!subseq.empty()) {
+        std::vector<int> scores(subseq.size(), 0);
+        int j = 0;
+        for (char op : cig) {
+          if (op != 'I') {
+            int penalty = op == 'M' ? 1 : -1;
+            if (penalty > 0) { if (j == 0) scores[j] = penalty; else scores[j] = scores[j - 1] + penalty; }
+            else if (j > 0 && scores[j - 1] > 0) scores[j] = scores[j - 1] + penalty;
+            ++j;
+          }
+        }
+        int max_sum_i = 0;
+        for (j = 0; j < (int)scores.size(); ++j) if (scores[j] > scores[max_sum_i]) max_sum_i = j;
+        int start_i = max_sum_i;
+        while (start_i > 0 && scores[start_i] > 0) --start_i;
+        if ((scores[max_sum_i] / (double)P.flank) >= P.min_sim) {
+          if (left_re) r.seq = r.seq.substr(max_sum_i);
+          else if (right_re) r.seq = r.seq.substr(0, r.cc2 + start_i);
+          r.spl = r.spr = true;
+        }
+      }
+    }
+  }
+}
+
+struct RegionOut {
+  int status = OTG_REGION_OK;
+  int ic = 0, fc = 0, n_valid = 0;
+  std::vector<Allele> alleles;
+  std::vector<int> labels;
+  std::vector<double> dist;    /* condensed matrix of the valid reads (debug / golden) */
+  double b0 = NAN, b1 = NAN, bc = NAN;
+};
+
+static void partition_valid_reads(bool ignore_haps, const std::vector<Read>& reads, std::vector<int>& valid, std::vector<int>& invalid)
+{ /* src/assemble.cpp:27-37 */
+  for (int i = 0; i < (int)reads.size(); ++i) {
+    if (!reads[i].spanning()) invalid.push_back(i);
+    else {
+      if (ignore_haps) valid.push_back(i);
+      else if (reads[i].hap_defined()) valid.push_back(i);
+      else invalid.push_back(i);
+    }
+  }
+}
+
+static int assemble_region(const otg_params& P, std::vector<Read>& reads, const std::string& fl, const std::string& fr,
+                           RegionOut& out, Stats* st)
+{ /* src/assemble.cpp:71-150 */
+  out.labels.assign(reads.size(), -1);
+  if (reads.empty()) { out.status = OTG_REGION_EMPTY; return 0; }
+  if ((int)reads.size() > P.max_cov) { out.status = OTG_REGION_SKIP_MAXCOV; return 0; }
+  if (P.realign) local_realignment(P, reads, fl, fr, st);
+  uint32_t spanning_reads = 0;
+  for (auto& r : reads) if (r.spanning()) ++spanning_reads;
+  if (spanning_reads == 0) { out.status = OTG_REGION_NO_SPANNING; return 0; }
+  bool local_ignore_haps = P.ignore_haps != 0;
+  std::vector<int> valid, invalid;
+  partition_valid_reads(local_ignore_haps, reads, valid, invalid);
+  if (valid.size() < 2) {
+    local_ignore_haps = true;
+    valid.clear(); invalid.clear();
+    partition_valid_reads(local_ignore_haps, reads, valid, invalid);
+  }
+  if (valid.empty()) { out.status = OTG_REGION_NO_SPANNING; return 0; }
+  out.n_valid = valid.size();
+  DistMatrix dm(valid.size());
+  if (P.max_alleles != 1) {                                                    /* fill_dist_matrix :117-124 */
+    for (uint32_t i = 0; i < valid.size(); ++i)
+      for (uint32_t j = i + 1; j < valid.size(); ++j)
+        dm.set_dist(i, j, get_dist_anreads(local_ignore_haps, reads[valid[i]], reads[valid[j]], st));
+  }
+  out.dist = dm.values;
+  Clustering cl;
+  std::vector<uint32_t> lens(valid.size());
+  for (size_t i = 0; i < valid.size(); ++i) lens[i] = reads[valid[i]].seq.size();
+  int err = otter_hclust(P, lens, dm, cl);
+  if (err) return OTG_ERR_FATAL;
+  out.ic = cl.ic; out.fc = cl.fc; out.b0 = cl.b0; out.b1 = cl.b1; out.bc = cl.bc;
+  std::vector<int>& labels = out.labels;
+  for (uint32_t i = 0; i < cl.labels.size(); ++i) labels[valid[i]] = cl.labels[i];
+  const int total_alleles = cl.fc;
+  if (!invalid.empty()) {                                                      /* invalid_reassignment :126-177 */
+    for (int i = 0; i < (int)labels.size(); ++i) {
+      if (labels[i] < 0) {
+        std::vector<double> max_sim(total_alleles, 0.0);
+        for (int j = 0; j < (int)labels.size(); ++j) {
+          if (i != j && labels[j] >= 0 && reads[j].spanning()) {
+            double dist = get_dist_anreads(true, reads[i], reads[j], st);
+            if (dist < 0) return OTG_ERR_FATAL;
+            double sim = 1 - dist;
+            if (sim > max_sim[labels[j]]) max_sim[labels[j]] = sim;
+          }
+        }
+        if (total_alleles == 0) continue;
+        int max_sim_label = 0;
+        for (int j = 1; j < total_alleles; ++j) if (max_sim[j] > max_sim[max_sim_label]) max_sim_label = j;
+        int same_max_sim = 0;
+        for (const auto& s : max_sim) if (s == max_sim[max_sim_label]) ++same_max_sim;
+        if (same_max_sim == 1) {
+          if (max_sim[max_sim_label] >= P.min_sim) {
+            double min_diff = 1.0;
+            for (int j = 0; j < total_alleles; ++j) if (max_sim_label != j) {
+              double diff = max_sim[max_sim_label] - max_sim[j];
+              if (diff < min_diff) min_diff = diff;
+            }
+            if (min_diff >= P.max_error) labels[i] = max_sim_label;
+          }
+        }
+      }
+    }
+  }
+  /* rapid_consensus :192-298 */
+  out.alleles.assign(total_alleles, Allele());
+  for (int label = 0; label < total_alleles; ++label) {
+    std::vector<uint32_t> liv_reads, liv_ind;
+    for (uint32_t i = 0; i < valid.size(); ++i) if (label == labels[valid[i]]) { liv_reads.push_back(valid[i]); liv_ind.push_back(i); }
+    if (liv_reads.empty()) return OTG_ERR_FATAL;                               /* :210-213 */
+    int rep_vi = dm.get_medoid(liv_ind);
+    int rep = valid[rep_vi];
+    std::vector<int> all;
+    for (int i = 0; i < (int)reads.size(); ++i) if (i != rep && labels[i] == label) all.push_back(i);
+    Allele& A = out.alleles[label];
+    A.tcov = reads.size(); A.acov = all.size() + 1; A.scov = liv_reads.size();
+    if (liv_ind.size() == 1) A.se = 0;
+    else if (liv_ind.size() == 2) A.se = dm.get_dist(liv_ind[0], liv_ind[1]);
+    else {
+      std::vector<double> vd;
+      for (const auto& i : liv_ind) if ((int)i != rep_vi) vd.push_back(dm.get_dist(i, rep_vi));
+      A.se = compute_se(vd);
+    }
+    int ps = -1, hp = -1; bool conflicting = false;
+    if (!local_ignore_haps) {
+      for (const auto& i : liv_reads) {
+        if (ps < 0) ps = reads[i].ps; else if (ps != reads[i].ps) conflicting = true;
+        if (hp < 0) hp = reads[i].hp; else if (hp != reads[i].hp) conflicting = true;
+      }
+    }
+    if (conflicting) { out.status = OTG_REGION_HAP_CONFLICT; out.alleles.clear(); return 0; }
+    const Read& rep_read = reads[rep];
+    if (!local_ignore_haps) { A.ps = rep_read.ps; A.hp = rep_read.hp; }
+    if (all.size() + 1 <= 2) A.seq = reads[liv_reads.front()].seq;
+    else {
+      PPOA poa;
+      poa.init(rep_read.seq);
+      std::string cigar; /* persists across members: stale-CIGAR behaviour of :267-273 is reproduced */
+      for (const auto& i : all) {
+        const Read& read = reads[i];
+        int length_diff = (int)rep_read.seq.size() - (int)read.seq.size();
+        Form f{0, 0, 0, 0, 0};
+        bool do_align = true;
+        if (read.spanning() || length_diff < 0) {
+          if (length_diff >= 0) { /* end2end */ }
+          else {
+            if (read.spl) f = Form{1, 0, 0, 0, -length_diff};
+            else if (read.spr) f = Form{1, 0, 0, -length_diff, 0};
+            else do_align = false;
+          }
+        } else {
+          if (read.spl) f = Form{1, 0, length_diff, 0, 0};
+          else if (read.spr) f = Form{1, length_diff, 0, 0, 0};
+          else f = Form{1, length_diff / 2, length_diff / 2, 0, 0};
+        }
+        if (do_align) {
+          uint64_t c = 0;
+          wfa_affine((const uint8_t*)rep_read.seq.data(), rep_read.seq.size(), (const uint8_t*)read.seq.data(), read.seq.size(),
+                     P.mismatch, P.gap_open, P.gap_ext, f, &cigar, &c);
+          if (st) { st->aff_tasks++; st->aff_cells += c; st->aff_bytes += rep_read.seq.size() + read.seq.size(); }
+        }
+        poa.insert_alignment(read.seq, cigar, read.spl, read.spr);
+      }
+      float c = (all.size() + 1) * 0.4;
+      float t = 0.3;
+      if (all.size() + 1 < 4) c = 1.0;
+      poa.adjust_weights(c, t);
+      poa.consensus(A.seq);
+      if (A.seq.empty()) A.seq = "N";
+    }
+  }
+  for (auto& A : out.alleles) A.ic = cl.ic;
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Genotype clustering: anallele_cluster (src/otterclust.cpp:463-527) with length_dist (:322-327),
+ * cluter_to_e (:329-349), remap_cluster_indeces (:351-365), KUSAGE (src/anseqs.cpp:111-147),
+ * seq2kcounts (:149-166), KmerEncoding (:171-208).
+ * ------------------------------------------------------------------------------------------ */
+static double length_dist(uint32_t x, uint32_t y)
+{
+  bool is_x_smallest = x < y;
+  double dist = is_x_smallest ? y - x : x - y;
+  return is_x_smallest ? dist / y : dist / x;
+}
+
+static void cluter_to_e(double max_error, uint32_t total, const DistMatrix& dm, std::vector<std::vector<int>>& clusters)
+{
+  std::vector<int> labels(total), merge(2 * (total - 1));
+  std::vector<double> height(total - 1), cpy = dm.values;
+  hclust_average(total, cpy.data(), merge.data(), height.data());
+  cutree_cdist(total, merge.data(), height.data(), max_error, labels.data());
+  uint32_t total_clusters = 0;
+  for (uint32_t i = 0; i < total; ++i) if (labels[i] > (int)total_clusters) total_clusters = labels[i];
+  ++total_clusters;
+  clusters.resize(total_clusters);
+  for (uint32_t l = 0; l < total_clusters; ++l) for (uint32_t i = 0; i < total; ++i) if (labels[i] == (int)l) clusters[l].push_back(i);
+}
+
+struct KUsage {
+  std::vector<double> vec; double vnorm = 0;
+  explicit KUsage(const std::vector<double>& kc) : vec(kc.size(), 0) {
+    int total_counts = 0;
+    for (const auto& k : kc) total_counts += k;
+    for (uint32_t i = 0; i < vec.size(); ++i) { double value = kc[i] / total_counts; vec[i] = value; vnorm += value * value; }
+    vnorm = std::sqrt(vnorm);
+  }
+  double cosine_sim(const KUsage& o) const {
+    double xy = 0;
+    for (uint32_t i = 0; i < vec.size(); ++i) xy += vec[i] * o.vec[i];
+    return xy / (vnorm * o.vnorm);
+  }
+  double hsdiv() const {
+    double acc = 0;
+    for (const auto& ku : vec) if (ku > 0) acc += (ku * std::log(ku));
+    acc = -1 * acc;
+    return std::pow(M_E, acc);
+  }
+};
+
+static void seq2kcounts(uint32_t k, const std::string& seq, std::vector<double>& kc)
+{
+  uint8_t enc[256];
+  for (int i = 0; i < 256; ++i) enc[i] = 4;
+  enc['A'] = enc['a'] = 0; enc['C'] = enc['c'] = 1; enc['G'] = enc['g'] = 2; enc['T'] = enc['t'] = 3;
+  uint32_t max_index = (int)std::pow(4, k);
+  kc.assign(max_index + 1, 0);
+  if (seq.size() >= k) {
+    for (uint32_t j = 0; j < seq.size() - k + 1; ++j) {
+      bool is_valid = true;
+      uint64_t idx = 0;
+      for (uint32_t h = 0; h < k; ++h) {
+        uint8_t c = enc[(uint8_t)seq[j + h]];
+        if (c == 4) { is_valid = false; break; }
+        idx = 4 * idx + c;
+      }
+      ++kc[is_valid ? idx : max_index];
+    }
+  }
+}
+
+struct Genotype { int gt = -1, gt_l = -1, gt_k = -1; double hsd = -1; };
+
+static int anallele_cluster(double max_error_l, double max_error_c, const std::vector<std::string>& alleles,
+                            std::vector<Genotype>& genotypes, std::vector<int>& gt_reps)
+{
+  const uint32_t A = alleles.size();
+  genotypes.assign(A, Genotype());
+  if (A < 2) { /* hclust on <2 observations is undefined in the reference; a single allele is its own genotype */
+    if (A == 1) { genotypes[0].gt = genotypes[0].gt_l = genotypes[0].gt_k = 0;
+      std::vector<double> kc; seq2kcounts(3, alleles[0], kc); genotypes[0].hsd = KUsage(kc).hsdiv(); gt_reps.push_back(0); }
+    return (int)A;
+  }
+  auto remap = [](const DistMatrix& dm, const std::vector<std::vector<int>>& in, std::vector<int>& medoids) {
+    for (const auto& cluster : in) {
+      if (cluster.size() <= 2) medoids.push_back(cluster[0]);
+      else { std::vector<uint32_t> tmp(cluster.begin(), cluster.end()); medoids.push_back(dm.get_medoid(tmp)); }
+    }
+  };
+  DistMatrix dl(A);
+  for (uint32_t i = 0; i < A; ++i) for (uint32_t j = i + 1; j < A; ++j) dl.set_dist(i, j, length_dist(alleles[i].size(), alleles[j].size()));
+  std::vector<std::vector<int>> lc; std::vector<int> lreps;
+  cluter_to_e(max_error_l, A, dl, lc);
+  remap(dl, lc, lreps);
+  for (uint32_t i = 0; i < lc.size(); ++i) for (int j : lc[i]) genotypes[j].gt_l = i;
+  std::vector<KUsage> ku;
+  for (uint32_t i = 0; i < A; ++i) { std::vector<double> kc; seq2kcounts(3, alleles[i], kc); ku.emplace_back(kc); }
+  DistMatrix dk(A);
+  for (int i = 0; i < (int)A; ++i) for (int j = i + 1; j < (int)A; ++j) {
+    double dist = 1.0 - ((std::isnan(ku[i].vnorm) || std::isnan(ku[j].vnorm)) ? 0 : (std::round(ku[i].cosine_sim(ku[j]) * 1000.0) / 1000.0));
+    dk.set_dist(i, j, dist);
+  }
+  std::vector<std::vector<int>> kcl; std::vector<int> kreps;
+  cluter_to_e(max_error_c, A, dk, kcl);
+  remap(dk, kcl, kreps);
+  for (uint32_t i = 0; i < kcl.size(); ++i) for (int j : kcl[i]) { genotypes[j].gt_k = i; genotypes[j].hsd = ku[j].hsdiv(); }
+  std::list<int> remaining;
+  for (int i = 0; i < (int)A; ++i) remaining.push_back(i);
+  std::vector<std::vector<int>> fin;
+  while (!remaining.empty()) {
+    int i = remaining.front();
+    fin.emplace_back();
+    auto& lc2 = fin.back();
+    auto it = remaining.begin();
+    while (it != remaining.end()) {
+      if (genotypes[i].gt_l == genotypes[*it].gt_l && genotypes[i].gt_k == genotypes[*it].gt_k) { lc2.push_back(*it); it = remaining.erase(it); }
+      else ++it;
+    }
+  }
+  for (int i = 0; i < (int)fin.size(); ++i) {
+    std::vector<uint32_t> tmp;
+    for (int j : fin[i]) { genotypes[j].gt = i; tmp.push_back(j); }
+    gt_reps.push_back((int)dl.get_medoid(tmp));
+  }
+  return (int)fin.size();
+}
+
+} // namespace oto
+
+/* =============================================================================================
+ * C entry points (ctypes-friendly).  Names mirror otg_* with the oto_ prefix.
+ * ============================================================================================= */
+extern "C" {
+
+int oto_edit_distance_batch(const uint8_t* arena, uint64_t, const otg_align_task* tasks, uint32_t n,
+                            int32_t* scores, uint64_t* cells)
+{
+  for (uint32_t i = 0; i < n; ++i) {
+    const otg_align_task& t = tasks[i];
+    oto::Form f{t.endsfree, t.pattern_begin_free, t.pattern_end_free, t.text_begin_free, t.text_end_free};
+    uint64_t c = 0;
+    scores[i] = oto::wfa_edit(arena + t.pattern_off, t.pattern_len, arena + t.text_off, t.text_len, f, &c);
+    if (cells) cells[i] = c;
+  }
+  return 0;
+}
+
+int oto_affine_align_batch(const uint8_t* arena, uint64_t, const otg_align_task* tasks, uint32_t n,
+                           int32_t x, int32_t o, int32_t e, int32_t* scores,
+                           uint64_t* cig_off, uint32_t* cig_len, uint8_t* cig_arena, uint64_t cap, uint64_t* used,
+                           uint64_t* cells)
+{
+  uint64_t pos = 0; int rc = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const otg_align_task& t = tasks[i];
+    oto::Form f{t.endsfree, t.pattern_begin_free, t.pattern_end_free, t.text_begin_free, t.text_end_free};
+    std::string cig; uint64_t c = 0;
+    scores[i] = oto::wfa_affine(arena + t.pattern_off, t.pattern_len, arena + t.text_off, t.text_len, x, o, e, f, &cig, &c);
+    if (cells) cells[i] = c;
+    cig_off[i] = pos; cig_len[i] = cig.size();
+    if (pos + cig.size() <= cap) memcpy(cig_arena + pos, cig.data(), cig.size()); else rc = OTG_ERR_CAPACITY;
+    pos += cig.size();
+  }
+  if (used) *used = pos;
+  return rc;
+}
+
+int oto_dp_edit(const uint8_t* p, int pl, const uint8_t* t, int tl, int endsfree, int pbf, int pef, int tbf, int tef)
+{ return oto::dp_edit(p, pl, t, tl, oto::Form{endsfree, pbf, pef, tbf, tef}); }
+
+int oto_dp_affine(const uint8_t* p, int pl, const uint8_t* t, int tl, int x, int o, int e, int endsfree, int pbf, int pef, int tbf, int tef)
+{ return oto::dp_affine(p, pl, t, tl, x, o, e, oto::Form{endsfree, pbf, pef, tbf, tef}); }
+
+int oto_cigar_score(const uint8_t* p, int pl, const uint8_t* t, int tl, int x, int o, int e, int endsfree, int pbf, int pef, int tbf, int tef,
+                    const char* cig, int n)
+{ return oto::cigar_score(p, pl, t, tl, x, o, e, oto::Form{endsfree, pbf, pef, tbf, tef}, cig, n); }
+
+/* KDE densities (normalised) + bound; dens_out has room for 401 doubles (nullable). returns err code */
+int oto_find_clustering_dist(int radius, double dinterval, double bandwidth, const double* values, uint64_t n,
+                             double* bounds3, double* dens_out, int* n_dens)
+{
+  std::vector<double> v(values, values + n), dens;
+  oto::DecisionBound b = oto::find_clustering_dist(radius, dinterval, bandwidth, v, &dens);
+  bounds3[0] = b.dist0; bounds3[1] = b.dist1; bounds3[2] = b.cut0;
+  if (dens_out) memcpy(dens_out, dens.data(), dens.size() * sizeof(double));
+  if (n_dens) *n_dens = dens.size();
+  return b.err;
+}
+
+int oto_kde_maximas(int radius, const double* dens, int n, int* max_i, double* max_v, int* n_max, int* min_i, double* min_v, int* n_min)
+{
+  std::vector<double> d(dens, dens + n);
+  std::vector<std::pair<int, double>> mx, mn;
+  oto::kde_maximas(radius, d, mx, mn);
+  for (size_t i = 0; i < mx.size(); ++i) { max_i[i] = mx[i].first; max_v[i] = mx[i].second; }
+  for (size_t i = 0; i < mn.size(); ++i) { min_i[i] = mn[i].first; min_v[i] = mn[i].second; }
+  *n_max = mx.size(); *n_min = mn.size();
+  return 0;
+}
+
+double oto_kde_f(double h, const double* values, uint64_t n, double x)
+{
+  std::vector<double> v(values, values + n);
+  oto::KDE k; k.h = h; k.values = &v;
+  return k.f(x);
+}
+
+int oto_hclust_average(int n, const double* dist, int* merge, double* height)
+{
+  std::vector<double> cpy(dist, dist + (size_t)n * (n - 1) / 2);
+  oto::hclust_average(n, cpy.data(), merge, height);
+  return 0;
+}
+void oto_cutree_k(int n, const int* merge, int nclust, int* labels) { oto::cutree_k(n, merge, nclust, labels); }
+void oto_cutree_cdist(int n, const int* merge, const double* height, double cdist, int* labels) { oto::cutree_cdist(n, merge, height, cdist, labels); }
+
+uint32_t oto_medoid(uint32_t n, const double* dist, const uint32_t* ind, uint32_t n_ind)
+{
+  oto::DistMatrix dm(n);
+  memcpy(dm.values.data(), dist, dm.values.size() * sizeof(double));
+  std::vector<uint32_t> v(ind, ind + n_ind);
+  return dm.get_medoid(v);
+}
+
+int oto_cluster_batch(const otg_params* P, const double* dist, const uint64_t* dist_off,
+                      const uint32_t* read_len, const uint64_t* len_off, const uint32_t* n_valid, uint32_t n_regions,
+                      int32_t* labels, int32_t* ic, int32_t* fc, double* bounds)
+{
+  int rc = 0;
+  for (uint32_t r = 0; r < n_regions; ++r) {
+    uint32_t n = n_valid[r];
+    if (n == 0) { ic[r] = fc[r] = 0; continue; }
+    oto::DistMatrix dm(n);
+    memcpy(dm.values.data(), dist + dist_off[r], dm.values.size() * sizeof(double));
+    std::vector<uint32_t> lens(read_len + len_off[r], read_len + len_off[r] + n);
+    oto::Clustering cl;
+    int err = oto::otter_hclust(*P, lens, dm, cl);
+    if (err) { rc = OTG_ERR_FATAL; ic[r] = fc[r] = -err; continue; }
+    for (uint32_t i = 0; i < n; ++i) labels[len_off[r] + i] = cl.labels[i];
+    ic[r] = cl.ic; fc[r] = cl.fc;
+    if (bounds) { bounds[3 * r] = cl.b0; bounds[3 * r + 1] = cl.b1; bounds[3 * r + 2] = cl.bc; }
+  }
+  return rc;
+}
+
+int oto_poa_consensus_batch(const uint8_t* seq_arena, uint64_t, const uint8_t* cig_arena, uint64_t,
+                            const otg_poa_member* members, uint32_t, const otg_poa_graph* graphs, uint32_t n_graphs,
+                            uint64_t* out_off, uint32_t* out_len, uint8_t* out_arena, uint64_t cap, uint64_t* used)
+{
+  uint64_t pos = 0; int rc = 0;
+  for (uint32_t g = 0; g < n_graphs; ++g) {
+    const otg_poa_graph& G = graphs[g];
+    oto::PPOA poa;
+    poa.init(std::string((const char*)seq_arena + G.backbone_off, G.backbone_len));
+    for (uint32_t m = 0; m < G.n_members; ++m) {
+      const otg_poa_member& mm = members[G.first_member + m];
+      poa.insert_alignment(std::string((const char*)seq_arena + mm.seq_off, mm.seq_len),
+                           std::string((const char*)cig_arena + mm.cigar_off, mm.cigar_len), mm.spanning_l, mm.spanning_r);
+    }
+    poa.adjust_weights(G.c, G.t);
+    std::string cons;
+    poa.consensus(cons);
+    out_off[g] = pos; out_len[g] = cons.size();
+    if (pos + cons.size() <= cap) memcpy(out_arena + pos, cons.data(), cons.size()); else rc = OTG_ERR_CAPACITY;
+    pos += cons.size();
+  }
+  if (used) *used = pos;
+  return rc;
+}
+
+int oto_genotype_cluster_batch(const otg_params* P, const uint8_t* arena, uint64_t, const uint64_t* seq_off, const uint32_t* seq_len,
+                               const uint32_t* first_allele, const uint32_t* n_alleles, uint32_t n_regions,
+                               int32_t* gt, int32_t* gt_l, int32_t* gt_k, double* hsd, int32_t* n_gt, int32_t* reps)
+{
+  for (uint32_t r = 0; r < n_regions; ++r) {
+    std::vector<std::string> al;
+    for (uint32_t a = 0; a < n_alleles[r]; ++a) al.emplace_back((const char*)arena + seq_off[first_allele[r] + a], seq_len[first_allele[r] + a]);
+    std::vector<oto::Genotype> g; std::vector<int> rp;
+    n_gt[r] = oto::anallele_cluster(P->gt_max_error, P->gt_max_cosdis, al, g, rp);
+    for (uint32_t a = 0; a < n_alleles[r]; ++a) {
+      gt[first_allele[r] + a] = g[a].gt; gt_l[first_allele[r] + a] = g[a].gt_l; gt_k[first_allele[r] + a] = g[a].gt_k; hsd[first_allele[r] + a] = g[a].hsd;
+      reps[first_allele[r] + a] = a < rp.size() ? rp[a] : -1;
+    }
+  }
+  return 0;
+}
+
+/* Region-batch pipeline, same data model as otg_assemble_* but one synchronous call.
+ * Output is held in a heap object the caller frees with oto_assemble_free. */
+struct oto_result {
+  std::vector<otg_region_result> regions;
+  std::vector<otg_allele> alleles;
+  std::vector<uint8_t> seqs;
+  std::vector<int32_t> labels;
+  std::vector<double> dist;          /* concatenated condensed matrices */
+  std::vector<uint64_t> dist_off;
+  std::vector<double> bounds;
+  otg_run_stats stats;
+};
+
+oto_result* oto_assemble_batch(const otg_params* P, const uint8_t* arena, uint64_t, const otg_read* reads, uint32_t n_reads,
+                               const otg_region* regions, uint32_t n_regions, uint32_t region_begin, uint32_t region_end)
+{
+  oto_result* R = new oto_result();
+  memset(&R->stats, 0, sizeof(R->stats));
+  R->labels.assign(n_reads, -1);
+  oto::Stats st;
+  if (region_end > n_regions) region_end = n_regions;
+  R->regions.resize(n_regions);
+  for (uint32_t r = 0; r < n_regions; ++r) { R->regions[r] = otg_region_result{0, 0, OTG_REGION_EMPTY, 0, 0, 0}; }
+  R->dist_off.assign(n_regions + 1, 0);
+  R->bounds.assign(3 * (size_t)n_regions, NAN);
+  for (uint32_t r = region_begin; r < region_end; ++r) {
+    const otg_region& G = regions[r];
+    std::vector<oto::Read> rd(G.n_reads);
+    for (uint32_t i = 0; i < G.n_reads; ++i) {
+      const otg_read& q = reads[G.first_read + i];
+      rd[i].seq.assign((const char*)arena + q.seq_off, q.seq_len);
+      rd[i].spl = q.spanning_l; rd[i].spr = q.spanning_r; rd[i].ps = q.ps; rd[i].hp = q.hp; rd[i].cc1 = q.ccoord_first; rd[i].cc2 = q.ccoord_second;
+    }
+    std::string fl((const char*)arena + G.flank_l_off, G.flank_l_len), fr((const char*)arena + G.flank_r_off, G.flank_r_len);
+    oto::RegionOut out;
+    int rc = oto::assemble_region(*P, rd, fl, fr, out, &st);
+    otg_region_result& rr = R->regions[r];
+    rr.first_allele = R->alleles.size();
+    rr.status = rc ? OTG_ERR_FATAL : out.status; rr.ic = out.ic; rr.fc = out.fc; rr.n_valid = out.n_valid;
+    rr.n_alleles = (rc == 0 && out.status == OTG_REGION_OK) ? out.alleles.size() : 0;
+    R->stats.n_regions++;
+    if (rr.n_alleles) R->stats.n_regions_ok++;
+    for (uint32_t a = 0; a < rr.n_alleles; ++a) {
+      const oto::Allele& A = out.alleles[a];
+      otg_allele o; memset(&o, 0, sizeof(o));
+      o.seq_off = R->seqs.size(); o.seq_len = A.seq.size(); o.scov = A.scov; o.acov = A.acov; o.tcov = A.tcov; o.se = A.se; o.ic = A.ic;
+      o.ps = A.ps; o.hp = A.hp; o.region = r; o.label = a;
+      R->seqs.insert(R->seqs.end(), A.seq.begin(), A.seq.end());
+      R->alleles.push_back(o);
+      R->stats.allele_bytes += A.seq.size() + 40;
+    }
+    for (uint32_t i = 0; i < G.n_reads && i < out.labels.size(); ++i) R->labels[G.first_read + i] = out.labels[i];
+    R->dist_off[r] = R->dist.size();
+    R->dist.insert(R->dist.end(), out.dist.begin(), out.dist.end());
+    R->bounds[3 * r] = out.b0; R->bounds[3 * r + 1] = out.b1; R->bounds[3 * r + 2] = out.bc;
+  }
+  for (uint32_t r = region_end; r <= n_regions; ++r) R->dist_off[r] = R->dist.size();
+  R->stats.edit_tasks = st.edit_tasks; R->stats.edit_cells = st.edit_cells; R->stats.edit_seq_bytes = st.edit_bytes;
+  R->stats.affine_tasks = st.aff_tasks; R->stats.affine_cells = st.aff_cells; R->stats.affine_seq_bytes = st.aff_bytes;
+  R->stats.algorithmic_bytes = st.edit_bytes + 4 * st.edit_cells + st.aff_bytes + 4 * st.aff_cells + (st.aff_cells + 1) / 2 + R->stats.allele_bytes;
+  return R;
+}
+
+void oto_assemble_free(oto_result* R) { delete R; }
+uint32_t oto_result_n_alleles(oto_result* R) { return R->alleles.size(); }
+uint64_t oto_result_seq_bytes(oto_result* R) { return R->seqs.size(); }
+uint64_t oto_result_dist_len(oto_result* R) { return R->dist.size(); }
+void oto_result_copy(oto_result* R, otg_region_result* regions, otg_allele* alleles, uint8_t* seqs, int32_t* labels,
+                     double* dist, uint64_t* dist_off, double* bounds, otg_run_stats* stats)
+{
+  if (regions) memcpy(regions, R->regions.data(), R->regions.size() * sizeof(otg_region_result));
+  if (alleles) memcpy(alleles, R->alleles.data(), R->alleles.size() * sizeof(otg_allele));
+  if (seqs) memcpy(seqs, R->seqs.data(), R->seqs.size());
+  if (labels) memcpy(labels, R->labels.data(), R->labels.size() * sizeof(int32_t));
+  if (dist) memcpy(dist, R->dist.data(), R->dist.size() * sizeof(double));
+  if (dist_off) memcpy(dist_off, R->dist_off.data(), R->dist_off.size() * sizeof(uint64_t));
+  if (bounds) memcpy(bounds, R->bounds.data(), R->bounds.size() * sizeof(double));
+  if (stats) *stats = R->stats;
+}
+
+void oto_params_default(otg_params* p)
+{
+  memset(p, 0, sizeof(*p));
+  p->max_alleles = 2; p->ignore_haps = 1; p->max_cov = 200; p->flank = 100; p->bandwidth_length = 500;
+  p->min_cov_fraction2_l = 500; p->mismatch = 4; p->gap_open = 6; p->gap_ext = 2; p->realign = 0;
+  p->bandwidth_short = 0.01; p->bandwidth_long = 0.015; p->max_error = 0.01; p->min_cov_fraction = 0.2;
+  p->min_cov_fraction2_f = 0.1; p->min_sim = 0.9; p->gt_max_error = 0.025; p->gt_max_cosdis = 0.025;
+}
+
+} /* extern "C" */

@@ -1,0 +1,156 @@
+"""Synthetic tandem-repeat region batches: the hot path's inputs, i.e. what
+parse_anreads (src/anseqs.cpp:439-460) would hand to the region loop — per read the region
+sub-sequence, spanning flags and clip coordinates — laid out as the C-ABI region batch
+(include/otter_gpu.h: otg_read / otg_region + one byte arena).  Seed 20241008."""
+import numpy as np
+from . import abi
+
+SEED = 20241008
+_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+ERR = {  # total rate, (sub, ins, del) split
+    "hifi": (0.002, (0.2, 0.4, 0.4)),
+    "ont": (0.07, (0.40, 0.25, 0.35)),
+    "none": (0.0, (1.0, 0.0, 0.0)),
+}
+
+
+def _mutate(rng, tmpl, rate, split):
+    """Apply sub/ins/del errors to a 0..3 coded template; returns coded read."""
+    n = tmpl.size
+    if rate <= 0 or n == 0:
+        return tmpl.copy()
+    u = rng.random(n)
+    ps, pi, pd = (rate * s for s in split)
+    sub = u < ps
+    ins = (u >= ps) & (u < ps + pi)
+    dele = (u >= ps + pi) & (u < ps + pi + pd)
+    base = tmpl.copy()
+    k = int(sub.sum())
+    if k:
+        base[sub] = (base[sub] + rng.integers(1, 4, k, dtype=np.uint8)) & 3
+    cnt = (~dele).astype(np.int64) + ins.astype(np.int64)
+    out = np.repeat(base, cnt)
+    if ins.any():
+        ends = np.cumsum(cnt) - 1
+        out[ends[ins]] = rng.integers(0, 4, int(ins.sum()), dtype=np.uint8)
+    return out
+
+
+def make_batch(n_regions, len_range=(1000, 5000), n_reads=30, err="ont", seed=SEED, frac_partial=0.12,
+               frac_het=0.7, realign=False, frac_clipped=0.25, haps=False, flank=100, reads_range=None):
+    """Returns dict(arena, reads, regions, truth) for `n_regions` diploid TR regions.
+
+    realign=True additionally gives 25 % of the reads a soft-clipped (divergent or junk) left or right
+    flank and adds the two (flank+1)-bp reference flanks per region (config 3, local_realignment inputs)."""
+    rng = np.random.default_rng(seed)
+    rate, split = ERR[err]
+    chunks, reads, regions = [], [], []
+    truth = []
+    pos = 0
+
+    def push(coded):
+        nonlocal pos
+        b = _ACGT[coded]
+        chunks.append(b)
+        off = pos
+        pos += b.size
+        return off, b.size
+
+    for r in range(n_regions):
+        L = int(rng.integers(len_range[0], len_range[1] + 1))
+        m = int(rng.integers(2, 7))
+        motif = rng.integers(0, 4, m, dtype=np.uint8)
+        while m > 1 and np.all(motif == motif[0]):
+            motif = rng.integers(0, 4, m, dtype=np.uint8)
+        copies_a = max(1, (L - 1) // m)
+        lead = rng.integers(0, 4, 1, dtype=np.uint8)           # the one flank base of offset "1,0"
+        al_a = np.concatenate([lead, np.tile(motif, copies_a)])
+        het = rng.random() < frac_het
+        if het:
+            d = rng.uniform(0.05, 0.3)
+            kc = max(1, int(round(d * copies_a)))
+            copies_b = copies_a + kc if (rng.random() < 0.5 or copies_a - kc < 1) else copies_a - kc
+            al_b = np.concatenate([lead, np.tile(motif, copies_b)])
+        else:
+            al_b = al_a
+        fl_l = rng.integers(0, 4, flank + 1, dtype=np.uint8)
+        fl_r = rng.integers(0, 4, flank + 1, dtype=np.uint8)
+        fl_l[-1] = lead[0]
+        nr = n_reads if reads_range is None else int(rng.integers(reads_range[0], reads_range[1] + 1))
+        n_a = int(rng.binomial(nr, 0.5)) if het else nr
+        first = len(reads)
+        which = np.zeros(nr, dtype=np.int8)
+        which[n_a:] = 1
+        rng.shuffle(which)
+        for i in range(nr):
+            tmpl = al_a if which[i] == 0 else al_b
+            spl, spr = 1, 1
+            cc1, cc2 = 0, 0
+            u = rng.random()
+            if realign and u < frac_clipped:
+                # read whose left (or right) flank was soft-clipped by the mapper
+                left = rng.random() < 0.5
+                clip_len = int(rng.integers(150, 401))
+                good = rng.random() < 0.6
+                body = _mutate(rng, tmpl, rate, split)
+                if good:
+                    fl = fl_l[:-1] if left else fl_r[1:]
+                    core = _mutate(rng, fl, max(rate, 0.03), (0.5, 0.25, 0.25))
+                    junk = rng.integers(0, 4, max(0, clip_len - core.size), dtype=np.uint8)
+                    clip = np.concatenate([junk, core]) if left else np.concatenate([core, junk])
+                else:
+                    clip = rng.integers(0, 4, clip_len, dtype=np.uint8)
+                if left:
+                    seq = np.concatenate([clip, body]); spl, spr = 0, 1
+                    cc1, cc2 = clip.size, clip.size + body.size
+                else:
+                    seq = np.concatenate([body, clip]); spl, spr = 1, 0
+                    cc1, cc2 = 0, body.size
+            elif u < (frac_clipped if realign else 0.0) + frac_partial:
+                cut = int(rng.integers(int(0.3 * tmpl.size), max(int(0.3 * tmpl.size) + 1, int(0.9 * tmpl.size))))
+                if rng.random() < 0.5:
+                    seq = _mutate(rng, tmpl[:cut], rate, split); spl, spr = 1, 0
+                else:
+                    seq = _mutate(rng, tmpl[tmpl.size - cut:], rate, split); spl, spr = 0, 1
+                cc1, cc2 = 0, seq.size
+            else:
+                seq = _mutate(rng, tmpl, rate, split)
+                cc1, cc2 = 0, seq.size
+            if seq.size == 0:
+                seq = np.zeros(1, dtype=np.uint8)
+            off, ln = push(seq)
+            ps, hp = (1, int(which[i]) + 1) if haps else (-1, -1)
+            reads.append((off, ln, spl, spr, 0, ps, hp, cc1, cc2))
+        if realign:
+            flo, fll = push(fl_l)
+            fro, frl = push(fl_r)
+        else:
+            flo = fro = fll = frl = 0
+        regions.append((first, nr, flo, fro, fll, frl))
+        truth.append((al_a.size, al_b.size, int(het)))
+    arena = np.concatenate(chunks + [np.zeros(64, dtype=np.uint8)]) if chunks else np.zeros(64, dtype=np.uint8)
+    reads_a = np.array(reads, dtype=abi.read_dt) if reads else np.zeros(0, dtype=abi.read_dt)
+    regions_a = np.array(regions, dtype=abi.region_dt) if regions else np.zeros(0, dtype=abi.region_dt)
+    return {"arena": arena, "reads": reads_a, "regions": regions_a,
+            "truth": np.array(truth, dtype=np.int64).reshape(-1, 3)}
+
+
+CONFIGS = {
+    # BASELINE.json configs, by index
+    0: dict(n_regions=100, len_range=(500, 500), n_reads=10, err="hifi", frac_partial=0.0),
+    1: dict(n_regions=10000, len_range=(1000, 5000), n_reads=30, err="ont"),
+    2: dict(n_regions=10000, len_range=(1000, 5000), n_reads=30, err="ont", realign=True),
+    4: dict(n_regions=100000, len_range=(1000, 10000), n_reads=30, err="ont"),
+}
+
+
+def shard_bounds(n_regions, world, rank):
+    """Static contiguous split of BS::thread_pool::parallelize_loop (src/BS_thread_pool.hpp:183-198):
+    block = total / world, the last shard takes the remainder."""
+    block = n_regions // world
+    if block == 0:
+        return (rank, rank + 1) if rank < n_regions else (n_regions, n_regions)
+    a = rank * block
+    b = n_regions if rank == world - 1 else a + block
+    return a, b
