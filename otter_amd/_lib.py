@@ -1,0 +1,185 @@
+"""ctypes binding of libotter_gpu.so (the C-ABI of include/otter_gpu.h).  There is no CPU fallback:
+if the HIP library is missing or no device is usable, every entry point raises."""
+import ctypes as C
+import os
+import numpy as np
+from . import abi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libotter_gpu.so")
+
+EXPORTS = [
+    "otg_params_default", "otg_create", "otg_destroy", "otg_last_error", "otg_device_count", "otg_exp_variant",
+    "otg_edit_distance_batch", "otg_affine_align_batch", "otg_cluster_batch", "otg_poa_consensus_batch",
+    "otg_genotype_cluster_batch", "otg_assemble_submit", "otg_assemble_run", "otg_assemble_result_sizes",
+    "otg_assemble_collect", "otg_assemble_stats",
+]
+
+_lib = None
+
+
+class OtterGpuError(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OtterGpuError("%s is missing: build it with `python -m otter_amd.build` (hipcc, gfx950). "
+                                "otter_amd has no CPU fallback." % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.otg_last_error.restype = C.c_char_p
+        _lib.otg_last_error.argtypes = [C.c_void_p]
+        _lib.otg_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        _lib.otg_destroy.argtypes = [C.c_void_p]
+    return _lib
+
+
+class Context:
+    """One otg_ctx = one GPU + one stream (single-threaded, like a reference worker thread's aligner pair,
+    src/assemble.cpp:45-50)."""
+
+    def __init__(self, device=0):
+        L = load()
+        h = C.c_void_p()
+        rc = L.otg_create(int(device), C.byref(h))
+        if rc != 0:
+            raise OtterGpuError("otg_create(device=%d) failed (%d): %s" % (device, rc, (L.otg_last_error(None) or b"").decode()))
+        self._h = h
+        self._L = L
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.otg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise OtterGpuError("%s failed (%d): %s" % (what, rc, (self._L.otg_last_error(self._h) or b"").decode()))
+
+    @property
+    def exp_variant(self):
+        return self._L.otg_exp_variant(self._h)
+
+    # ------------------------------------------------------------------ L1
+    def edit_distance_batch(self, arena, tasks, want_cells=False):
+        n = len(tasks)
+        scores = np.zeros(n, dtype=np.int32)
+        cells = np.zeros(n, dtype=np.uint64)
+        rc = self._L.otg_edit_distance_batch(self._h, abi.ptr(arena), C.c_uint64(arena.size), abi.ptr(tasks), C.c_uint32(n),
+                                             abi.ptr(scores), abi.ptr(cells))
+        self._check(rc, "otg_edit_distance_batch")
+        return (scores, cells) if want_cells else scores
+
+    def affine_align_batch(self, arena, tasks, x=4, o=6, e=2, want_cells=False):
+        n = len(tasks)
+        scores = np.zeros(n, dtype=np.int32)
+        off = np.zeros(n, dtype=np.uint64)
+        ln = np.zeros(n, dtype=np.uint32)
+        cap = int(tasks["pattern_len"].astype(np.int64).sum() + tasks["text_len"].astype(np.int64).sum()) + 64
+        out = np.zeros(cap, dtype=np.uint8)
+        used = C.c_uint64(0)
+        cells = np.zeros(n, dtype=np.uint64)
+        rc = self._L.otg_affine_align_batch(self._h, abi.ptr(arena), C.c_uint64(arena.size), abi.ptr(tasks), C.c_uint32(n),
+                                            int(x), int(o), int(e), abi.ptr(scores), abi.ptr(off), abi.ptr(ln), abi.ptr(out),
+                                            C.c_uint64(cap), C.byref(used), abi.ptr(cells))
+        self._check(rc, "otg_affine_align_batch")
+        cigs = [out[int(off[i]):int(off[i]) + int(ln[i])].tobytes() for i in range(n)]
+        return (scores, cigs, cells) if want_cells else (scores, cigs)
+
+    # ------------------------------------------------------------------ L2
+    def cluster_batch(self, params, dist, dist_off, read_len, len_off, n_valid):
+        nreg = len(n_valid)
+        labels = np.full(int(read_len.size), -1, dtype=np.int32)
+        ic = np.zeros(nreg, dtype=np.int32)
+        fc = np.zeros(nreg, dtype=np.int32)
+        bounds = np.full(3 * nreg, np.nan)
+        rc = self._L.otg_cluster_batch(self._h, C.byref(params), abi.ptr(dist), abi.ptr(dist_off), abi.ptr(read_len), abi.ptr(len_off),
+                                       abi.ptr(n_valid), C.c_uint32(nreg), abi.ptr(labels), abi.ptr(ic), abi.ptr(fc), abi.ptr(bounds))
+        self._check(rc, "otg_cluster_batch")
+        return labels, ic, fc, bounds.reshape(-1, 3)
+
+    def poa_consensus_batch(self, seq_arena, cig_arena, members, graphs):
+        ng = len(graphs)
+        off = np.zeros(ng, dtype=np.uint64)
+        ln = np.zeros(ng, dtype=np.uint32)
+        cap = int(seq_arena.size) * 2 + 1024
+        out = np.zeros(cap, dtype=np.uint8)
+        used = C.c_uint64(0)
+        rc = self._L.otg_poa_consensus_batch(self._h, abi.ptr(seq_arena), C.c_uint64(seq_arena.size), abi.ptr(cig_arena),
+                                             C.c_uint64(cig_arena.size), abi.ptr(members), C.c_uint32(len(members)),
+                                             abi.ptr(graphs), C.c_uint32(ng), abi.ptr(off), abi.ptr(ln), abi.ptr(out),
+                                             C.c_uint64(cap), C.byref(used))
+        self._check(rc, "otg_poa_consensus_batch")
+        return [out[int(off[i]):int(off[i]) + int(ln[i])].tobytes() for i in range(ng)]
+
+    def genotype_cluster_batch(self, params, arena, seq_off, seq_len, first_allele, n_alleles):
+        nreg = len(n_alleles)
+        na = len(seq_off)
+        gt, gl, gk = (np.zeros(na, dtype=np.int32) for _ in range(3))
+        hsd = np.zeros(na)
+        ngt = np.zeros(nreg, dtype=np.int32)
+        reps = np.zeros(na, dtype=np.int32)
+        rc = self._L.otg_genotype_cluster_batch(self._h, C.byref(params), abi.ptr(arena), C.c_uint64(arena.size), abi.ptr(seq_off),
+                                                abi.ptr(seq_len), abi.ptr(first_allele), abi.ptr(n_alleles), C.c_uint32(nreg),
+                                                abi.ptr(gt), abi.ptr(gl), abi.ptr(gk), abi.ptr(hsd), abi.ptr(ngt), abi.ptr(reps))
+        self._check(rc, "otg_genotype_cluster_batch")
+        return gt, gl, gk, hsd, ngt, reps
+
+    # ------------------------------------------------------------------ L3
+    def assemble_submit(self, params, batch, region_range=None):
+        arena, reads, regions = batch["arena"], batch["reads"], batch["regions"]
+        if region_range is not None:
+            a, b = region_range
+            regions = np.ascontiguousarray(regions[a:b])
+        self._n_regions = len(regions)
+        self._n_reads = len(reads)
+        self._first_read = int(regions["first_read"].min()) if len(regions) else 0
+        rc = self._L.otg_assemble_submit(self._h, C.byref(params), abi.ptr(arena), C.c_uint64(arena.size), abi.ptr(reads),
+                                         C.c_uint32(len(reads)), abi.ptr(regions), C.c_uint32(len(regions)))
+        self._check(rc, "otg_assemble_submit")
+
+    def assemble_run(self):
+        self._check(self._L.otg_assemble_run(self._h), "otg_assemble_run")
+
+    def assemble_collect(self):
+        na = C.c_uint32(0)
+        sb = C.c_uint64(0)
+        self._check(self._L.otg_assemble_result_sizes(self._h, C.byref(na), C.byref(sb)), "otg_assemble_result_sizes")
+        res = {
+            "regions": np.zeros(self._n_regions, dtype=abi.region_result_dt),
+            "alleles": np.zeros(na.value, dtype=abi.allele_dt),
+            "seqs": np.zeros(max(1, sb.value), dtype=np.uint8),
+            "labels": np.zeros(self._n_reads, dtype=np.int32),
+        }
+        rc = self._L.otg_assemble_collect(self._h, abi.ptr(res["regions"]), abi.ptr(res["alleles"]), C.c_uint32(na.value),
+                                          abi.ptr(res["seqs"]), C.c_uint64(res["seqs"].size), abi.ptr(res["labels"]))
+        self._check(rc, "otg_assemble_collect")
+        return res
+
+    def assemble_stats(self):
+        st = np.zeros(1, dtype=abi.run_stats_dt)
+        self._check(self._L.otg_assemble_stats(self._h, abi.ptr(st)), "otg_assemble_stats")
+        return st[0]
+
+    def assemble(self, params, batch, region_range=None):
+        self.assemble_submit(params, batch, region_range)
+        self.assemble_run()
+        return self.assemble_collect()
+
+
+def device_count():
+    return load().otg_device_count()

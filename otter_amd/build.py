@@ -1,0 +1,70 @@
+"""Builds libotter_gpu.so (hand-written HIP for gfx950) in-tree with hipcc.  No CPU fallback is built."""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libotter_gpu.so")
+SOURCES = ["otg_api.hip", "wfa_edit.hip", "wfa_affine.hip", "cluster.hip", "poa.hip", "genotype.hip", "pipeline.hip"]
+# -ffp-contract=off: the reference's clustering decisions are FP64 comparisons made without FMA
+# contraction; fused operations are written explicitly where glibc uses them.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+         "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: cannot build libotter_gpu.so (there is no CPU fallback)")
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "otter_gpu.h")]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.isfile(d))
+
+
+def build(force=False, verbose=False, jobs=4):
+    if not force and not needs_build():
+        return LIB
+    cc = hipcc()
+    objs = []
+    procs = []
+    os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
+    for src in SOURCES:
+        path = os.path.join(CSRC, src)
+        obj = os.path.join(CSRC, "build", src.replace(".hip", ".o"))
+        objs.append(obj)
+        if (not force) and os.path.exists(obj) and os.path.getmtime(obj) > max(
+                os.path.getmtime(path), os.path.getmtime(os.path.join(CSRC, "otg_common.hpp")),
+                os.path.getmtime(os.path.join(HERE, "..", "include", "otter_gpu.h"))):
+            continue
+        cmd = [cc] + FLAGS + ["-c", path, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        if len(procs) >= jobs:
+            _drain(procs)
+    _drain(procs)
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    subprocess.check_call(cmd)
+    return LIB
+
+
+def _drain(procs):
+    while procs:
+        src, p = procs.pop(0)
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s" % (src, out.decode(errors="replace")))
+        if out.strip():
+            sys.stderr.write(out.decode(errors="replace"))
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

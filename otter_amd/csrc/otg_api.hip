@@ -1,0 +1,269 @@
+// otg_api.hip — context, device scratch and the L1/L2 C-ABI entry points (host side).
+#include "otg_common.hpp"
+#include <cmath>
+#include <cstdarg>
+
+thread_local std::string g_otg_err;
+
+int otg_fail(otg_ctx* ctx, int code, const char* fmt, ...)
+{
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_otg_err = buf;
+  if (ctx) ctx->err = buf;
+  return code;
+}
+
+void* otg_slot(otg_ctx* ctx, int slot, size_t bytes)
+{
+  if (bytes == 0) bytes = 16;
+  DevBuf& b = ctx->pool[slot];
+  if (b.cap >= bytes) return b.p;
+  if (b.p) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+  size_t want = bytes + (bytes >> 3) + 256;
+  hipError_t e = hipMalloc(&b.p, want);
+  if (e != hipSuccess) {
+    otg_fail(ctx, OTG_ERR_HIP, "hipMalloc(%zu bytes, slot %d) failed: %s", want, slot, hipGetErrorString(e));
+    b.p = nullptr;
+    return nullptr;
+  }
+  b.cap = want;
+  return b.p;
+}
+
+// ---- glibc exp() restated on the host, used ONLY to detect which build of exp() the host libm runs
+// (the device KDE mirrors that build bit for bit; see cluster.hip / DESIGN.md §5). -------------------
+#include "exp_table.inc"
+static double host_exp_variant(double x, bool use_fma);
+
+extern "C" {
+
+void otg_params_default(otg_params* p)
+{
+  memset(p, 0, sizeof(*p));
+  p->max_alleles = 2; p->ignore_haps = 1; p->max_cov = 200; p->flank = 100; p->bandwidth_length = 500;
+  p->min_cov_fraction2_l = 500; p->mismatch = 4; p->gap_open = 6; p->gap_ext = 2; p->realign = 0;
+  p->bandwidth_short = 0.01; p->bandwidth_long = 0.015; p->max_error = 0.01; p->min_cov_fraction = 0.2;
+  p->min_cov_fraction2_f = 0.1; p->min_sim = 0.9; p->gt_max_error = 0.025; p->gt_max_cosdis = 0.025;
+}
+
+int otg_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* otg_last_error(otg_ctx* ctx) { return ctx ? ctx->err.c_str() : g_otg_err.c_str(); }
+
+int otg_create(int device, otg_ctx** out)
+{
+  if (!out) return otg_fail(nullptr, OTG_ERR_ARG, "otg_create: out is NULL");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0)
+    return otg_fail(nullptr, OTG_ERR_NO_DEVICE, "no HIP device available (%s); libotter_gpu has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+  if (device < 0 || device >= n) return otg_fail(nullptr, OTG_ERR_ARG, "device %d out of range (0..%d)", device, n - 1);
+  otg_ctx* ctx = new otg_ctx();
+  ctx->device = device;
+  ctx->pool.resize(SLOT_COUNT);
+  if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&ctx->prop, device) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+    delete ctx;
+    return otg_fail(nullptr, OTG_ERR_HIP, "HIP device %d could not be initialised", device);
+  }
+  ctx->n_cu = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+  // probe the host libm: does exp() round like glibc's FMA build or its non-FMA build?
+  {
+    int agree_fma = 0, agree_nofma = 0;
+    uint64_t s = 88172645463325252ULL;
+    for (int i = 0; i < 4096; ++i) {
+      s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+      double u = (double)(s >> 11) * (1.0 / 9007199254740992.0);
+      double z = u * 39.0, x = -(z * z / 2);
+      double ref = std::exp(x);
+      agree_fma += (memcmp(&ref, (const void*)&(const double&)(host_exp_variant(x, true)), 8) == 0);
+      agree_nofma += (memcmp(&ref, (const void*)&(const double&)(host_exp_variant(x, false)), 8) == 0);
+    }
+    ctx->exp_variant = (agree_nofma > agree_fma) ? 0 : 1;
+  }
+  *out = ctx;
+  return OTG_OK;
+}
+
+void otg_destroy(otg_ctx* ctx)
+{
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  otg_pipeline_free(ctx);
+  for (auto& b : ctx->pool) if (b.p) (void)hipFree(b.p);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int otg_exp_variant(otg_ctx* ctx) { return ctx ? ctx->exp_variant : -1; }
+
+static uint32_t max_len_of(const otg_align_task* tasks, uint32_t n)
+{
+  uint32_t m = 1;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (tasks[i].pattern_len > m) m = tasks[i].pattern_len;
+    if (tasks[i].text_len > m) m = tasks[i].text_len;
+  }
+  return m;
+}
+
+static int check_tasks(otg_ctx* ctx, const otg_align_task* tasks, uint32_t n, uint64_t arena_bytes)
+{
+  for (uint32_t i = 0; i < n; ++i) {
+    const otg_align_task& t = tasks[i];
+    if (t.pattern_off + t.pattern_len > arena_bytes || t.text_off + t.text_len > arena_bytes)
+      return otg_fail(ctx, OTG_ERR_ARG, "task %u: sequence range outside the arena", i);
+    if (t.endsfree && (t.pattern_begin_free < 0 || t.pattern_end_free < 0 || t.text_begin_free < 0 || t.text_end_free < 0))
+      return otg_fail(ctx, OTG_ERR_ARG, "task %u: negative free-end length", i);
+  }
+  return OTG_OK;
+}
+
+int otg_edit_distance_batch(otg_ctx* ctx, const uint8_t* seq_arena, uint64_t arena_bytes,
+                            const otg_align_task* tasks, uint32_t n_tasks, int32_t* scores_out, uint64_t* cells_out)
+{
+  if (!ctx) return otg_fail(nullptr, OTG_ERR_NO_DEVICE, "otg_edit_distance_batch: no context (no HIP device?)");
+  if (n_tasks == 0) return OTG_OK;
+  if (!seq_arena || !tasks || !scores_out) return otg_fail(ctx, OTG_ERR_ARG, "otg_edit_distance_batch: NULL argument");
+  int rc = check_tasks(ctx, tasks, n_tasks, arena_bytes);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  uint8_t* d_arena = (uint8_t*)otg_slot(ctx, SLOT_ARENA, arena_bytes + 64);
+  otg_align_task* d_tasks = (otg_align_task*)otg_slot(ctx, SLOT_TASKS, (size_t)n_tasks * sizeof(otg_align_task));
+  int32_t* d_scores = (int32_t*)otg_slot(ctx, SLOT_SCORES, (size_t)n_tasks * sizeof(int32_t));
+  uint64_t* d_cells = (uint64_t*)otg_slot(ctx, SLOT_CELLS, (size_t)n_tasks * sizeof(uint64_t));
+  if (!d_arena || !d_tasks || !d_scores || !d_cells) return OTG_ERR_HIP;
+  HIP_TRY(ctx, hipMemsetAsync(d_arena + arena_bytes, 0, 64, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_arena, seq_arena, arena_bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_tasks, tasks, (size_t)n_tasks * sizeof(otg_align_task), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(d_scores, 0xff, (size_t)n_tasks * sizeof(int32_t), ctx->stream));
+  ctx->max_seq_len = max_len_of(tasks, n_tasks);
+  rc = otg_launch_edit(ctx, d_arena, d_tasks, n_tasks, d_scores, d_cells, nullptr, nullptr);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(scores_out, d_scores, (size_t)n_tasks * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  if (cells_out) HIP_TRY(ctx, hipMemcpyAsync(cells_out, d_cells, (size_t)n_tasks * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (uint32_t i = 0; i < n_tasks; ++i)
+    if (scores_out[i] < 0) return otg_fail(ctx, OTG_ERR_FATAL, "edit task %u did not terminate", i);
+  return OTG_OK;
+}
+
+int otg_affine_align_batch(otg_ctx* ctx, const uint8_t* seq_arena, uint64_t arena_bytes,
+                           const otg_align_task* tasks, uint32_t n_tasks,
+                           int32_t mismatch, int32_t gap_open, int32_t gap_ext,
+                           int32_t* scores_out, uint64_t* cigar_off_out, uint32_t* cigar_len_out,
+                           uint8_t* cigar_arena, uint64_t cigar_capacity, uint64_t* cigar_bytes_used,
+                           uint64_t* cells_out)
+{
+  if (!ctx) return otg_fail(nullptr, OTG_ERR_NO_DEVICE, "otg_affine_align_batch: no context (no HIP device?)");
+  if (cigar_bytes_used) *cigar_bytes_used = 0;
+  if (n_tasks == 0) return OTG_OK;
+  if (!seq_arena || !tasks || !scores_out || !cigar_off_out || !cigar_len_out || !cigar_arena)
+    return otg_fail(ctx, OTG_ERR_ARG, "otg_affine_align_batch: NULL argument");
+  int rc = check_tasks(ctx, tasks, n_tasks, arena_bytes);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  // device CIGAR slots: task i may emit at most pattern_len + text_len ops
+  std::vector<uint64_t> slot(n_tasks + 1);
+  slot[0] = 0;
+  for (uint32_t i = 0; i < n_tasks; ++i) slot[i + 1] = slot[i] + (((uint64_t)tasks[i].pattern_len + tasks[i].text_len + 15) & ~15ull);
+  uint8_t* d_arena = (uint8_t*)otg_slot(ctx, SLOT_ARENA, arena_bytes + 64);
+  otg_align_task* d_tasks = (otg_align_task*)otg_slot(ctx, SLOT_TASKS, (size_t)n_tasks * sizeof(otg_align_task));
+  int32_t* d_scores = (int32_t*)otg_slot(ctx, SLOT_SCORES, (size_t)n_tasks * sizeof(int32_t));
+  uint64_t* d_cells = (uint64_t*)otg_slot(ctx, SLOT_CELLS, (size_t)n_tasks * sizeof(uint64_t));
+  uint64_t* d_off = (uint64_t*)otg_slot(ctx, SLOT_CIG_OFF, (size_t)(n_tasks + 1) * sizeof(uint64_t));
+  uint32_t* d_len = (uint32_t*)otg_slot(ctx, SLOT_CIG_LEN, (size_t)n_tasks * sizeof(uint32_t));
+  uint8_t* d_cig = (uint8_t*)otg_slot(ctx, SLOT_CIG_ARENA, slot[n_tasks] + 64);
+  if (!d_arena || !d_tasks || !d_scores || !d_cells || !d_off || !d_len || !d_cig) return OTG_ERR_HIP;
+  HIP_TRY(ctx, hipMemsetAsync(d_arena + arena_bytes, 0, 64, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_arena, seq_arena, arena_bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_tasks, tasks, (size_t)n_tasks * sizeof(otg_align_task), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_off, slot.data(), (size_t)(n_tasks + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(d_scores, 0xff, (size_t)n_tasks * sizeof(int32_t), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(d_len, 0, (size_t)n_tasks * sizeof(uint32_t), ctx->stream));
+  ctx->max_seq_len = max_len_of(tasks, n_tasks);
+  rc = otg_launch_affine(ctx, d_arena, d_tasks, n_tasks, mismatch, gap_open, gap_ext, d_scores, d_off, d_len, d_cig, d_cells);
+  if (rc) return rc;
+  std::vector<uint8_t> h_cig(slot[n_tasks] + 1);
+  HIP_TRY(ctx, hipMemcpyAsync(scores_out, d_scores, (size_t)n_tasks * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(cigar_len_out, d_len, (size_t)n_tasks * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  if (cells_out) HIP_TRY(ctx, hipMemcpyAsync(cells_out, d_cells, (size_t)n_tasks * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(h_cig.data(), d_cig, slot[n_tasks], hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  uint64_t pos = 0;
+  rc = OTG_OK;
+  for (uint32_t i = 0; i < n_tasks; ++i) {
+    if (scores_out[i] < 0)
+      return otg_fail(ctx, scores_out[i] == -1 ? OTG_ERR_CAPACITY : OTG_ERR_FATAL,
+                      "affine task %u failed on the device (code %d: -1 = backtrace storage exhausted)", i, scores_out[i]);
+    cigar_off_out[i] = pos;
+    if (pos + cigar_len_out[i] <= cigar_capacity) memcpy(cigar_arena + pos, h_cig.data() + slot[i], cigar_len_out[i]);
+    else rc = OTG_ERR_CAPACITY;
+    pos += cigar_len_out[i];
+  }
+  if (cigar_bytes_used) *cigar_bytes_used = pos;
+  if (rc) return otg_fail(ctx, rc, "cigar_capacity %llu too small, %llu needed", (unsigned long long)cigar_capacity, (unsigned long long)pos);
+  return OTG_OK;
+}
+
+} // extern "C"
+
+// ---------------------------------------------------------------------------------------------------
+static inline uint64_t asu64(double x) { uint64_t u; memcpy(&u, &x, 8); return u; }
+static inline double asf64(uint64_t u) { double x; memcpy(&x, &u, 8); return x; }
+
+static double host_exp_variant(double x, bool use_fma)
+{
+  // glibc 2.28+ exp (sysdeps/ieee754/dbl-64/e_exp.c), N = 128; use_fma mirrors the x86-64 ifunc'd FMA build
+  const double InvLn2N = 0x1.71547652b82fep0 * 128, NegLn2hiN = -0x1.62e42fefa0000p-8, NegLn2loN = -0x1.cf79abc9e3b3ap-47;
+  const double Shift = 0x1.8p52;
+  const double C2 = 0x1.ffffffffffdbdp-2, C3 = 0x1.555555555543cp-3, C4 = 0x1.55555cf172b91p-5, C5 = 0x1.1111167a4d017p-7;
+  auto F = [use_fma](double a, double b, double c) { return use_fma ? std::fma(a, b, c) : a * b + c; };
+  uint32_t abstop = (uint32_t)(asu64(x) >> 52) & 0x7ff;
+  if (abstop - 0x3c9 >= 0x408 - 0x3c9) {
+    if (abstop - 0x3c9 >= 0x80000000u) return 1.0 + x;
+    if (abstop >= 0x409) {
+      if (asu64(x) == asu64(-INFINITY)) return 0.0;
+      if (abstop >= 0x7ff) return 1.0 + x;
+      return (asu64(x) >> 63) ? 0.0 : INFINITY;
+    }
+    abstop = 0;
+  }
+  double z = InvLn2N * x;
+  double kd = z + Shift;
+  uint64_t ki = asu64(kd);
+  kd -= Shift;
+  double r = F(kd, NegLn2loN, F(kd, NegLn2hiN, x));
+  uint64_t idx = 2 * (ki % 128), top = ki << 45;
+  double tail = asf64(OTG_EXP_TAB[idx]);
+  uint64_t sbits = OTG_EXP_TAB[idx + 1] + top;
+  double r2 = r * r;
+  double tmp = use_fma ? F(r2 * r2, F(r, C5, C4), F(r2, F(r, C3, C2), tail + r))
+                       : tail + r + r2 * (C2 + r * C3) + r2 * r2 * (C4 + r * C5);
+  if (abstop == 0) {
+    double scale, y;
+    if ((ki & 0x80000000) == 0) { sbits -= 1009ull << 52; scale = asf64(sbits); y = 0x1p1009 * (scale + scale * tmp); return y; }
+    sbits += 1022ull << 52; scale = asf64(sbits);
+    double st = scale * tmp;
+    y = scale + st;
+    if (y < 1.0) { double hi, lo; lo = scale - y + st; hi = 1.0 + y; lo = 1.0 - hi + y + lo; y = (hi + lo) - 1.0; if (y == 0.0) y = 0.0; }
+    return 0x1p-1022 * y;
+  }
+  double scale = asf64(sbits);
+  return F(scale, tmp, scale);
+}

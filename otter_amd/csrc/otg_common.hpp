@@ -1,0 +1,112 @@
+// otg_common.hpp — shared host-side plumbing of libotter_gpu.so (HIP runtime only, no torch).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/otter_gpu.h"
+
+#define OTG_NULL_OFF (-(1 << 30))
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct otg_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipDeviceProp_t prop;
+  std::string err;
+  int exp_variant = 1;
+  int n_cu = 256;
+  uint32_t max_seq_len = 65536;   // longest sequence of the current batch (sizes the tier-3 edit workspace)
+  // grow-only device scratch, keyed by purpose
+  std::vector<DevBuf> pool;
+  // resident batch of the L3 pipeline
+  struct Pipeline* pipe = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+extern thread_local std::string g_otg_err;
+
+int otg_fail(otg_ctx* ctx, int code, const char* fmt, ...);
+
+#define HIP_TRY(ctx, call)                                                                      \
+  do {                                                                                          \
+    hipError_t e__ = (call);                                                                    \
+    if (e__ != hipSuccess)                                                                      \
+      return otg_fail(ctx, OTG_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), \
+                      __FILE__, __LINE__);                                                      \
+  } while (0)
+
+// Grow-only device allocation slot; returns nullptr on failure (error recorded).
+void* otg_slot(otg_ctx* ctx, int slot, size_t bytes);
+
+enum {
+  SLOT_ARENA = 0, SLOT_TASKS, SLOT_SCORES, SLOT_CELLS, SLOT_COUNTERS, SLOT_WF_WS, SLOT_CIG_OFF, SLOT_CIG_LEN,
+  SLOT_CIG_ARENA, SLOT_BT_POOL, SLOT_ROWTAB, SLOT_REVOPS, SLOT_TASKSTATE, SLOT_TODO, SLOT_AUX0, SLOT_AUX1,
+  SLOT_AUX2, SLOT_AUX3, SLOT_AUX4, SLOT_AUX5, SLOT_AUX6, SLOT_AUX7, SLOT_AUX8, SLOT_AUX9,
+  SLOT_P0, SLOT_P1, SLOT_P2, SLOT_P3, SLOT_P4, SLOT_P5, SLOT_P6, SLOT_P7, SLOT_P8, SLOT_P9,
+  SLOT_P10, SLOT_P11, SLOT_P12, SLOT_P13, SLOT_P14, SLOT_P15, SLOT_P16, SLOT_P17, SLOT_P18, SLOT_P19,
+  SLOT_P20, SLOT_P21, SLOT_P22, SLOT_P23, SLOT_P24, SLOT_P25, SLOT_P26, SLOT_P27, SLOT_P28, SLOT_P29,
+  SLOT_COUNT
+};
+
+void otg_pipeline_free(otg_ctx* ctx);
+
+#if defined(__HIPCC__)
+// One atomic add per WAVE, issued with exec forced to lane 0 and no divergent branch in the HIP source.
+// (A source-level `if (lane == 0) atomicAdd(..)` + readfirstlane at the head of a persistent-wave loop was
+// structurized by hipcc 7.2 so that lanes 1..63 re-entered the loop with lane 0 masked: an endless loop.)
+// Call only from wave-uniform control flow.
+__device__ __forceinline__ uint32_t otg_wave_atomic_add(uint32_t* ctr, uint32_t val)
+{
+  uint32_t r;
+  uint64_t saved;
+  asm volatile(
+      "s_mov_b64 %1, exec\n\t"
+      "s_mov_b64 exec, 1\n\t"
+      "global_atomic_add %0, %2, %3, off sc0\n\t"
+      "s_waitcnt vmcnt(0)\n\t"
+      "s_mov_b64 exec, %1"
+      : "=&v"(r), "=&s"(saved)
+      : "v"(ctr), "v"(val)
+      : "memory");
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
+}
+#endif
+
+// ---- device-resident launch helpers implemented in the .hip files -------------------------------------
+// All take device pointers; they enqueue on ctx->stream and do not synchronise unless stated.
+
+// wfa_edit.hip
+int otg_launch_edit(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_task* d_tasks, uint32_t n_tasks,
+                    int32_t* d_scores, uint64_t* d_cells, float* kernel_ms, uint64_t* launches);
+
+// wfa_affine.hip — forward + backtrace + unpack; CIGARs land in d_cig_arena at d_cig_off (precomputed
+// exclusive prefix of pattern_len+text_len per task), lengths in d_cig_len.  Synchronises internally
+// (multi-round when the backtrace pool is smaller than the batch needs).
+int otg_launch_affine(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_task* d_tasks, uint32_t n_tasks,
+                      int x, int o, int e, int32_t* d_scores, const uint64_t* d_cig_off, uint32_t* d_cig_len,
+                      uint8_t* d_cig_arena, uint64_t* d_cells);
+
+// cluster.hip
+int otg_launch_cluster(otg_ctx* ctx, const otg_params* P, const double* d_dist, const uint64_t* d_dist_off,
+                       const uint32_t* d_read_len, const uint64_t* d_len_off, const uint32_t* d_n_valid,
+                       uint32_t n_regions, int32_t* d_labels, int32_t* d_ic, int32_t* d_fc, double* d_bounds,
+                       int32_t* d_err);
+
+// poa.hip
+int otg_launch_poa(otg_ctx* ctx, const uint8_t* d_seq_arena, const uint8_t* d_cig_arena,
+                   const otg_poa_member* d_members, uint32_t n_members, const otg_poa_graph* d_graphs,
+                   const otg_poa_graph* h_graphs, const otg_poa_member* h_members, uint32_t n_graphs,
+                   const uint64_t* d_out_off, uint32_t* d_out_len, uint8_t* d_out_arena);
+
+// genotype.hip
+int otg_launch_genotype(otg_ctx* ctx, const otg_params* P, const uint8_t* d_arena, const uint64_t* d_seq_off,
+                        const uint32_t* d_seq_len, const uint32_t* d_first, const uint32_t* d_n, uint32_t n_regions,
+                        uint32_t max_alleles_per_region, int32_t* d_gt, int32_t* d_gtl, int32_t* d_gtk,
+                        double* d_hsd, int32_t* d_ngt, int32_t* d_reps);

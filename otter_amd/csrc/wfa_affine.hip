@@ -1,0 +1,335 @@
+// wfa_affine.hip — batched gap-affine wavefront aligner with full op string (gfx950).
+//
+// Replaces wfa::WFAlignerGapAffine(x,o,e, Alignment, MemoryMed)::alignEnd2End / alignEndsFree +
+// getAlignmentCigar() (reference: src/assemble.cpp:50; call sites src/analignments.cpp:25,31,37,268-280).
+//
+// One wave64 per alignment, persistent waves + device ticket.  Per wave, in HBM/L2:
+//   * rings of wavefront rows (int32 offsets, index = k + plen + 1): M keeps max(x,o+e)/g + 1 rows,
+//     I and D keep e/g + 1 rows (scores are walked in units of g = gcd(x, o+e, e): (4,6,2) -> 2,4,1);
+//   * one provenance byte per (score, diagonal): bits0-1 M origin (0 mismatch, 1 deletion, 2 insertion),
+//     bit2 I came from extension, bit3 D came from extension — the piggy-back rule of WFA2
+//     (ext >= open; M provenance tested in the order ins, del, mism so
+//     mismatch wins ties over deletion over insertion); rows are bump-allocated in a per-wave slab and
+//     addressed through a per-wave row table;
+//   * the reversed op list of the backtrace.
+// After the forward pass the same wave walks the provenance back (uniform scalar walk), then unpacks the
+// ops forward, re-deriving match runs 64 bytes at a time with a ballot (pcigar_unpack_affine semantics:
+// matches are extended only in the M state; a gap close is a marker, not an op), and writes the op string
+// (M X I D, free end gaps explicit).  A task whose provenance does not fit the tier-1 slab is queued on the
+// device for tier 2 (few waves, large slabs).
+#include "otg_common.hpp"
+#include <algorithm>
+
+namespace {
+
+struct AffWs {
+  uint8_t* base;        // per-wave workspaces, contiguous
+  size_t stride;        // bytes per wave
+  size_t off_rowtab, off_rev, off_slab;
+  size_t slab_bytes;
+  int capa;             // diagonals per ring row
+  int rm, ri;           // ring depths
+  int nrows;            // row-table entries
+  size_t rev_cap;
+};
+
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+
+template <int WPB>
+__global__ __launch_bounds__(WPB * 64) void wfa_affine_kernel(
+    const uint8_t* __restrict__ arena, const otg_align_task* __restrict__ tasks,
+    const uint32_t* __restrict__ todo, const uint32_t* __restrict__ n_todo_ptr, uint32_t n_todo_imm,
+    int xs, int oes, int es, int g,
+    int32_t* __restrict__ scores, const uint64_t* __restrict__ cig_off, uint32_t* __restrict__ cig_len,
+    uint8_t* __restrict__ cig_arena, uint64_t* __restrict__ cells,
+    uint32_t* __restrict__ ticket, uint32_t* __restrict__ n_overflow, uint32_t* __restrict__ overflow_list,
+    AffWs ws)
+{
+  __shared__ int s_lo[WPB][3][64];
+  __shared__ int s_hi[WPB][3][64];
+  const int lane = threadIdx.x & 63;
+  const int wib = threadIdx.x >> 6;
+  uint8_t* my = ws.base + (size_t)(blockIdx.x * WPB + wib) * ws.stride;
+  int32_t* ringM = (int32_t*)my;
+  int32_t* ringI = ringM + (size_t)ws.rm * ws.capa;
+  int32_t* ringD = ringI + (size_t)ws.ri * ws.capa;
+  int64_t* rowtab = (int64_t*)(my + ws.off_rowtab);
+  uint8_t* rev = my + ws.off_rev;
+  uint8_t* slab = my + ws.off_slab;
+  int* mlo = s_lo[wib][0]; int* mhi = s_hi[wib][0];
+  int* ilo = s_lo[wib][1]; int* ihi = s_hi[wib][1];
+  int* dlo = s_lo[wib][2]; int* dhi = s_hi[wib][2];
+  const uint32_t n_todo = n_todo_ptr ? *n_todo_ptr : n_todo_imm;
+
+  for (;;) {
+    const uint32_t tk = otg_wave_atomic_add(ticket, 1u);
+    if (tk >= n_todo) break;
+    const uint32_t ti = todo ? todo[tk] : tk;
+    const otg_align_task t = tasks[ti];
+    const uint8_t* P = arena + t.pattern_off;
+    const uint8_t* T = arena + t.text_off;
+    const int pl = (int)t.pattern_len, tl = (int)t.text_len;
+    const bool ef = t.endsfree != 0;
+    const int pef = t.pattern_end_free, tef = t.text_end_free;
+    const int kb = pl + 1; // ring index of diagonal k is k + kb
+    const int kend = tl - pl;
+    bool fail = (pl + tl + 3 > ws.capa);
+    size_t slab_top = 0;
+    uint64_t W = 0;
+    int s_end = -1, k_end = 0;
+
+    // ---------------- forward pass
+    for (int s = 0; !fail; ++s) {
+      if (s >= ws.nrows) { fail = true; break; }
+      const int sm = s % ws.rm, si = s % ws.ri;
+      int lo, hi;
+      const int32_t *Mx = nullptr, *Mo = nullptr, *Ie = nullptr, *De = nullptr;
+      int mxlo = 1, mxhi = 0, molo = 1, mohi = 0, ielo = 1, iehi = 0, delo = 1, dehi = 0;
+      if (s == 0) {
+        lo = ef ? imax(-t.pattern_begin_free, -pl) : 0;
+        hi = ef ? imin(t.text_begin_free, tl) : 0;
+      } else {
+        lo = 1 << 30; hi = -(1 << 30);
+        if (s - xs >= 0) { int q = (s - xs) % ws.rm; mxlo = mlo[q]; mxhi = mhi[q]; Mx = ringM + (size_t)q * ws.capa; }
+        if (s - oes >= 0) { int q = (s - oes) % ws.rm; molo = mlo[q]; mohi = mhi[q]; Mo = ringM + (size_t)q * ws.capa; }
+        if (s - es >= 0) { int q = (s - es) % ws.ri; ielo = ilo[q]; iehi = ihi[q]; delo = dlo[q]; dehi = dhi[q];
+                           Ie = ringI + (size_t)q * ws.capa; De = ringD + (size_t)q * ws.capa; }
+        if (mxhi >= mxlo) { lo = imin(lo, mxlo); hi = imax(hi, mxhi); }
+        if (mohi >= molo) { lo = imin(lo, molo - 1); hi = imax(hi, mohi + 1); }
+        if (iehi >= ielo) { lo = imin(lo, ielo + 1); hi = imax(hi, iehi + 1); }
+        if (dehi >= delo) { lo = imin(lo, delo - 1); hi = imax(hi, dehi - 1); }
+        if (lo < -pl) lo = -pl;
+        if (hi > tl) hi = tl;
+      }
+      if (hi < lo) { // null wavefront: this score is not reachable
+        mlo[sm] = 1; mhi[sm] = 0; ilo[si] = 1; ihi[si] = 0; dlo[si] = 1; dhi[si] = 0; rowtab[s] = -1;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        if (s > g * 0 + 2 * (oes + es * (pl + tl)) + 8) { fail = true; }
+        continue;
+      }
+      const int width = hi - lo + 1;
+      if (slab_top + (size_t)width > ws.slab_bytes) { fail = true; break; }
+      uint8_t* btrow = slab + slab_top - lo;   // btrow[k]
+      rowtab[s] = (int64_t)slab_top - lo; mlo[sm] = lo; mhi[sm] = hi;
+      if (s == 0) { ilo[si] = 1; ihi[si] = 0; dlo[si] = 1; dhi[si] = 0; }   // no I/D wavefront at score 0
+      else { ilo[si] = lo; ihi[si] = hi; dlo[si] = lo; dhi[si] = hi; }
+      slab_top += (size_t)width;
+      W += 3ull * (uint64_t)width;
+      int32_t* Mc = ringM + (size_t)sm * ws.capa;
+      int32_t* Ic = ringI + (size_t)si * ws.capa;
+      int32_t* Dc = ringD + (size_t)si * ws.capa;
+      bool done = false;
+      for (int c = lo; c <= hi && !done; c += 64) {
+        const int k = c + lane;
+        const int j = k + kb;
+        const bool in = k <= hi;
+        int mx, ins = OTG_NULL_OFF, del = OTG_NULL_OFF;
+        uint32_t bits = 0;
+        if (s == 0) {
+          mx = k > 0 ? k : 0;
+        } else {
+          int io = (Mo && k - 1 >= molo && k - 1 <= mohi) ? Mo[j - 1] : OTG_NULL_OFF;
+          int dop = (Mo && k + 1 >= molo && k + 1 <= mohi) ? Mo[j + 1] : OTG_NULL_OFF;
+          int ix = (Ie && k - 1 >= ielo && k - 1 <= iehi) ? Ie[j - 1] : OTG_NULL_OFF;
+          int dx = (De && k + 1 >= delo && k + 1 <= dehi) ? De[j + 1] : OTG_NULL_OFF;
+          int mm = (Mx && k >= mxlo && k <= mxhi) ? Mx[j] : OTG_NULL_OFF;
+          if (ix >= io) { ins = ix; bits |= 4u; } else ins = io;
+          ins += 1;
+          if (dx >= dop) { del = dx; bits |= 8u; } else del = dop;
+          const int mis = mm + 1;
+          mx = imax(del, imax(mis, ins));
+          uint32_t org = 0;
+          if (mx == ins) org = 2;
+          if (mx == del) org = 1;
+          if (mx == mis) org = 0;
+          bits |= org;
+          if (ins < 0) ins = OTG_NULL_OFF;
+          if (del < 0) del = OTG_NULL_OFF;
+        }
+        int h = mx, v = mx - k;
+        const bool valid = in && mx >= 0 && h <= tl && v <= pl;
+        bool act = valid;
+        for (;;) {
+          const bool go = act && v < pl && h < tl;
+          if (!__any(go)) break;
+          if (go) {
+            uint64_t a, b;
+            __builtin_memcpy(&a, P + v, 8);
+            __builtin_memcpy(&b, T + h, 8);
+            const uint64_t xx = a ^ b;
+            int m = xx ? (__builtin_ctzll(xx) >> 3) : 8;
+            const int rem = imin(pl - v, tl - h);
+            m = imin(m, rem);
+            v += m; h += m;
+            act = (m == 8);
+          } else act = false;
+        }
+        if (in) {
+          Mc[j] = valid ? h : OTG_NULL_OFF;
+          Ic[j] = ins; Dc[j] = del;
+          btrow[k] = (uint8_t)bits;
+        }
+        bool fin;
+        if (ef) fin = valid && ((h >= tl && pl - v <= pef) || (v >= pl && tl - h <= tef));
+        else fin = valid && k == kend && h >= tl;
+        const unsigned long long fm = __ballot(fin);
+        if (fm) { done = true; s_end = s; k_end = c + (int)__builtin_ctzll(fm); }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      if (done) break;
+    }
+
+    if (fail || s_end < 0) {
+      if (overflow_list) { const uint32_t q = otg_wave_atomic_add(n_overflow, 1u); overflow_list[q] = ti; }
+      else { scores[ti] = -1; cig_len[ti] = 0; }
+      continue;
+    }
+
+    // ---------------- backtrace (uniform walk; every lane follows the same path, lane 0 records)
+    uint32_t nrev = 0;
+    int k0;
+    {
+      int s = s_end, k = k_end, comp = 0;
+      bool bt_fail = false;
+      while (s > 0 || comp != 0) {
+        const int64_t rb = rowtab[s];
+        const uint32_t bits = slab[rb + k];
+        uint8_t op;
+        if (comp == 0) {
+          const uint32_t org = bits & 3u;
+          if (org == 0) { op = 'X'; s -= xs; }
+          else if (org == 1) { op = 'c'; comp = 2; }
+          else { op = 'c'; comp = 1; }
+        } else if (comp == 1) {
+          op = 'I';
+          if (bits & 4u) s -= es; else { s -= oes; comp = 0; }
+          k -= 1;
+        } else {
+          op = 'D';
+          if (bits & 8u) s -= es; else { s -= oes; comp = 0; }
+          k += 1;
+        }
+        if (nrev >= ws.rev_cap || s < 0) { bt_fail = true; break; }
+        rev[nrev] = op; /* every lane stores the same byte: keeps the walk free of divergent branches */
+        ++nrev;
+      }
+      k0 = k;
+      if (bt_fail) {
+        scores[ti] = -2; cig_len[ti] = 0;
+        continue;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+
+    // ---------------- forward unpack
+    uint8_t* out = cig_arena + cig_off[ti];
+    uint32_t pos = 0;
+    int h = k0 > 0 ? k0 : 0, v = k0 < 0 ? -k0 : 0;
+    for (int q = lane; q < h; q += 64) out[q] = 'I';
+    pos += h;
+    for (int q = lane; q < v; q += 64) out[pos + q] = 'D';
+    pos += v;
+    auto emit_matches = [&]() {
+      for (;;) {
+        const int rem = imin(pl - v, tl - h);
+        if (rem <= 0) break;
+        const int n = rem < 64 ? rem : 64;
+        const bool eq = lane < n && P[v + lane] == T[h + lane];
+        const unsigned long long ne = ~__ballot(eq);
+        const int m = ne ? (int)__builtin_ctzll(ne) : 64;
+        if (lane < m) out[pos + lane] = 'M';
+        v += m; h += m; pos += m;
+        if (m < 64) break;
+      }
+    };
+    int state = 0;
+    for (int q = (int)nrev - 1; q >= 0; --q) {
+      if (state == 0) emit_matches();
+      const uint8_t op = rev[q];
+      if (op == 'I') { out[pos] = 'I'; ++pos; ++h; state = 1; }
+      else if (op == 'D') { out[pos] = 'D'; ++pos; ++v; state = 2; }
+      else if (op == 'c') { state = 0; }
+      else { out[pos] = 'X'; ++pos; ++v; ++h; }
+    }
+    emit_matches();
+    { const int n = tl - h; for (int q = lane; q < n; q += 64) out[pos + q] = 'I'; if (n > 0) { pos += n; h = tl; } }
+    { const int n = pl - v; for (int q = lane; q < n; q += 64) out[pos + q] = 'D'; if (n > 0) { pos += n; v = pl; } }
+    scores[ti] = s_end * g;
+    cig_len[ti] = pos;
+    if (cells) cells[ti] = W;
+  }
+}
+
+int gcd3(int a, int b, int c)
+{
+  auto g2 = [](int x, int y) { while (y) { int t = x % y; x = y; y = t; } return x; };
+  return g2(g2(a, b), c);
+}
+
+} // namespace
+
+int otg_launch_affine(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_task* d_tasks, uint32_t n_tasks,
+                      int x, int o, int e, int32_t* d_scores, const uint64_t* d_cig_off, uint32_t* d_cig_len,
+                      uint8_t* d_cig_arena, uint64_t* d_cells)
+{
+  if (n_tasks == 0) return OTG_OK;
+  if (x <= 0 || e <= 0 || o < 0) return otg_fail(ctx, OTG_ERR_ARG, "affine penalties must satisfy x>0, o>=0, e>0");
+  const int g = gcd3(x, o + e, e);
+  const int xs = x / g, oes = (o + e) / g, es = e / g;
+  if (std::max(xs, oes) + 1 > 64 || es + 1 > 64) return otg_fail(ctx, OTG_ERR_ARG, "affine penalties too large after gcd reduction");
+  uint32_t* cnt = (uint32_t*)otg_slot(ctx, SLOT_COUNTERS, 64 * sizeof(uint32_t));
+  uint32_t* todo = (uint32_t*)otg_slot(ctx, SLOT_TODO, 2 * (size_t)n_tasks * sizeof(uint32_t));
+  if (!cnt || !todo) return OTG_ERR_HIP;
+  HIP_TRY(ctx, hipMemsetAsync(cnt + 8, 0, 8 * sizeof(uint32_t), ctx->stream));
+
+  const size_t maxlen = ctx->max_seq_len;
+  AffWs ws;
+  ws.capa = (int)(2 * maxlen + 8);
+  ws.rm = std::max(xs, oes) + 1;
+  ws.ri = es + 1;
+  ws.nrows = (int)(2 * (size_t)oes + (size_t)es * 2 * maxlen + 16);
+  ws.rev_cap = 4 * maxlen + 64;
+  size_t ring_bytes = (size_t)(ws.rm + 2 * ws.ri) * ws.capa * sizeof(int32_t);
+  ws.off_rowtab = (ring_bytes + 255) & ~(size_t)255;
+  ws.off_rev = (ws.off_rowtab + (size_t)ws.nrows * sizeof(int64_t) + 255) & ~(size_t)255;
+  ws.off_slab = (ws.off_rev + ws.rev_cap + 255) & ~(size_t)255;
+
+  size_t free_b = 0, total_b = 0;
+  HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+  // reuse what SLOT_WF_WS already holds
+  free_b += ctx->pool[SLOT_WF_WS].cap;
+  constexpr int WPB = 4;
+  // tier 1: many waves, slab sized for ONT-divergence alignments of the batch's longest reads
+  uint32_t want_waves = std::min<uint32_t>((uint32_t)ctx->n_cu * 8, n_tasks);
+  uint32_t grid1 = (want_waves + WPB - 1) / WPB;
+  size_t budget = (size_t)(free_b * 0.6);
+  size_t slab1 = (size_t)(0.5 * (double)maxlen * (double)maxlen) + (1 << 16);   // ~ (0.7 L)^2 cells
+  if (slab1 > ((size_t)96 << 20)) slab1 = (size_t)96 << 20;
+  while (grid1 > 1 && (ws.off_slab + slab1) * (size_t)grid1 * WPB > budget) {
+    if (slab1 > ((size_t)4 << 20)) slab1 /= 2; else grid1 = (grid1 + 1) / 2;
+  }
+  ws.slab_bytes = slab1 & ~(size_t)255;
+  ws.stride = ws.off_slab + ws.slab_bytes;
+  size_t need1 = ws.stride * (size_t)grid1 * WPB;
+  // tier 2: few waves, slab = worst case useful size
+  AffWs ws2 = ws;
+  uint32_t grid2 = 8;
+  size_t slab2 = std::min<size_t>((size_t)2 * maxlen * (size_t)(ws.nrows) , budget / (grid2 * WPB));
+  if (slab2 > ws.off_slab + 256) slab2 -= ws.off_slab + 256;
+  ws2.slab_bytes = slab2 & ~(size_t)255;
+  ws2.stride = ws2.off_slab + ws2.slab_bytes;
+  size_t need2 = ws2.stride * (size_t)grid2 * WPB;
+  uint8_t* wsp = (uint8_t*)otg_slot(ctx, SLOT_WF_WS, std::max(need1, need2));
+  if (!wsp) return OTG_ERR_HIP;
+  ws.base = wsp; ws2.base = wsp;
+
+  hipLaunchKernelGGL((wfa_affine_kernel<WPB>), dim3(grid1), dim3(WPB * 64), 0, ctx->stream, d_arena, d_tasks,
+                     (const uint32_t*)nullptr, (const uint32_t*)nullptr, n_tasks, xs, oes, es, g, d_scores, d_cig_off, d_cig_len,
+                     d_cig_arena, d_cells, cnt + 8, cnt + 9, todo, ws);
+  hipLaunchKernelGGL((wfa_affine_kernel<WPB>), dim3(grid2), dim3(WPB * 64), 0, ctx->stream, d_arena, d_tasks,
+                     (const uint32_t*)todo, (const uint32_t*)(cnt + 9), 0u, xs, oes, es, g, d_scores, d_cig_off, d_cig_len,
+                     d_cig_arena, d_cells, cnt + 10, cnt + 11, (uint32_t*)nullptr, ws2);
+  HIP_TRY(ctx, hipGetLastError());
+  return OTG_OK;
+}

@@ -1,0 +1,201 @@
+// wfa_edit.hip — batched unit-cost wavefront aligner, score only (gfx950).
+//
+// Replaces wfa::WFAlignerEdit(Score, MemoryMed)::alignEnd2End / alignEndsFree + getAlignmentScore()
+// (reference: src/assemble.cpp:49; call sites src/analignments.cpp:70-71,88-97).
+//
+// Mapping: ONE wave64 per alignment.  The wavefront of furthest-reaching offsets lives in LDS
+// (one int32 per diagonal, updated IN PLACE: chunks of 64 diagonals are swept in ascending order, the
+// left neighbour of lane 0 is carried in an SGPR-uniform register, the right neighbour of lane 63 is
+// still the old value).  Lanes = diagonals; the extend step compares 8 sequence bytes per iteration
+// (unaligned 64-bit loads, xor + ctz) and the wave leaves the extend loop on a ballot.
+// Work distribution: persistent waves pull tickets from one device counter (tasks differ ~100x in cost).
+// Three capacity tiers share this code: LDS 2048 diagonals/wave (20 waves/CU), LDS 16384/wave
+// (2 waves/CU), and a global-memory wavefront for anything wider; a tier that runs out of diagonals
+// appends the task to the next tier's todo list on the device (no host round trip).
+//
+// Recurrence: M[s][k] = max(M[s-1][k-1]+1, M[s-1][k]+1, M[s-1][k+1]), nulled
+// when h>tlen or v>plen; k = h - v, offset = h.  End2end stops when M[s][tlen-plen] == tlen; ends-free
+// when any diagonal reaches a permitted boundary (score only: which diagonal does not matter).
+#include "otg_common.hpp"
+#include <cstdlib>
+
+namespace {
+
+using lds_i32 = __attribute__((address_space(3))) int32_t;
+
+__device__ __forceinline__ uint64_t load8(const uint8_t* p)
+{
+  uint64_t v;
+  __builtin_memcpy(&v, p, 8);
+  return v;
+}
+
+template <int CAP, int WPB, bool GLOBAL_WF>
+__global__ __launch_bounds__(WPB * 64) void wfa_edit_kernel(
+    const uint8_t* __restrict__ arena, const otg_align_task* __restrict__ tasks,
+    const uint32_t* __restrict__ todo, const uint32_t* __restrict__ n_todo_ptr, uint32_t n_todo_imm,
+    int32_t* __restrict__ scores, uint64_t* __restrict__ cells,
+    uint32_t* __restrict__ ticket, uint32_t* __restrict__ n_overflow, uint32_t* __restrict__ overflow_list,
+    int32_t* gws, int gcap)
+{
+  extern __shared__ __attribute__((aligned(16))) int32_t smem[];
+  const int lane = threadIdx.x & 63;
+  const int wib = threadIdx.x >> 6;
+  const int cap = GLOBAL_WF ? gcap : CAP;
+  // volatile keeps program order of the in-place, cross-lane wavefront updates (a wave's DS / VMEM ops
+  // execute in issue order); the LDS pointer keeps its address space so these stay ds_read/ds_write.
+  volatile int32_t* gwf = GLOBAL_WF ? (volatile int32_t*)(gws + (size_t)(blockIdx.x * WPB + wib) * (size_t)gcap) : nullptr;
+  volatile lds_i32* lwf = (volatile lds_i32*)smem + wib * CAP;
+  auto wf_rd = [&](int j) -> int { if constexpr (GLOBAL_WF) return gwf[j]; else return lwf[j]; };
+  auto wf_wr = [&](int j, int v) { if constexpr (GLOBAL_WF) gwf[j] = v; else lwf[j] = v; };
+  const uint32_t n_todo = n_todo_ptr ? *n_todo_ptr : n_todo_imm;
+
+  for (;;) {
+    const uint32_t tk = otg_wave_atomic_add(ticket, 1u);
+    if (tk >= n_todo) break;
+    const uint32_t ti = todo ? todo[tk] : tk;
+    const otg_align_task t = tasks[ti];
+    const uint8_t* P = arena + t.pattern_off;
+    const uint8_t* T = arena + t.text_off;
+    const int pl = (int)t.pattern_len, tl = (int)t.text_len;
+    const bool ef = t.endsfree != 0;
+    const int pef = t.pattern_end_free, tef = t.text_end_free;
+    int lo = ef ? -t.pattern_begin_free : 0, hi = ef ? t.text_begin_free : 0;
+    if (lo < -pl) lo = -pl;
+    if (hi > tl) hi = tl;
+    const int kend = tl - pl;
+    const int kbase = lo - ((cap - (hi - lo + 1)) >> 1);
+    int lo_prev = lo, hi_prev = hi;
+    int s = 0;
+    uint64_t W = 0;
+    bool done = false, overflow = false;
+    if (hi - lo + 1 > cap) overflow = true;
+
+    while (!overflow) {
+      W += (uint64_t)(hi - lo + 1);
+      int carry = OTG_NULL_OFF;
+      bool any_done = false;
+      for (int c = lo; c <= hi; c += 64) {
+        const int k = c + lane;
+        const int j = k - kbase;
+        const bool in = k <= hi;
+        int mx;
+        if (s == 0) {
+          mx = k > 0 ? k : 0;
+        } else {
+          int o = (k >= lo_prev && k <= hi_prev) ? wf_rd(j) : OTG_NULL_OFF;
+          int r = (k + 1 >= lo_prev && k + 1 <= hi_prev) ? wf_rd(j + 1) : OTG_NULL_OFF;
+          int l = __shfl_up(o, 1);
+          if (lane == 0) l = carry;
+          carry = __shfl(o, 63);
+          int a = l + 1, b = o + 1;
+          mx = a > b ? a : b;
+          mx = r > mx ? r : mx;
+        }
+        int h = mx, v = mx - k;
+        bool valid = in && mx >= 0 && h <= tl && v <= pl;
+        bool act = valid;
+        for (;;) {
+          const bool go = act && v < pl && h < tl;
+          if (!__any(go)) break;
+          if (go) {
+            const uint64_t x = load8(P + v) ^ load8(T + h);
+            int m = x ? (__builtin_ctzll(x) >> 3) : 8;
+            int rem = pl - v < tl - h ? pl - v : tl - h;
+            m = m < rem ? m : rem;
+            v += m; h += m;
+            act = (m == 8);
+          } else act = false;
+        }
+        if (in) wf_wr(j, valid ? h : OTG_NULL_OFF);
+        bool fin;
+        if (ef) fin = valid && ((h >= tl && pl - v <= pef) || (v >= pl && tl - h <= tef));
+        else fin = valid && k == kend && h >= tl;
+        any_done |= __any(fin) != 0;
+      }
+      if (any_done) { done = true; break; }
+      lo_prev = lo; hi_prev = hi;
+      lo = lo - 1 < -pl ? -pl : lo - 1;
+      hi = hi + 1 > tl ? tl : hi + 1;
+      ++s;
+      if (lo - kbase < 0 || hi - kbase + 1 >= cap) overflow = true;
+      if (s > pl + tl + 2) break; /* cannot happen: edit distance <= max(pl,tl) */
+    }
+    // wave-uniform tail: every lane stores the same value to the same address (one write after coalescing)
+    if (done) {
+      scores[ti] = s;
+      if (cells) cells[ti] = W;
+    } else if (overflow && overflow_list) {
+      const uint32_t q = otg_wave_atomic_add(n_overflow, 1u);
+      overflow_list[q] = ti;
+    } else {
+      scores[ti] = -1;
+    }
+  }
+}
+
+} // namespace
+
+// Enqueue the three capacity tiers.  Requires: d_arena padded with >= 8 readable bytes after the last
+// sequence byte.  Uses SLOT_COUNTERS (16 u32), SLOT_TODO (2*n_tasks u32), SLOT_WF_WS (tier 3 only).
+int otg_launch_edit(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_task* d_tasks, uint32_t n_tasks,
+                    int32_t* d_scores, uint64_t* d_cells, float* kernel_ms, uint64_t* launches)
+{
+  if (n_tasks == 0) return OTG_OK;
+  uint32_t* cnt = (uint32_t*)otg_slot(ctx, SLOT_COUNTERS, 64 * sizeof(uint32_t));
+  uint32_t* todo = (uint32_t*)otg_slot(ctx, SLOT_TODO, 2 * (size_t)n_tasks * sizeof(uint32_t));
+  if (!cnt || !todo) return OTG_ERR_HIP;
+  HIP_TRY(ctx, hipMemsetAsync(cnt, 0, 64 * sizeof(uint32_t), ctx->stream));
+  uint32_t* todo2 = todo;            // overflow of tier 1
+  uint32_t* todo3 = todo + n_tasks;  // overflow of tier 2
+  if (kernel_ms) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  {
+    constexpr int CAP = 2048, WPB = 4;
+    const size_t lds = (size_t)CAP * WPB * sizeof(int32_t);
+    uint32_t want = (n_tasks + WPB - 1) / WPB;
+    uint32_t grid = (uint32_t)ctx->n_cu * 5;
+    if (grid > want) grid = want;
+    hipLaunchKernelGGL((wfa_edit_kernel<CAP, WPB, false>), dim3(grid), dim3(WPB * 64), lds, ctx->stream, d_arena, d_tasks,
+                       (const uint32_t*)nullptr, (const uint32_t*)nullptr, n_tasks, d_scores, d_cells, cnt + 0, cnt + 1, todo2,
+                       (int32_t*)nullptr, 0);
+  }
+  if (kernel_ms) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  if (getenv("OTG_DEBUG")) { hipError_t e = hipStreamSynchronize(ctx->stream); fprintf(stderr, "[otg] tier1 done: %s\n", hipGetErrorString(e)); }
+  {
+    constexpr int CAP = 16384, WPB = 2;
+    const size_t lds = (size_t)CAP * WPB * sizeof(int32_t);
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)wfa_edit_kernel<CAP, WPB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    uint32_t grid = (uint32_t)ctx->n_cu;
+    hipLaunchKernelGGL((wfa_edit_kernel<CAP, WPB, false>), dim3(grid), dim3(WPB * 64), lds, ctx->stream, d_arena, d_tasks,
+                       (const uint32_t*)todo2, (const uint32_t*)(cnt + 1), 0u, d_scores, d_cells, cnt + 2, cnt + 3, todo3,
+                       (int32_t*)nullptr, 0);
+  }
+  if (getenv("OTG_DEBUG")) { hipError_t e = hipStreamSynchronize(ctx->stream); fprintf(stderr, "[otg] tier2 done: %s\n", hipGetErrorString(e)); }
+  {
+    // tier 3: global-memory wavefront sized for the longest possible pair; only reached by huge inputs
+    constexpr int WPB = 4;
+    uint32_t grid = (uint32_t)ctx->n_cu;
+    int gcap = (int)(2 * (size_t)ctx->max_seq_len + 4);
+    int32_t* ws = (int32_t*)otg_slot(ctx, SLOT_WF_WS, (size_t)grid * WPB * (size_t)gcap * sizeof(int32_t));
+    if (!ws) return OTG_ERR_HIP;
+    hipLaunchKernelGGL((wfa_edit_kernel<0, WPB, true>), dim3(grid), dim3(WPB * 64), 0, ctx->stream, d_arena, d_tasks,
+                       (const uint32_t*)todo3, (const uint32_t*)(cnt + 3), 0u, d_scores, d_cells, cnt + 4, cnt + 5,
+                       (uint32_t*)nullptr, ws, gcap);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  if (getenv("OTG_DEBUG")) {
+    fprintf(stderr, "[otg] edit tiers enqueued (n_tasks=%u)\n", n_tasks);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    uint32_t h[8];
+    (void)hipMemcpy(h, cnt, sizeof(h), hipMemcpyDeviceToHost);
+    fprintf(stderr, "[otg] edit sync: %s; tickets %u/%u/%u overflow %u/%u\n", hipGetErrorString(e), h[0], h[2], h[4], h[1], h[3]);
+  }
+  if (kernel_ms) {
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *kernel_ms += ms;
+    if (launches) *launches += 1;
+  }
+  return OTG_OK;
+}

@@ -1,0 +1,78 @@
+"""GPU parity: batched gap-affine WFA kernel (score + op string) vs the CPU oracle — bit-exact."""
+import numpy as np
+import pytest
+from helpers import rand_seq, mutate, tr_seq, pair_tasks
+
+pytestmark = pytest.mark.gpu
+
+
+def _pairs(rng, n, lmax, endsfree_every=3):
+    pairs, forms = [], []
+    for i in range(n):
+        L = int(rng.integers(0, lmax))
+        a = tr_seq(rng, L) if i % 2 else rand_seq(rng, L)
+        mode = i % 5
+        b = rand_seq(rng, int(rng.integers(0, lmax))) if mode == 4 else mutate(rng, a, [0.002, 0.07, 0.15, 0.3][mode])
+        f = None
+        if endsfree_every and i % endsfree_every == 0:
+            d = len(a) - len(b)
+            if d >= 0:
+                f = [(0, d, 0, 0), (d, 0, 0, 0), (d // 2, d // 2, 0, 0)][(i // 3) % 3]
+            else:
+                f = [(0, 0, 0, -d), (0, 0, -d, 0)][(i // 3) % 2]
+        pairs.append((a, b))
+        forms.append(f)
+    return pairs, forms
+
+
+def test_affine_small_mixed(gpu, oracle):
+    rng = np.random.default_rng(21)
+    pairs, forms = _pairs(rng, 500, 260)
+    pairs += [(b"", b""), (b"A", b""), (b"", b"ACGT"), (b"ACGT", b"ACGT"), (b"ACTGGA", b"ACCGA")]
+    forms += [None] * 5
+    arena, tasks = pair_tasks(pairs, forms)
+    gs, gc, gcells = gpu.affine_align_batch(arena, tasks, want_cells=True)
+    es, ec, ecells = oracle.affine_align_batch(arena, tasks, want_cells=True)
+    assert np.array_equal(gs, es)
+    assert gc == ec
+    assert np.array_equal(gcells, ecells)
+
+
+def test_affine_other_penalties(gpu, oracle):
+    rng = np.random.default_rng(22)
+    pairs, forms = _pairs(rng, 120, 200)
+    arena, tasks = pair_tasks(pairs, forms)
+    for (x, o, e) in [(1, 0, 1), (3, 5, 1), (2, 4, 2), (6, 2, 3)]:
+        gs, gc = gpu.affine_align_batch(arena, tasks, x, o, e)
+        es, ec = oracle.affine_align_batch(arena, tasks, x, o, e)
+        assert np.array_equal(gs, es), (x, o, e)
+        assert gc == ec, (x, o, e)
+
+
+def test_affine_long_ont(gpu, oracle):
+    rng = np.random.default_rng(23)
+    pairs = []
+    for i in range(24):
+        L = int(rng.integers(1000, 4000))
+        a = mutate(rng, tr_seq(rng, L), 0.07)
+        b = mutate(rng, a, 0.07 if i % 3 else 0.2)
+        pairs.append((a, b))
+    arena, tasks = pair_tasks(pairs)
+    gs, gc = gpu.affine_align_batch(arena, tasks)
+    es, ec = oracle.affine_align_batch(arena, tasks)
+    assert np.array_equal(gs, es)
+    assert gc == ec
+
+
+def test_affine_cigar_valid_full_size(gpu, oracle):
+    """Size-independent property at 10 kb: the op string consumes both sequences, M/X agree with the bytes and
+    re-scoring it reproduces the reported penalty (oracle.cigar_score is a plain re-scorer)."""
+    rng = np.random.default_rng(24)
+    a = mutate(rng, tr_seq(rng, 10000), 0.07)
+    b = mutate(rng, a, 0.07)
+    arena, tasks = pair_tasks([(a, b), (a, a)])
+    gs, gc = gpu.affine_align_batch(arena, tasks)
+    assert gs[1] == 0 and gc[1] == b"M" * len(a)
+    assert oracle.cigar_score(a, b, gc[0]) == gs[0]
+    assert gc[0].count(b"M") + gc[0].count(b"X") + gc[0].count(b"D") == len(a)
+    assert gc[0].count(b"M") + gc[0].count(b"X") + gc[0].count(b"I") == len(b)

@@ -1,0 +1,91 @@
+"""GPU parity: batched edit-distance WFA kernel vs the CPU oracle (bit-exact integer scores)."""
+import numpy as np
+import pytest
+from helpers import rand_seq, mutate, tr_seq, pair_tasks
+
+pytestmark = pytest.mark.gpu
+
+
+def _mixed_pairs(rng, n, lmax):
+    pairs, forms = [], []
+    for i in range(n):
+        L = int(rng.integers(0, lmax))
+        a = tr_seq(rng, L) if i % 2 else rand_seq(rng, L)
+        mode = i % 5
+        if mode == 4:
+            b = rand_seq(rng, int(rng.integers(0, lmax)))
+        else:
+            b = mutate(rng, a, [0.002, 0.07, 0.15, 0.3][mode])
+        if len(b) > len(a):
+            a, b = b, a
+        f = None
+        if i % 3 == 0:
+            d = len(a) - len(b)
+            f = [(0, d, 0, 0), (d, 0, 0, 0), (d // 2, d // 2, 0, 0)][(i // 3) % 3]
+        pairs.append((a, b))
+        forms.append(f)
+    return pairs, forms
+
+
+def test_edit_small_mixed(gpu, oracle):
+    rng = np.random.default_rng(11)
+    pairs, forms = _mixed_pairs(rng, 600, 300)
+    pairs += [(b"", b""), (b"A", b""), (b"", b"ACGT"), (b"ACGT", b"ACGT"), (b"N" * 70, b"N" * 70), (b"acgt", b"ACGT")]
+    forms += [None] * 6
+    arena, tasks = pair_tasks(pairs, forms)
+    got, cells = gpu.edit_distance_batch(arena, tasks, want_cells=True)
+    exp, ecells = oracle.edit_distance_batch(arena, tasks, want_cells=True)
+    assert np.array_equal(got, exp)
+    assert np.array_equal(cells, ecells)
+
+
+def test_edit_long_ont(gpu, oracle):
+    rng = np.random.default_rng(12)
+    pairs = []
+    for i in range(48):
+        L = int(rng.integers(1000, 6000))
+        a = tr_seq(rng, L)
+        a = mutate(rng, a, 0.07)
+        b = mutate(rng, a, 0.07 if i % 2 else 0.25)
+        if len(b) > len(a):
+            a, b = b, a
+        pairs.append((a, b))
+    arena, tasks = pair_tasks(pairs)
+    got = gpu.edit_distance_batch(arena, tasks)
+    exp = oracle.edit_distance_batch(arena, tasks)
+    assert np.array_equal(got, exp)
+
+
+def test_edit_capacity_tiers(gpu, oracle):
+    """Pairs whose wavefront outgrows the 2048- and 16384-diagonal LDS tiers (unrelated sequences)."""
+    rng = np.random.default_rng(13)
+    pairs = [(rand_seq(rng, 3000), rand_seq(rng, 2500)),       # s ~ 1500 -> tier 2
+             (rand_seq(rng, 20000), rand_seq(rng, 9000)),       # |k| > 8192 -> tier 3 (global wavefront)
+             (rand_seq(rng, 40), rand_seq(rng, 30))]
+    arena, tasks = pair_tasks(pairs)
+    got = gpu.edit_distance_batch(arena, tasks)
+    exp = oracle.edit_distance_batch(arena, tasks)
+    assert np.array_equal(got, exp)
+
+
+def test_edit_properties_full_size(gpu):
+    """Size-independent properties at bench-like sizes: d(a,a)=0, symmetry, triangle inequality,
+    length-difference lower bound, and d(a, a with k substitutions) <= k."""
+    rng = np.random.default_rng(14)
+    L = 10000
+    a = mutate(rng, tr_seq(rng, L), 0.07)
+    b = mutate(rng, a, 0.07)
+    c = mutate(rng, b, 0.07)
+    sub = bytearray(a)
+    for p in rng.choice(len(a), 50, replace=False):
+        sub[p] = b"ACGT"[(b"ACGT".index(bytes([sub[p]])) + 1) % 4]
+    sub = bytes(sub)
+    def big(x, y):
+        return (x, y) if len(x) >= len(y) else (y, x)
+    arena, tasks = pair_tasks([(a, a), big(a, b), big(b, a), big(b, c), big(a, c), big(a, sub)])
+    d = gpu.edit_distance_batch(arena, tasks)
+    assert d[0] == 0
+    assert d[1] == d[2]
+    assert d[4] <= d[1] + d[3]
+    assert d[1] >= abs(len(a) - len(b))
+    assert 0 < d[5] <= 50
