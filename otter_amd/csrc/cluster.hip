@@ -1,1 +1,559 @@
+// cluster.hip — per-region KDE cut-height selection + average-linkage clustering + coverage repair (gfx950).
+//
+// Replaces otter_hclust (reference: src/otterclust.cpp:118-320) with everything it calls:
+//   otter_find_clustering_dist (src/otterclust.cpp:20-116), KDE::f / KDE::maximas (src/ankde.cpp:8-62),
+//   hclust_fast(AVERAGE) = NN_chain_core (include/hclust-cpp/fastcluster_dm.hpp:563-766) +
+//   generate_R_dendrogram<false> (fastcluster_R_dm.hpp:68-115), cutree_cdist / cutree_k (fastcluster.cpp:33-105).
+//
+// One 256-thread workgroup per region.  FP64 throughout, compiled with -ffp-contract=off; every sum keeps
+// the reference's order (one thread per KDE grid point looping over the distances in index order;
+// normalisation and extremum scan sequential).  exp() is glibc's algorithm restated (table + degree-5
+// polynomial) in the variant — FMA or not — that the host libm uses, so densities are bit-identical to the
+// reference running on this host.  The integer-valued outputs (labels, ic, fc) are decided by
+// the same comparisons on the same bits.
 #include "otg_common.hpp"
+#include <cmath>
+
+#define OTG_EXP_TAB_QUAL __device__ __constant__ const
+#include "exp_table.inc"
+
+namespace {
+
+constexpr int NMAX = 256;      // max valid reads per region handled on chip (reference default max_cov = 200)
+constexpr int GMAX = 512;      // max KDE grid points
+constexpr int DLDS = 2016;     // dist working copy kept in LDS when n <= 64
+
+__device__ __constant__ double c_grid[GMAX];
+
+struct ClusterArgs {
+  int max_alleles;
+  int bandwidth_length, min_cov_fraction2_l;
+  double bandwidth_short, bandwidth_long, max_error, min_cov_fraction, min_cov_fraction2_f;
+  double inv_sqrt_2pi, inv_h_short, inv_h_long;
+  int n_grid, radius, exp_fma;
+  double dinterval;
+};
+
+__device__ __forceinline__ uint64_t d2u(double x) { return (uint64_t)__double_as_longlong(x); }
+__device__ __forceinline__ double u2d(uint64_t u) { return __longlong_as_double((long long)u); }
+
+// glibc 2.28+ exp(), N = 128 (sysdeps/ieee754/dbl-64/e_exp.c), restated.  FMA=true mirrors the x86-64
+// ifunc-selected FMA build (gcc contracts r, tmp and the final scale+scale*tmp; the subnormal path is not
+// contracted) — verified bit-for-bit against libm on 4e7 arguments on the build host.
+template <bool FMA>
+__device__ double otg_exp(double x)
+{
+  const double InvLn2N = 0x1.71547652b82fep0 * 128, NegLn2hiN = -0x1.62e42fefa0000p-8, NegLn2loN = -0x1.cf79abc9e3b3ap-47;
+  const double Shift = 0x1.8p52;
+  const double C2 = 0x1.ffffffffffdbdp-2, C3 = 0x1.555555555543cp-3, C4 = 0x1.55555cf172b91p-5, C5 = 0x1.1111167a4d017p-7;
+  uint32_t abstop = (uint32_t)(d2u(x) >> 52) & 0x7ff;
+  if (abstop - 0x3c9u >= 0x408u - 0x3c9u) {
+    if (abstop - 0x3c9u >= 0x80000000u) return 1.0 + x;
+    if (abstop >= 0x409u) {
+      if (d2u(x) == 0xfff0000000000000ull) return 0.0;
+      if (abstop >= 0x7ffu) return 1.0 + x;
+      return (d2u(x) >> 63) ? 0.0 : u2d(0x7ff0000000000000ull);
+    }
+    abstop = 0;
+  }
+  const double z = InvLn2N * x;
+  double kd = z + Shift;
+  const uint64_t ki = d2u(kd);
+  kd -= Shift;
+  double r;
+  if (FMA) r = fma(kd, NegLn2loN, fma(kd, NegLn2hiN, x));
+  else r = x + kd * NegLn2hiN + kd * NegLn2loN;
+  const uint64_t idx = 2 * (ki % 128), top = ki << 45;
+  const double tail = u2d(OTG_EXP_TAB[idx]);
+  uint64_t sbits = OTG_EXP_TAB[idx + 1] + top;
+  const double r2 = r * r;
+  double tmp;
+  if (FMA) tmp = fma(r2 * r2, fma(r, C5, C4), fma(r2, fma(r, C3, C2), tail + r));
+  else tmp = tail + r + r2 * (C2 + r * C3) + r2 * r2 * (C4 + r * C5);
+  if (abstop == 0) {
+    double scale, y;
+    if ((ki & 0x80000000ull) == 0) {
+      sbits -= 1009ull << 52; scale = u2d(sbits);
+      y = 0x1p1009 * (FMA ? fma(scale, tmp, scale) : scale + scale * tmp);
+      return y;
+    }
+    sbits += 1022ull << 52; scale = u2d(sbits);
+    const double st = scale * tmp;
+    y = scale + st;
+    if (y < 1.0) {
+      double hi, lo;
+      lo = scale - y + st; hi = 1.0 + y; lo = 1.0 - hi + y + lo;
+      y = (hi + lo) - 1.0;
+      if (y == 0.0) y = 0.0;
+    }
+    return 0x1p-1022 * y;
+  }
+  const double scale = u2d(sbits);
+  return FMA ? fma(scale, tmp, scale) : scale + scale * tmp;
+}
+
+__device__ __forceinline__ size_t didx(int N, int r, int c) { return (size_t)((((long long)(2 * N - 3 - r)) * r) >> 1) + c - 1; } // r < c
+__device__ __forceinline__ double dget(const double* D, int N, int i, int j) { return i < j ? D[didx(N, i, j)] : D[didx(N, j, i)]; }
+
+// ---- sequential pieces (run by thread 0) ---------------------------------------------------------------
+
+// libstdc++ std::sort on an int array with the reference's non-strict-weak comparator
+// (src/otterclust.cpp:61-66): introsort without the heapsort fallback (returns false if it would be needed).
+struct MaxCmp {
+  const int* mi; const double* mv;
+  __device__ bool operator()(int a, int b) const {
+    double diff = mv[a] - mv[b];
+    diff = diff > 0 ? diff : -diff;
+    if (diff <= 0.01) return mi[a] < mi[b];
+    return mv[a] > mv[b];
+  }
+};
+
+__device__ void ins_sort_guarded(int* f, int first, int last, const MaxCmp& cmp)
+{
+  for (int i = first + 1; i < last; ++i) {
+    if (cmp(f[i], f[first])) {
+      int val = f[i];
+      for (int q = i; q > first; --q) f[q] = f[q - 1];
+      f[first] = val;
+    } else {
+      int val = f[i], l = i, nx = i - 1;
+      while (cmp(val, f[nx])) { f[l] = f[nx]; l = nx; --nx; }
+      f[l] = val;
+    }
+  }
+}
+
+__device__ bool std_sort_emul(int* f, int n, const MaxCmp& cmp)
+{
+  if (n <= 1) return true;
+  if (n > 16) {
+    int lg = 31 - __clz(n);
+    int st_first[64], st_last[64], st_depth[64];
+    int sp = 0;
+    st_first[0] = 0; st_last[0] = n; st_depth[0] = 2 * lg; sp = 1;
+    while (sp > 0) {
+      --sp;
+      int first = st_first[sp], last = st_last[sp], depth = st_depth[sp];
+      while (last - first > 16) {
+        if (depth == 0) return false;
+        --depth;
+        int mid = first + (last - first) / 2;
+        int a = first + 1, b = mid, c = last - 1, res = first;
+        auto sw = [&](int x, int y) { int t = f[x]; f[x] = f[y]; f[y] = t; };
+        if (cmp(f[a], f[b])) { if (cmp(f[b], f[c])) sw(res, b); else if (cmp(f[a], f[c])) sw(res, c); else sw(res, a); }
+        else if (cmp(f[a], f[c])) sw(res, a);
+        else if (cmp(f[b], f[c])) sw(res, c);
+        else sw(res, b);
+        int lo = first + 1, hi = last;
+        for (;;) {
+          while (cmp(f[lo], f[first])) ++lo;
+          --hi;
+          while (cmp(f[first], f[hi])) --hi;
+          if (!(lo < hi)) break;
+          sw(lo, hi);
+          ++lo;
+        }
+        // recurse on [lo, last), iterate on [first, lo)
+        if (sp >= 63) return false;
+        st_first[sp] = lo; st_last[sp] = last; st_depth[sp] = depth; ++sp;
+        last = lo;
+      }
+    }
+    ins_sort_guarded(f, 0, 16, cmp);
+    for (int i = 16; i < n; ++i) {
+      int val = f[i], l = i, nx = i - 1;
+      while (cmp(val, f[nx])) { f[l] = f[nx]; l = nx; --nx; }
+      f[l] = val;
+    }
+    return true;
+  }
+  ins_sort_guarded(f, 0, n, cmp);
+  return true;
+}
+
+// The recursion order of libstdc++ is depth-first on the RIGHT part first ([cut,last) recursive call,
+// then the loop continues on [first,cut)); partitions are disjoint, so processing order does not change
+// the result.
+
+struct Lds {
+  double dens[GMAX];
+  double sums[GMAX];
+  double members[NMAX];
+  double zdist[NMAX];
+  double height[NMAX];
+  double dwork[DLDS];
+  int maxi[GMAX / 2 + 2], mini[GMAX / 2 + 2];
+  double maxv[GMAX / 2 + 2], minv[GMAX / 2 + 2];
+  int sorted[GMAX / 2 + 2];
+  int nn_chain[NMAX], succ[NMAX + 1], pred[NMAX + 1];
+  int z1[NMAX], z2[NMAX], zrank[NMAX];
+  int parent[2 * NMAX];
+  int merge[2 * NMAX];
+  int labels[NMAX], labels2[NMAX], last_merge[NMAX], zz[NMAX + 1];
+  int cnt[NMAX], maxsz[NMAX], req[NMAX], remap[NMAX];
+  double total;
+  int n_max, n_min, err;
+  int do_hclust;
+  double b0, b1, bc, dist_final, bandwidth;
+};
+
+__device__ void cutree_k_dev(int n, const int* merge, int nclust, int* labels, int* last_merge, int* z)
+{
+  if (nclust > n || nclust < 2) { for (int j = 0; j < n; j++) labels[j] = 0; return; }
+  for (int j = 0; j < n; ++j) last_merge[j] = 0;
+  for (int k = 1; k <= (n - nclust); k++) {
+    int m1 = merge[k - 1], m2 = merge[n - 1 + k - 1], j;
+    if (m1 < 0 && m2 < 0) { last_merge[-m1 - 1] = last_merge[-m2 - 1] = k; }
+    else if (m1 < 0 || m2 < 0) {
+      if (m1 < 0) { j = -m1; m1 = m2; } else j = -m2;
+      for (int l = 0; l < n; l++) if (last_merge[l] == m1) last_merge[l] = k;
+      last_merge[j - 1] = k;
+    } else {
+      for (int l = 0; l < n; l++) if (last_merge[l] == m1 || last_merge[l] == m2) last_merge[l] = k;
+    }
+  }
+  int label = 0;
+  for (int j = 0; j <= n; ++j) z[j] = -1;
+  for (int j = 0; j < n; j++) {
+    if (last_merge[j] == 0) labels[j] = label++;
+    else {
+      if (z[last_merge[j]] < 0) z[last_merge[j]] = label++;
+      labels[j] = z[last_merge[j]];
+    }
+  }
+}
+
+__device__ void nn_chain_average(int N, double* D, Lds& L)
+{
+#define D_(r_, c_) (D[didx(N, (r_), (c_))])
+  int start = 0;
+  for (int i = 0; i < N; ++i) { L.pred[i + 1] = i; L.succ[i] = i + 1; L.members[i] = 1.0; }
+  int tip = 0, idx1 = 0, idx2 = 0, i;
+  double mn = 0;
+  for (int j = 0; j < N - 1; ++j) {
+    if (tip <= 3) {
+      L.nn_chain[0] = idx1 = start;
+      tip = 1;
+      idx2 = L.succ[idx1];
+      mn = D_(idx1, idx2);
+      for (i = L.succ[idx2]; i < N; i = L.succ[i]) {
+        double d = D_(idx1, i);
+        if (d < mn) { mn = d; idx2 = i; }
+      }
+    } else {
+      tip -= 3;
+      idx1 = L.nn_chain[tip - 1];
+      idx2 = L.nn_chain[tip];
+      mn = idx1 < idx2 ? D_(idx1, idx2) : D_(idx2, idx1);
+    }
+    do {
+      L.nn_chain[tip] = idx2;
+      for (i = start; i < idx2; i = L.succ[i]) {
+        double d = D_(i, idx2);
+        if (d < mn) { mn = d; idx1 = i; }
+      }
+      for (i = L.succ[idx2]; i < N; i = L.succ[i]) {
+        double d = D_(idx2, i);
+        if (d < mn) { mn = d; idx1 = i; }
+      }
+      idx2 = idx1;
+      idx1 = L.nn_chain[tip++];
+    } while (idx2 != L.nn_chain[tip - 2]);
+    L.z1[j] = idx1; L.z2[j] = idx2; L.zdist[j] = mn;
+    if (idx1 > idx2) { int t = idx1; idx1 = idx2; idx2 = t; }
+    const double size1 = L.members[idx1], size2 = L.members[idx2];
+    L.members[idx2] += L.members[idx1];
+    // active_nodes.remove(idx1)
+    if (idx1 == start) start = L.succ[idx1];
+    else { L.succ[L.pred[idx1]] = L.succ[idx1]; L.pred[L.succ[idx1]] = L.pred[idx1]; }
+    L.succ[idx1] = 0;
+    const double s = size1 / (size1 + size2), t = size2 / (size1 + size2);
+    for (i = start; i < idx1; i = L.succ[i]) D_(i, idx2) = s * D_(i, idx1) + t * D_(i, idx2);
+    for (; i < idx2; i = L.succ[i]) D_(i, idx2) = s * D_(idx1, i) + t * D_(i, idx2);
+    for (i = L.succ[idx2]; i < N; i = L.succ[i]) D_(idx2, i) = s * D_(idx1, i) + t * D_(idx2, i);
+  }
+#undef D_
+}
+
+template <bool FMA>
+__global__ __launch_bounds__(256) void cluster_kernel(
+    ClusterArgs A, const double* __restrict__ dist, const uint64_t* __restrict__ dist_off,
+    const uint32_t* __restrict__ read_len, const uint64_t* __restrict__ len_off, const uint32_t* __restrict__ n_valid,
+    uint32_t n_regions, double* __restrict__ gwork,
+    int32_t* __restrict__ labels_out, int32_t* __restrict__ ic_out, int32_t* __restrict__ fc_out,
+    double* __restrict__ bounds_out, int32_t* __restrict__ err_out)
+{
+  __shared__ Lds L;
+  const int tid = threadIdx.x;
+  for (uint32_t r = blockIdx.x; r < n_regions; r += gridDim.x) {
+    const int n = (int)n_valid[r];
+    const double* dv = dist + dist_off[r];
+    const uint32_t* lens = read_len + len_off[r];
+    int32_t* lab = labels_out + len_off[r];
+    const size_t npairs = (size_t)n * (size_t)(n - 1) / 2;
+    __syncthreads();
+    if (tid == 0) {
+      L.err = 0; L.do_hclust = 0; L.b0 = L.b1 = L.bc = __longlong_as_double(0x7ff8000000000000ll);
+    }
+    __syncthreads();
+    // ---- trivial cases (src/otterclust.cpp:121-156)
+    if (n <= 2 || A.max_alleles == 1 || n > NMAX) {
+      if (tid == 0) {
+        int ic = 0, fc = 0;
+        if (n > NMAX) { L.err = 10; }
+        else if (n == 1) { lab[0] = 0; ic = fc = 1; }
+        else if (n == 2) {
+          lab[0] = 0; lab[1] = 0; ic = fc = 1;
+          if (A.max_alleles != 1 && !(dv[0] <= A.max_error)) { lab[1] = 1; ic = fc = 2; }
+        } else if (n > 2) { for (int i = 0; i < n; ++i) lab[i] = 0; ic = fc = 1; }
+        ic_out[r] = ic; fc_out[r] = fc;
+        if (bounds_out) { bounds_out[3 * r] = L.b0; bounds_out[3 * r + 1] = L.b1; bounds_out[3 * r + 2] = L.bc; }
+        if (err_out) err_out[r] = L.err;
+      }
+      continue;
+    }
+    // ---- bandwidth (:162-168)
+    if (tid == 0) {
+      double bw = A.bandwidth_short;
+      for (int i = 0; i < n; ++i) if ((int)lens[i] >= A.bandwidth_length) { bw = A.bandwidth_long; break; }
+      L.bandwidth = bw;
+    }
+    __syncthreads();
+    const double h = L.bandwidth;
+    const double inv_h = (h == A.bandwidth_long && h != A.bandwidth_short) ? A.inv_h_long : (h == A.bandwidth_short ? A.inv_h_short : 1 / h);
+    // ---- KDE::f on the grid (src/ankde.cpp:8-23; src/otterclust.cpp:26-28): one thread per grid point
+    for (int p = tid; p < A.n_grid; p += blockDim.x) {
+      const double x = c_grid[p];
+      double total = 0.0;
+      for (size_t q = 0; q < npairs; ++q) {
+        const double y = x - dv[q];
+        const double zq = y / h;
+        const double e = otg_exp<FMA>(-(zq * zq / 2));
+        const double kk = A.inv_sqrt_2pi * e;
+        total += inv_h * kk;
+      }
+      L.dens[p] = total / (double)npairs;
+    }
+    __syncthreads();
+    if (tid == 0) { double t = 0.0; for (int p = 0; p < A.n_grid; ++p) t += L.dens[p]; L.total = t; }   // :29-30
+    __syncthreads();
+    for (int p = tid; p < A.n_grid; p += blockDim.x) L.dens[p] = L.dens[p] / L.total;                     // :31-34
+    __syncthreads();
+    // ---- KDE::maximas (src/ankde.cpp:25-62): windowed sums in parallel, extremum scan sequential
+    for (int i = tid; i < A.n_grid; i += blockDim.x) {
+      double sum = 0.0;
+      sum += L.dens[i];
+      for (int j = 1; j < A.radius && (i - j) >= 0; ++j) sum += L.dens[i - j];
+      for (int j = 1; j < A.radius && (i + j) < A.n_grid; ++j) sum += L.dens[i + j];
+      L.sums[i] = sum;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      bool find_maxima = true;
+      double last_sum = 0.0;
+      int last_sum_i = 1, nmx = 0, nmn = 0;
+      for (int i = 1; i < A.n_grid - 1; ++i) {
+        const double sum = L.sums[i];
+        if (find_maxima) { if (sum < last_sum) { find_maxima = false; L.maxi[nmx] = last_sum_i; L.maxv[nmx] = last_sum; ++nmx; } }
+        else { if (sum > last_sum) { find_maxima = true; L.mini[nmn] = last_sum_i; L.minv[nmn] = last_sum; ++nmn; } }
+        last_sum = sum; last_sum_i = i;
+      }
+      if (find_maxima) { L.maxi[nmx] = last_sum_i; L.maxv[nmx] = last_sum; ++nmx; }
+      L.n_max = nmx; L.n_min = nmn;
+      // ---- decision bound (src/otterclust.cpp:39-115)
+      const double di = A.dinterval;
+      if (nmx == 0) L.err = 1;
+      else if (nmx == 1) { L.b0 = L.maxi[0] * di; L.b1 = L.maxi[0] * di; L.bc = -1.0; }
+      else if (nmn == 0) L.err = 2;
+      else if (nmx == 2) { L.b0 = L.maxi[0] * di; L.b1 = L.maxi[1] * di; L.bc = L.mini[0] * di; }
+      else {
+        int ns = nmx;
+        for (int i = 0; i < ns; ++i) L.sorted[i] = i;
+        MaxCmp cmp{L.maxi, L.maxv};
+        if (!std_sort_emul(L.sorted, ns, cmp)) L.err = 5;
+        int last_i = 0, acc_i = 1;
+        while (acc_i < ns) {
+          int index_diff = acc_i > last_i ? acc_i - last_i : last_i - acc_i;
+          double f_diff = L.maxv[L.sorted[acc_i]] - L.maxv[L.sorted[last_i]];
+          f_diff = f_diff < 0 ? -f_diff : f_diff;
+          if (index_diff == 1 && f_diff <= 0.01) {
+            for (int q = acc_i; q + 1 < ns; ++q) L.sorted[q] = L.sorted[q + 1];
+            --ns;
+            last_i = acc_i;
+          }
+          ++acc_i;
+        }
+        if (ns < 2) { L.b0 = L.maxi[0] * di; L.b1 = L.maxi[1] * di; L.bc = L.mini[0] * di; }
+        else {
+          int m1 = L.sorted[0], m2 = L.sorted[1];
+          if (m1 > m2) { int t = m1; m1 = m2; m2 = t; }
+          int boundary_i = m2 - 1;
+          if (boundary_i < 0 || boundary_i >= nmn) L.err = 3;
+          else {
+            if (m2 - m1 > 1 && m2 - 2 >= 0 && (L.maxi[m2] * di - L.mini[boundary_i] * di <= 0.01)) {
+              boundary_i = m2 - 2;
+              if (boundary_i < 0 || boundary_i >= nmn) L.err = 4;
+            }
+            if (!L.err) { L.b0 = L.maxi[m1] * di; L.b1 = L.maxi[m2] * di; L.bc = L.mini[m1 + (m2 - m1) / 2] * di; }
+          }
+        }
+      }
+      if (!L.err) {
+        if (L.b1 - L.b0 <= A.max_error) L.do_hclust = 0;   // :172-176
+        else { L.do_hclust = 1; L.dist_final = (L.b1 == L.bandwidth) ? L.b1 : L.bc + 0.0025; }   // :184
+      }
+    }
+    __syncthreads();
+    if (L.err || !L.do_hclust) {
+      for (int i = tid; i < n; i += blockDim.x) lab[i] = L.err ? -1 : 0;
+      if (tid == 0) {
+        ic_out[r] = L.err ? 0 : 1; fc_out[r] = L.err ? 0 : 1;
+        if (bounds_out) { bounds_out[3 * r] = L.b0; bounds_out[3 * r + 1] = L.b1; bounds_out[3 * r + 2] = L.bc; }
+        if (err_out) err_out[r] = L.err;
+      }
+      continue;
+    }
+    // ---- hclust_fast(AVERAGE) on a working copy (:181-182)
+    double* D = (npairs <= (size_t)DLDS) ? L.dwork : gwork + dist_off[r];
+    for (size_t q = tid; q < npairs; q += blockDim.x) D[q] = dv[q];
+    __syncthreads();
+    if (tid == 0) nn_chain_average(n, D, L);
+    __syncthreads();
+    // generate_R_dendrogram<false>: std::stable_sort by dist == rank by (dist, original position)
+    for (int i = tid; i < n - 1; i += blockDim.x) {
+      int rank = 0;
+      const double di = L.zdist[i];
+      for (int j = 0; j < n - 1; ++j) { const double dj = L.zdist[j]; if (dj < di || (dj == di && j < i)) ++rank; }
+      L.zrank[rank] = i;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      for (int i = 0; i < 2 * n - 1; ++i) L.parent[i] = 0;
+      int nextparent = n;
+      for (int k = 0; k < n - 1; ++k) {
+        const int src = L.zrank[k];
+        int a = L.z1[src], b = L.z2[src];
+        // union_find::Find with path compression (fastcluster_dm.hpp:366-383)
+        for (int w = 0; w < 2; ++w) {
+          int idx = w ? b : a;
+          if (L.parent[idx] != 0) {
+            int p = idx;
+            idx = L.parent[idx];
+            if (L.parent[idx] != 0) {
+              do { idx = L.parent[idx]; } while (L.parent[idx] != 0);
+              do { int tmp = L.parent[p]; L.parent[p] = idx; p = tmp; } while (L.parent[p] != idx);
+            }
+          }
+          if (w) b = idx; else a = idx;
+        }
+        L.parent[a] = L.parent[b] = nextparent++;
+        if (a > b) { int t = a; a = b; b = t; }
+        L.merge[k] = (a < n) ? -a - 1 : a - n + 1;
+        L.merge[k + n - 1] = (b < n) ? -b - 1 : b - n + 1;
+        L.height[k] = L.zdist[src];
+      }
+      // cutree_cdist (:185; fastcluster.cpp:95-105)
+      int kc;
+      for (kc = 0; kc < (n - 1); kc++) if (L.height[kc] >= L.dist_final) break;
+      cutree_k_dev(n, L.merge, n - kc, L.labels, L.last_merge, L.zz);
+      int total_alleles = 0;
+      for (int i = 0; i < n; ++i) if (L.labels[i] > total_alleles) total_alleles = L.labels[i];
+      ++total_alleles;
+      int ic = total_alleles, fc = 0;
+      const int min_cov1 = (int)(n * A.min_cov_fraction + 0.5);
+      const int min_cov2 = (int)(n * A.min_cov_fraction2_f + 0.5);
+      if (A.max_alleles != 0) {
+        for (int l = 0; l < total_alleles; ++l) { L.cnt[l] = 0; L.maxsz[l] = 0; }
+        for (int i = 0; i < n; ++i) { ++L.cnt[L.labels[i]]; if ((int)lens[i] > L.maxsz[L.labels[i]]) L.maxsz[L.labels[i]] = (int)lens[i]; }
+        for (int l = 0; l < total_alleles; ++l) L.req[l] = (L.maxsz[l] < A.min_cov_fraction2_l) ? min_cov1 : min_cov2;
+        bool only_single = true;
+        for (int l = 0; l < total_alleles; ++l) if (L.cnt[l] >= L.req[l]) { only_single = false; break; }
+        if (only_single) {
+          cutree_k_dev(n, L.merge, A.max_alleles, L.labels2, L.last_merge, L.zz);
+          fc = A.max_alleles;
+          for (int i = 0; i < n; ++i) L.labels[i] = L.labels2[i];
+        } else {
+          int seeds = 0;
+          for (int l = 0; l < total_alleles; ++l) if (!(L.cnt[l] < L.req[l])) ++seeds;
+          if (seeds == 0 || seeds > A.max_alleles) {
+            cutree_k_dev(n, L.merge, A.max_alleles, L.labels, L.last_merge, L.zz);
+            fc = A.max_alleles;
+          } else {
+            int sj = 0;
+            for (int l = 0; l < total_alleles; ++l) L.remap[l] = (L.cnt[l] < L.req[l]) ? -1 : sj++;
+            for (int i = 0; i < n; ++i) L.labels[i] = L.remap[L.labels[i]];
+            for (int i = 0; i < n; ++i) {
+              if (L.labels[i] == -1) {
+                int closest_j = 0;
+                double min_dist = 100000.0;
+                for (int j = 0; j < n; ++j) {
+                  if (i != j && L.labels[j] != -1) {
+                    const double jd = dget(dv, n, i, j);
+                    if (jd < min_dist) { closest_j = j; min_dist = jd; }
+                  }
+                }
+                L.labels[i] = L.labels[closest_j];
+              }
+            }
+            fc = seeds;
+          }
+        }
+      }
+      for (int i = 0; i < n; ++i) lab[i] = L.labels[i];
+      ic_out[r] = ic; fc_out[r] = fc;
+      if (bounds_out) { bounds_out[3 * r] = L.b0; bounds_out[3 * r + 1] = L.b1; bounds_out[3 * r + 2] = L.bc; }
+      if (err_out) err_out[r] = 0;
+    }
+  }
+}
+
+} // namespace
+
+int otg_launch_cluster(otg_ctx* ctx, const otg_params* P, const double* d_dist, const uint64_t* d_dist_off,
+                       const uint32_t* d_read_len, const uint64_t* d_len_off, const uint32_t* d_n_valid,
+                       uint32_t n_regions, int32_t* d_labels, int32_t* d_ic, int32_t* d_fc, double* d_bounds,
+                       int32_t* d_err)
+{
+  if (n_regions == 0) return OTG_OK;
+  ClusterArgs A;
+  A.max_alleles = P->max_alleles;
+  A.bandwidth_length = P->bandwidth_length;
+  A.min_cov_fraction2_l = P->min_cov_fraction2_l;
+  A.bandwidth_short = P->bandwidth_short; A.bandwidth_long = P->bandwidth_long;
+  A.max_error = P->max_error; A.min_cov_fraction = P->min_cov_fraction; A.min_cov_fraction2_f = P->min_cov_fraction2_f;
+  {
+    // constants the reference evaluates at run time (src/ankde.cpp:10,15), in the same operation order
+    volatile double pi = 3.14159265358979323846;
+    volatile double two_pi = 2 * pi;
+    A.inv_sqrt_2pi = 1 / std::sqrt(two_pi);
+    volatile double hs = P->bandwidth_short, hl = P->bandwidth_long;
+    A.inv_h_short = 1 / hs; A.inv_h_long = 1 / hl;
+  }
+  const double error_intervals = 0.0025;
+  int radius = int(P->max_error / error_intervals);     // src/otterclust.cpp:160-161
+  A.radius = radius < 1 ? 1 : radius;
+  A.dinterval = error_intervals;
+  A.exp_fma = ctx->exp_variant;
+  static double grid[GMAX];
+  int ng = 0;
+  for (volatile double x = 0.0; x <= 1.0; x += error_intervals) {     // src/otterclust.cpp:26
+    if (ng >= GMAX) return otg_fail(ctx, OTG_ERR_ARG, "KDE grid too large");
+    grid[ng++] = x;
+  }
+  A.n_grid = ng;
+  HIP_TRY(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(c_grid), grid, sizeof(double) * ng, 0, hipMemcpyHostToDevice, ctx->stream));
+  // working copy for regions whose matrix does not fit LDS: same layout as d_dist
+  // (size unknown here -> callers guarantee SLOT_AUX9 holds at least as many doubles as d_dist)
+  double* gwork = (double*)ctx->pool[SLOT_AUX9].p;
+  if (!gwork) return otg_fail(ctx, OTG_ERR_ARG, "cluster workspace (SLOT_AUX9) not allocated");
+  uint32_t grid_dim = n_regions < (uint32_t)ctx->n_cu * 8 ? n_regions : (uint32_t)ctx->n_cu * 8;
+  if (A.exp_fma)
+    hipLaunchKernelGGL((cluster_kernel<true>), dim3(grid_dim), dim3(256), 0, ctx->stream, A, d_dist, d_dist_off, d_read_len, d_len_off,
+                       d_n_valid, n_regions, gwork, d_labels, d_ic, d_fc, d_bounds, d_err);
+  else
+    hipLaunchKernelGGL((cluster_kernel<false>), dim3(grid_dim), dim3(256), 0, ctx->stream, A, d_dist, d_dist_off, d_read_len, d_len_off,
+                       d_n_valid, n_regions, gwork, d_labels, d_ic, d_fc, d_bounds, d_err);
+  HIP_TRY(ctx, hipGetLastError());
+  return OTG_OK;
+}

@@ -2,6 +2,7 @@
 #include "otg_common.hpp"
 #include <cmath>
 #include <cstdarg>
+#include <algorithm>
 
 thread_local std::string g_otg_err;
 
@@ -218,6 +219,114 @@ int otg_affine_align_batch(otg_ctx* ctx, const uint8_t* seq_arena, uint64_t aren
   }
   if (cigar_bytes_used) *cigar_bytes_used = pos;
   if (rc) return otg_fail(ctx, rc, "cigar_capacity %llu too small, %llu needed", (unsigned long long)cigar_capacity, (unsigned long long)pos);
+  return OTG_OK;
+}
+
+int otg_cluster_batch(otg_ctx* ctx, const otg_params* params,
+                      const double* dist, const uint64_t* dist_off,
+                      const uint32_t* read_len, const uint64_t* len_off,
+                      const uint32_t* n_valid, uint32_t n_regions,
+                      int32_t* labels_out, int32_t* ic_out, int32_t* fc_out, double* bounds_out)
+{
+  if (!ctx) return otg_fail(nullptr, OTG_ERR_NO_DEVICE, "otg_cluster_batch: no context (no HIP device?)");
+  if (n_regions == 0) return OTG_OK;
+  if (!params || !dist_off || !read_len || !len_off || !n_valid || !labels_out || !ic_out || !fc_out)
+    return otg_fail(ctx, OTG_ERR_ARG, "otg_cluster_batch: NULL argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  uint64_t n_dist = 0, n_len = 0;
+  for (uint32_t r = 0; r < n_regions; ++r) {
+    uint64_t n = n_valid[r];
+    n_dist = std::max<uint64_t>(n_dist, dist_off[r] + n * (n ? n - 1 : 0) / 2);
+    n_len = std::max<uint64_t>(n_len, len_off[r] + n);
+  }
+  if (n_dist && !dist) return otg_fail(ctx, OTG_ERR_ARG, "otg_cluster_batch: dist is NULL");
+  double* d_dist = (double*)otg_slot(ctx, SLOT_AUX0, (n_dist + 1) * sizeof(double));
+  uint64_t* d_doff = (uint64_t*)otg_slot(ctx, SLOT_AUX1, (size_t)n_regions * sizeof(uint64_t));
+  uint32_t* d_len = (uint32_t*)otg_slot(ctx, SLOT_AUX2, (n_len + 1) * sizeof(uint32_t));
+  uint64_t* d_loff = (uint64_t*)otg_slot(ctx, SLOT_AUX3, (size_t)n_regions * sizeof(uint64_t));
+  uint32_t* d_nv = (uint32_t*)otg_slot(ctx, SLOT_AUX4, (size_t)n_regions * sizeof(uint32_t));
+  int32_t* d_lab = (int32_t*)otg_slot(ctx, SLOT_AUX5, (n_len + 1) * sizeof(int32_t));
+  int32_t* d_ic = (int32_t*)otg_slot(ctx, SLOT_AUX6, (size_t)n_regions * 3 * sizeof(int32_t));
+  double* d_bounds = (double*)otg_slot(ctx, SLOT_AUX7, (size_t)n_regions * 3 * sizeof(double));
+  double* d_work = (double*)otg_slot(ctx, SLOT_AUX9, (n_dist + 1) * sizeof(double));
+  if (!d_dist || !d_doff || !d_len || !d_loff || !d_nv || !d_lab || !d_ic || !d_bounds || !d_work) return OTG_ERR_HIP;
+  int32_t* d_fc = d_ic + n_regions;
+  int32_t* d_err = d_fc + n_regions;
+  if (n_dist) HIP_TRY(ctx, hipMemcpyAsync(d_dist, dist, n_dist * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_doff, dist_off, (size_t)n_regions * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_len, read_len, n_len * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_loff, len_off, (size_t)n_regions * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_nv, n_valid, (size_t)n_regions * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(d_lab, 0xff, (n_len + 1) * sizeof(int32_t), ctx->stream));
+  int rc = otg_launch_cluster(ctx, params, d_dist, d_doff, d_len, d_loff, d_nv, n_regions, d_lab, d_ic, d_fc, d_bounds, d_err);
+  if (rc) return rc;
+  std::vector<int32_t> h_err(n_regions);
+  HIP_TRY(ctx, hipMemcpyAsync(labels_out, d_lab, n_len * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ic_out, d_ic, (size_t)n_regions * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(fc_out, d_fc, (size_t)n_regions * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(h_err.data(), d_err, (size_t)n_regions * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  if (bounds_out) HIP_TRY(ctx, hipMemcpyAsync(bounds_out, d_bounds, (size_t)n_regions * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (uint32_t r = 0; r < n_regions; ++r)
+    if (h_err[r])
+      return otg_fail(ctx, h_err[r] == 10 ? OTG_ERR_CAPACITY : OTG_ERR_FATAL,
+                      "region %u: clustering failed with code %d (1-4: the reference exit(1)s here, src/otterclust.cpp:39-109; "
+                      "5: std::sort emulation depth; 10: more than 256 valid reads)", r, h_err[r]);
+  return OTG_OK;
+}
+
+int otg_poa_consensus_batch(otg_ctx* ctx, const uint8_t* seq_arena, uint64_t arena_bytes,
+                            const uint8_t* cigar_arena, uint64_t cigar_bytes,
+                            const otg_poa_member* members, uint32_t n_members,
+                            const otg_poa_graph* graphs, uint32_t n_graphs,
+                            uint64_t* out_off, uint32_t* out_len,
+                            uint8_t* out_arena, uint64_t out_capacity, uint64_t* out_bytes_used)
+{
+  if (!ctx) return otg_fail(nullptr, OTG_ERR_NO_DEVICE, "otg_poa_consensus_batch: no context (no HIP device?)");
+  if (out_bytes_used) *out_bytes_used = 0;
+  if (n_graphs == 0) return OTG_OK;
+  if (!seq_arena || !graphs || !out_off || !out_len || !out_arena || (n_members && (!members || !cigar_arena)))
+    return otg_fail(ctx, OTG_ERR_ARG, "otg_poa_consensus_batch: NULL argument");
+  for (uint32_t g = 0; g < n_graphs; ++g) {
+    if (graphs[g].backbone_off + graphs[g].backbone_len > arena_bytes || (uint64_t)graphs[g].first_member + graphs[g].n_members > n_members)
+      return otg_fail(ctx, OTG_ERR_ARG, "graph %u: backbone or member range out of bounds", g);
+  }
+  for (uint32_t m = 0; m < n_members; ++m)
+    if (members[m].seq_off + members[m].seq_len > arena_bytes || members[m].cigar_off + members[m].cigar_len > cigar_bytes)
+      return otg_fail(ctx, OTG_ERR_ARG, "member %u: sequence or op string out of bounds", m);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  uint8_t* d_arena = (uint8_t*)otg_slot(ctx, SLOT_ARENA, arena_bytes + 64);
+  uint8_t* d_cig = (uint8_t*)otg_slot(ctx, SLOT_CIG_ARENA, cigar_bytes + 64);
+  otg_poa_member* d_mem = (otg_poa_member*)otg_slot(ctx, SLOT_AUX0, (size_t)(n_members + 1) * sizeof(otg_poa_member));
+  otg_poa_graph* d_gr = (otg_poa_graph*)otg_slot(ctx, SLOT_AUX1, (size_t)n_graphs * sizeof(otg_poa_graph));
+  uint32_t* d_len = (uint32_t*)otg_slot(ctx, SLOT_AUX2, (size_t)n_graphs * sizeof(uint32_t));
+  if (!d_arena || !d_cig || !d_mem || !d_gr || !d_len) return OTG_ERR_HIP;
+  HIP_TRY(ctx, hipMemcpyAsync(d_arena, seq_arena, arena_bytes, hipMemcpyHostToDevice, ctx->stream));
+  if (cigar_bytes) HIP_TRY(ctx, hipMemcpyAsync(d_cig, cigar_arena, cigar_bytes, hipMemcpyHostToDevice, ctx->stream));
+  if (n_members) HIP_TRY(ctx, hipMemcpyAsync(d_mem, members, (size_t)n_members * sizeof(otg_poa_member), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_gr, graphs, (size_t)n_graphs * sizeof(otg_poa_graph), hipMemcpyHostToDevice, ctx->stream));
+  std::vector<uint64_t> node_off;
+  int rc = otg_launch_poa(ctx, d_arena, d_cig, d_mem, n_members, d_gr, graphs, n_graphs, d_len, node_off);
+  if (rc) return rc;
+  std::vector<uint32_t> h_start(n_graphs);
+  std::vector<int32_t> h_status(n_graphs);
+  std::vector<uint8_t> h_out(node_off[n_graphs] + 1);
+  HIP_TRY(ctx, hipMemcpyAsync(out_len, d_len, (size_t)n_graphs * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(h_start.data(), ctx->pool[SLOT_P29].p, (size_t)n_graphs * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(h_status.data(), ctx->pool[SLOT_P28].p, (size_t)n_graphs * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(h_out.data(), ctx->pool[SLOT_P17].p, node_off[n_graphs], hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  uint64_t pos = 0;
+  rc = OTG_OK;
+  for (uint32_t g = 0; g < n_graphs; ++g) {
+    if (h_status[g]) return otg_fail(ctx, OTG_ERR_FATAL, "POA graph %u failed on the device (status %d)", g, h_status[g]);
+    out_off[g] = pos;
+    if (pos + out_len[g] <= out_capacity) memcpy(out_arena + pos, h_out.data() + node_off[g] + h_start[g], out_len[g]);
+    else rc = OTG_ERR_CAPACITY;
+    pos += out_len[g];
+  }
+  if (out_bytes_used) *out_bytes_used = pos;
+  if (rc) return otg_fail(ctx, rc, "out_capacity %llu too small, %llu needed", (unsigned long long)out_capacity, (unsigned long long)pos);
   return OTG_OK;
 }
 

@@ -102,8 +102,8 @@ int otg_launch_cluster(otg_ctx* ctx, const otg_params* P, const double* d_dist, 
 // poa.hip
 int otg_launch_poa(otg_ctx* ctx, const uint8_t* d_seq_arena, const uint8_t* d_cig_arena,
                    const otg_poa_member* d_members, uint32_t n_members, const otg_poa_graph* d_graphs,
-                   const otg_poa_graph* h_graphs, const otg_poa_member* h_members, uint32_t n_graphs,
-                   const uint64_t* d_out_off, uint32_t* d_out_len, uint8_t* d_out_arena);
+                   const otg_poa_graph* h_graphs, uint32_t n_graphs, uint32_t* d_out_len,
+                   std::vector<uint64_t>& node_off);
 
 // genotype.hip
 int otg_launch_genotype(otg_ctx* ctx, const otg_params* P, const uint8_t* d_arena, const uint64_t* d_seq_off,

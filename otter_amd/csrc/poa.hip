@@ -1,1 +1,301 @@
+// poa.hip — batched "pseudo-POA" consensus (gfx950).
+//
+// Replaces PPOA (reference: src/anppoa.hpp:64-380) as driven by rapid_consensus
+// (src/analignments.cpp:261-292): backbone graph, per-read op-string threading with alt-node reuse,
+// weight damping (adjust_weights :243-252) and heaviest path ending in an ending node (:254-380).
+//
+// Graph image in HBM (per graph, sizes from a counting pre-pass over the op strings):
+//   nodes: base byte, is_end flag, in-degree, extra-edge list head/tail, heaviest weight, predecessor;
+//   backbone edge i -> i+1 is implicit: weight 1 + bb_cnt[i] (integer count, exact in FP32);
+//   extra edges (everything else) in creation order with a per-source singly linked list, which is the
+//   reference's per-node insertion order.
+// The reference finds the heaviest path by scanning, for every node, all edges of the graph (O(N*E)) and
+// copying path vectors; here it is one Kahn sweep that PUSHES along out-edges and keeps, per node, the best
+// (weight, source) with the reference's tie-breaks restated: candidates are compared with strict '>' in
+// incoming-scan order = ascending source id (one edge per (source,sink) pair, so the source id alone orders
+// ties), first candidate always accepted; the end node is the lowest id among the heaviest ending nodes.
+// Damping is applied on the fly with the reference's FP32 operations (-ffp-contract=off).
+// v1 mapping: one thread per graph (graphs are independent and the threading is inherently sequential);
+// node initialisation is a separate fully parallel kernel.
 #include "otg_common.hpp"
+#include <vector>
+#include <algorithm>
+
+namespace {
+
+struct PoaDev {
+  const uint8_t* seq_arena;
+  const uint8_t* cig_arena;
+  const otg_poa_member* members;
+  const otg_poa_graph* graphs;
+  uint32_t n_graphs;
+  // per-graph layout
+  const uint64_t* node_off;   // [n_graphs+1]
+  const uint64_t* edge_off;   // [n_graphs+1]
+  const uint64_t* start_off;  // [n_graphs+1]
+  // node arrays
+  uint8_t* node_base; uint8_t* is_end; uint8_t* hdef;
+  int32_t* head; int32_t* tail; uint32_t* indeg; uint32_t* bb_cnt; float* hw; int32_t* pred; uint32_t* queue;
+  // edge arrays
+  uint32_t* e_sink; float* e_w; int32_t* e_next;
+  uint32_t* start_list;
+  // outputs
+  const uint64_t* out_off; uint32_t* out_len; uint8_t* out_arena; uint32_t* out_start; int32_t* status;
+};
+
+__global__ void poa_count_kernel(const uint8_t* __restrict__ cig_arena, const otg_poa_member* __restrict__ members,
+                                 uint32_t n_members, uint32_t* __restrict__ n_alt, uint32_t* __restrict__ n_nonm)
+{
+  const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= n_members) return;
+  const uint8_t* c = cig_arena + members[m].cigar_off;
+  const uint32_t n = members[m].cigar_len;
+  uint32_t alt = 0, nonm = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint8_t op = c[i];
+    alt += (op == 'X' || op == 'I');
+    nonm += (op != 'M');
+  }
+  n_alt[m] = alt; n_nonm[m] = nonm;
+}
+
+// PPOA::init (src/anppoa.hpp:64-84), one block per graph
+__global__ void poa_init_kernel(PoaDev P)
+{
+  for (uint32_t g = blockIdx.x; g < P.n_graphs; g += gridDim.x) {
+    const otg_poa_graph G = P.graphs[g];
+    const uint64_t no = P.node_off[g];
+    const uint32_t B = G.backbone_len;
+    const uint8_t* bb = P.seq_arena + G.backbone_off;
+    const uint64_t cap = P.node_off[g + 1] - no;
+    for (uint64_t i = threadIdx.x; i < cap; i += blockDim.x) {
+      const bool isb = i < B && B >= 2;
+      P.node_base[no + i] = isb ? bb[i] : 0;
+      P.is_end[no + i] = (isb && i >= 1 && B - i <= 10) ? 1 : 0;
+      P.indeg[no + i] = (isb && i >= 1) ? 1u : 0u;
+      P.head[no + i] = -1; P.tail[no + i] = -1;
+      P.bb_cnt[no + i] = 0; P.hdef[no + i] = 0; P.hw[no + i] = 0.0f; P.pred[no + i] = -1;
+    }
+    if (threadIdx.x == 0 && B >= 2) P.start_list[P.start_off[g]] = 0;
+  }
+}
+
+__global__ __launch_bounds__(64) void poa_graph_kernel(PoaDev P)
+{
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= P.n_graphs) return;
+  const otg_poa_graph G = P.graphs[g];
+  const uint64_t no = P.node_off[g], eo = P.edge_off[g], so = P.start_off[g];
+  const uint32_t node_cap = (uint32_t)(P.node_off[g + 1] - no), edge_cap = (uint32_t)(P.edge_off[g + 1] - eo);
+  uint8_t* nbase = P.node_base + no; uint8_t* isend = P.is_end + no; uint8_t* hdef = P.hdef + no;
+  int32_t* head = P.head + no; int32_t* tail = P.tail + no; uint32_t* indeg = P.indeg + no; uint32_t* bbc = P.bb_cnt + no;
+  float* hw = P.hw + no; int32_t* pred = P.pred + no; uint32_t* queue = P.queue + no;
+  uint32_t* esink = P.e_sink + eo; float* ew = P.e_w + eo; int32_t* enext = P.e_next + eo;
+  uint32_t* starts = P.start_list + so;
+  const int B = (int)G.backbone_len;
+  uint32_t n_nodes = (uint32_t)B, n_edges = 0, n_start = B >= 2 ? 1u : 0u;
+  int status = 0;
+
+  auto new_node = [&](uint8_t base) -> uint32_t {
+    if (n_nodes >= node_cap) { status = 1; return n_nodes - 1; }
+    nbase[n_nodes] = base;
+    return n_nodes++;
+  };
+  auto insert_edge = [&](uint32_t src, uint32_t sink) {     // src/anppoa.hpp:96-110
+    if ((int)src < B - 1 && sink == src + 1) { atomicAdd(&bbc[src], 1u); return; }
+    for (int e = head[src]; e >= 0; e = enext[e]) if (esink[e] == sink) { ew[e] += 1.0f; return; }
+    if (n_edges >= edge_cap) { status = 2; return; }
+    const int e = (int)n_edges++;
+    esink[e] = sink; ew[e] = 1.0f; enext[e] = -1;
+    if (tail[src] >= 0) enext[tail[src]] = e; else head[src] = e;
+    tail[src] = e;
+    atomicAdd(&indeg[sink], 1u);
+  };
+  auto alt_step = [&](uint32_t prev, uint8_t tc) -> uint32_t {   // :162-186 / :206-233
+    for (int e = head[prev]; e >= 0; e = enext[e]) {
+      const uint32_t sk = esink[e];
+      if ((int)sk >= B && nbase[sk] == tc) { ew[e] += 1.0f; return sk; }
+    }
+    const uint32_t nn = new_node(tc);
+    if (!status) insert_edge(prev, nn);
+    return nn;
+  };
+
+  // ---- insert_alignment for every member, in order (src/anppoa.hpp:112-241)
+  for (uint32_t mi = 0; mi < G.n_members && !status; ++mi) {
+    const otg_poa_member M = P.members[G.first_member + mi];
+    const uint8_t* seq = P.seq_arena + M.seq_off;
+    const uint8_t* cig = P.cig_arena + M.cigar_off;
+    const int clen = (int)M.cigar_len, slen = (int)M.seq_len;
+    const bool spl = M.spanning_l != 0, spr = M.spanning_r != 0;
+    int prev = 0, ref_i = 0, tgt = 0, ci = 0;
+    bool first = true;
+    if (!spl) {
+      first = false;
+      while (ci < clen) {
+        const uint8_t c = cig[ci];
+        if (c != 'D' && c != 'I') break;
+        if (c == 'D') { ++ref_i; prev = ref_i; } else ++tgt;
+        ++ci;
+      }
+    }
+    while (ci < clen && !status) {
+      const uint8_t c = cig[ci];
+      if (c == 'M') {
+        if (first || prev == ref_i) first = false;
+        else if ((uint32_t)prev >= n_nodes) { status = 3; break; }    // the reference indexes edges[] out of range here
+        else insert_edge((uint32_t)prev, (uint32_t)ref_i);
+        prev = ref_i; ++ref_i; ++tgt;
+      } else if (c == 'X') {
+        const uint8_t tc = tgt < slen ? seq[tgt] : 0;
+        if (first) {
+          bool need_new = true;
+          for (uint32_t q = 0; q < n_start; ++q) if (nbase[starts[q]] == tc) { need_new = false; break; }
+          if (need_new) { prev = (int)new_node(tc); starts[n_start++] = (uint32_t)prev; }
+          first = false;
+        } else if ((uint32_t)prev >= n_nodes) { status = 3; break; }
+        else prev = (int)alt_step((uint32_t)prev, tc);
+        ++ref_i; ++tgt;
+      } else if (c == 'D') {
+        if (!first) ++ref_i; else { ++ref_i; prev = ref_i; }
+      } else if (c == 'I') {
+        const uint8_t tc = tgt < slen ? seq[tgt] : 0;
+        if (first) { prev = (int)new_node(tc); starts[n_start++] = (uint32_t)prev; first = false; }
+        else if ((uint32_t)prev >= n_nodes) { status = 3; break; }
+        else prev = (int)alt_step((uint32_t)prev, tc);
+        ++tgt;
+      }
+      if (B - ref_i <= 10 && spr && (uint32_t)prev < node_cap) isend[prev] = 1;   // ids not yet created are remembered too (std::set of ids)
+      ++ci;
+    }
+  }
+  __threadfence();   // bb_cnt / indeg atomics of this thread are visible to its own loads below
+
+  // ---- heaviest path: Kahn sweep pushing (weight, source) along out-edges
+  const float c_ = G.c, t_ = G.t;
+  auto damp = [&](float w) -> float {                      // adjust_weights :243-252
+    const float t_applied = t_ * w;
+    const float final_weight = c_ > t_applied ? c_ : t_applied;
+    return w - final_weight;
+  };
+  auto relax = [&](uint32_t u, uint32_t v, float w) {
+    const float cand = hw[u] + w;
+    if (!hdef[v]) { hdef[v] = 1; hw[v] = cand; pred[v] = (int32_t)u; }
+    else if (cand > hw[v] || (cand == hw[v] && (int32_t)u < pred[v])) { hw[v] = cand; pred[v] = (int32_t)u; }
+  };
+  uint32_t qh = 0, qt = 0;
+  if (!status) {
+    for (uint32_t i = 0; i < n_nodes; ++i) if (__hip_atomic_load(&indeg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) queue[qt++] = i;
+    while (qh < qt) {
+      const uint32_t u = queue[qh++];
+      if ((int)u < B - 1) {
+        const uint32_t v = u + 1;
+        const float w = damp(1.0f + (float)__hip_atomic_load(&bbc[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        relax(u, v, w);
+        const uint32_t left = __hip_atomic_load(&indeg[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1;
+        __hip_atomic_store(&indeg[v], left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (left == 0) queue[qt++] = v;
+      }
+      for (int e = head[u]; e >= 0; e = enext[e]) {
+        const uint32_t v = esink[e];
+        relax(u, v, damp(ew[e]));
+        const uint32_t left = __hip_atomic_load(&indeg[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1;
+        __hip_atomic_store(&indeg[v], left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (left == 0) queue[qt++] = v;
+      }
+    }
+    if (qt != n_nodes) status = 4;    // cycle: the reference would never return
+  }
+  // ---- pick the end node (:346-367) and emit the path (:373-378)
+  uint32_t len = 0, startpos = 0;
+  if (!status && n_nodes > 0) {
+    uint32_t h_node = 0; bool not_init = true; float best = 0.0f;
+    for (uint32_t i = 0; i < n_nodes; ++i) {
+      if (isend[i]) { const float w = hw[i]; if (not_init || w > best) { not_init = false; h_node = i; best = w; } }
+    }
+    uint8_t* out = P.out_arena + P.out_off[g];
+    const uint32_t cap = node_cap;
+    uint32_t pos = cap;
+    int32_t cur = (int32_t)h_node;
+    while (cur >= 0 && pos > 0) {
+      const uint8_t b = nbase[cur];
+      if (b) out[--pos] = b;
+      cur = pred[cur];
+    }
+    startpos = pos; len = cap - pos;
+  }
+  P.out_len[g] = len; P.out_start[g] = startpos; P.status[g] = status;
+}
+
+} // namespace
+
+// h_graphs: host copy (layout sizes); d_* device copies.  Outputs (device): consensus g starts at
+// SLOT_P17 + node_off[g] + out_start[g] with length d_out_len[g]; out_start is SLOT_P29 (uint32 per graph),
+// per-graph status SLOT_P28 (0 ok; 1 node / 2 edge capacity; 3 reference-UB index; 4 cycle).
+int otg_launch_poa(otg_ctx* ctx, const uint8_t* d_seq_arena, const uint8_t* d_cig_arena,
+                   const otg_poa_member* d_members, uint32_t n_members, const otg_poa_graph* d_graphs,
+                   const otg_poa_graph* h_graphs, uint32_t n_graphs, uint32_t* d_out_len,
+                   std::vector<uint64_t>& node_off)
+{
+  if (n_graphs == 0) return OTG_OK;
+  // counting pre-pass
+  uint32_t* d_alt = (uint32_t*)otg_slot(ctx, SLOT_P20, (size_t)(n_members + 1) * sizeof(uint32_t));
+  uint32_t* d_nonm = (uint32_t*)otg_slot(ctx, SLOT_P21, (size_t)(n_members + 1) * sizeof(uint32_t));
+  if (!d_alt || !d_nonm) return OTG_ERR_HIP;
+  std::vector<uint32_t> h_alt(n_members), h_nonm(n_members);
+  if (n_members) {
+    hipLaunchKernelGGL(poa_count_kernel, dim3((n_members + 255) / 256), dim3(256), 0, ctx->stream, d_cig_arena, d_members, n_members, d_alt, d_nonm);
+    HIP_TRY(ctx, hipMemcpyAsync(h_alt.data(), d_alt, (size_t)n_members * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(h_nonm.data(), d_nonm, (size_t)n_members * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  std::vector<uint64_t> edge_off(n_graphs + 1), start_off(n_graphs + 1);
+  node_off.assign(n_graphs + 1, 0);
+  node_off[0] = edge_off[0] = start_off[0] = 0;
+  for (uint32_t g = 0; g < n_graphs; ++g) {
+    uint64_t alt = 0, nonm = 0;
+    for (uint32_t m = 0; m < h_graphs[g].n_members; ++m) { alt += h_alt[h_graphs[g].first_member + m]; nonm += h_nonm[h_graphs[g].first_member + m]; }
+    node_off[g + 1] = node_off[g] + (((uint64_t)h_graphs[g].backbone_len + alt + 2 + 3) & ~3ull);
+    edge_off[g + 1] = edge_off[g] + 2 * nonm + 2;
+    start_off[g + 1] = start_off[g] + h_graphs[g].n_members + 2;
+  }
+  const uint64_t NN = node_off[n_graphs], NE = edge_off[n_graphs], NS = start_off[n_graphs];
+  PoaDev P;
+  P.seq_arena = d_seq_arena; P.cig_arena = d_cig_arena; P.members = d_members; P.graphs = d_graphs; P.n_graphs = n_graphs;
+  uint64_t* d_node_off = (uint64_t*)otg_slot(ctx, SLOT_P0, (size_t)(n_graphs + 1) * sizeof(uint64_t));
+  uint64_t* d_edge_off = (uint64_t*)otg_slot(ctx, SLOT_P1, (size_t)(n_graphs + 1) * sizeof(uint64_t));
+  uint64_t* d_start_off = (uint64_t*)otg_slot(ctx, SLOT_P2, (size_t)(n_graphs + 1) * sizeof(uint64_t));
+  P.node_base = (uint8_t*)otg_slot(ctx, SLOT_P3, NN);
+  P.is_end = (uint8_t*)otg_slot(ctx, SLOT_P4, NN);
+  P.hdef = (uint8_t*)otg_slot(ctx, SLOT_P5, NN);
+  P.head = (int32_t*)otg_slot(ctx, SLOT_P6, NN * 4);
+  P.tail = (int32_t*)otg_slot(ctx, SLOT_P7, NN * 4);
+  P.indeg = (uint32_t*)otg_slot(ctx, SLOT_P8, NN * 4);
+  P.bb_cnt = (uint32_t*)otg_slot(ctx, SLOT_P9, NN * 4);
+  P.hw = (float*)otg_slot(ctx, SLOT_P10, NN * 4);
+  P.pred = (int32_t*)otg_slot(ctx, SLOT_P11, NN * 4);
+  P.queue = (uint32_t*)otg_slot(ctx, SLOT_P12, NN * 4);
+  P.e_sink = (uint32_t*)otg_slot(ctx, SLOT_P13, NE * 4);
+  P.e_w = (float*)otg_slot(ctx, SLOT_P14, NE * 4);
+  P.e_next = (int32_t*)otg_slot(ctx, SLOT_P15, NE * 4);
+  P.start_list = (uint32_t*)otg_slot(ctx, SLOT_P16, NS * 4);
+  P.out_arena = (uint8_t*)otg_slot(ctx, SLOT_P17, NN);
+  P.out_start = (uint32_t*)otg_slot(ctx, SLOT_P29, (size_t)n_graphs * 4);
+  P.status = (int32_t*)otg_slot(ctx, SLOT_P28, (size_t)n_graphs * 4);
+  if (!d_node_off || !d_edge_off || !d_start_off || !P.node_base || !P.is_end || !P.hdef || !P.head || !P.tail || !P.indeg ||
+      !P.bb_cnt || !P.hw || !P.pred || !P.queue || !P.e_sink || !P.e_w || !P.e_next || !P.start_list || !P.out_arena ||
+      !P.out_start || !P.status)
+    return OTG_ERR_HIP;
+  P.node_off = d_node_off; P.edge_off = d_edge_off; P.start_off = d_start_off;
+  P.out_off = d_node_off;     // consensus g is written into [node_off[g], node_off[g+1]) of out_arena
+  P.out_len = d_out_len;
+  HIP_TRY(ctx, hipMemcpyAsync(d_node_off, node_off.data(), (size_t)(n_graphs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_edge_off, edge_off.data(), (size_t)(n_graphs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_start_off, start_off.data(), (size_t)(n_graphs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // host vectors go out of scope after return
+  uint32_t gi = n_graphs < (uint32_t)ctx->n_cu * 8 ? n_graphs : (uint32_t)ctx->n_cu * 8;
+  hipLaunchKernelGGL(poa_init_kernel, dim3(gi), dim3(256), 0, ctx->stream, P);
+  hipLaunchKernelGGL(poa_graph_kernel, dim3((n_graphs + 63) / 64), dim3(64), 0, ctx->stream, P);
+  HIP_TRY(ctx, hipGetLastError());
+  return OTG_OK;
+}
