@@ -973,7 +973,9 @@ static int assemble_region(const otg_params& P, std::vector<Read>& reads, const 
   std::vector<int>& labels = out.labels;
   for (uint32_t i = 0; i < cl.labels.size(); ++i) labels[valid[i]] = cl.labels[i];
   const int total_alleles = cl.fc;
-  if (!invalid.empty()) {                                                      /* invalid_reassignment :126-177 */
+  /* `-a 0` leaves fc = 0 (reference defect): the reference then indexes an empty max_sim vector (UB);
+     the restatement (and the GPU path) skip the reassignment for such regions. */
+  if (!invalid.empty() && total_alleles > 0) {                                 /* invalid_reassignment :126-177 */
     for (int i = 0; i < (int)labels.size(); ++i) {
       if (labels[i] < 0) {
         std::vector<double> max_sim(total_alleles, 0.0);
@@ -985,7 +987,6 @@ static int assemble_region(const otg_params& P, std::vector<Read>& reads, const 
             if (sim > max_sim[labels[j]]) max_sim[labels[j]] = sim;
           }
         }
-        if (total_alleles == 0) continue;
         int max_sim_label = 0;
         for (int j = 1; j < total_alleles; ++j) if (max_sim[j] > max_sim[max_sim_label]) max_sim_label = j;
         int same_max_sim = 0;

@@ -86,6 +86,13 @@ __device__ __forceinline__ uint32_t otg_wave_atomic_add(uint32_t* ctr, uint32_t 
 int otg_launch_edit(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_task* d_tasks, uint32_t n_tasks,
                     int32_t* d_scores, uint64_t* d_cells, float* kernel_ms, uint64_t* launches);
 
+int otg_launch_edit_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_task* d_tasks, const uint32_t* d_todo,
+                         const uint32_t* d_n_todo, uint32_t n_task_slots, int32_t* d_scores, uint64_t* d_cells,
+                         float* kernel_ms, uint64_t* launches);
+int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_task* d_tasks, const uint32_t* d_todo,
+                           const uint32_t* d_n_todo, uint32_t n_task_slots, int x, int o, int e, int32_t* d_scores,
+                           const uint64_t* d_cig_off, uint32_t* d_cig_len, uint8_t* d_cig_arena, uint64_t* d_cells);
+
 // wfa_affine.hip — forward + backtrace + unpack; CIGARs land in d_cig_arena at d_cig_off (precomputed
 // exclusive prefix of pattern_len+text_len per task), lengths in d_cig_len.  Synchronises internally
 // (multi-round when the backtrace pool is smaller than the batch needs).

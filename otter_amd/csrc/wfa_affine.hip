@@ -273,6 +273,13 @@ int otg_launch_affine(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_task
                       int x, int o, int e, int32_t* d_scores, const uint64_t* d_cig_off, uint32_t* d_cig_len,
                       uint8_t* d_cig_arena, uint64_t* d_cells)
 {
+  return otg_launch_affine_todo(ctx, d_arena, d_tasks, nullptr, nullptr, n_tasks, x, o, e, d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells);
+}
+
+int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_task* d_tasks, const uint32_t* d_todo,
+                           const uint32_t* d_n_todo, uint32_t n_tasks, int x, int o, int e, int32_t* d_scores,
+                           const uint64_t* d_cig_off, uint32_t* d_cig_len, uint8_t* d_cig_arena, uint64_t* d_cells)
+{
   if (n_tasks == 0) return OTG_OK;
   if (x <= 0 || e <= 0 || o < 0) return otg_fail(ctx, OTG_ERR_ARG, "affine penalties must satisfy x>0, o>=0, e>0");
   const int g = gcd3(x, o + e, e);
@@ -325,7 +332,7 @@ int otg_launch_affine(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_task
   ws.base = wsp; ws2.base = wsp;
 
   hipLaunchKernelGGL((wfa_affine_kernel<WPB>), dim3(grid1), dim3(WPB * 64), 0, ctx->stream, d_arena, d_tasks,
-                     (const uint32_t*)nullptr, (const uint32_t*)nullptr, n_tasks, xs, oes, es, g, d_scores, d_cig_off, d_cig_len,
+                     d_todo, d_n_todo, n_tasks, xs, oes, es, g, d_scores, d_cig_off, d_cig_len,
                      d_cig_arena, d_cells, cnt + 8, cnt + 9, todo, ws);
   hipLaunchKernelGGL((wfa_affine_kernel<WPB>), dim3(grid2), dim3(WPB * 64), 0, ctx->stream, d_arena, d_tasks,
                      (const uint32_t*)todo, (const uint32_t*)(cnt + 9), 0u, xs, oes, es, g, d_scores, d_cig_off, d_cig_len,

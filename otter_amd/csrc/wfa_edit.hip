@@ -141,6 +141,15 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_kernel(
 int otg_launch_edit(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_task* d_tasks, uint32_t n_tasks,
                     int32_t* d_scores, uint64_t* d_cells, float* kernel_ms, uint64_t* launches)
 {
+  return otg_launch_edit_todo(ctx, d_arena, d_tasks, nullptr, nullptr, n_tasks, d_scores, d_cells, kernel_ms, launches);
+}
+
+// Same, for a compacted todo list of task slots whose length lives on the device (d_n_todo); n_tasks is
+// then the number of task SLOTS (upper bound, sizes the overflow lists and the grid).
+int otg_launch_edit_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_task* d_tasks, const uint32_t* d_todo,
+                         const uint32_t* d_n_todo, uint32_t n_tasks, int32_t* d_scores, uint64_t* d_cells,
+                         float* kernel_ms, uint64_t* launches)
+{
   if (n_tasks == 0) return OTG_OK;
   uint32_t* cnt = (uint32_t*)otg_slot(ctx, SLOT_COUNTERS, 64 * sizeof(uint32_t));
   uint32_t* todo = (uint32_t*)otg_slot(ctx, SLOT_TODO, 2 * (size_t)n_tasks * sizeof(uint32_t));
@@ -156,7 +165,7 @@ int otg_launch_edit(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_task* 
     uint32_t grid = (uint32_t)ctx->n_cu * 5;
     if (grid > want) grid = want;
     hipLaunchKernelGGL((wfa_edit_kernel<CAP, WPB, false>), dim3(grid), dim3(WPB * 64), lds, ctx->stream, d_arena, d_tasks,
-                       (const uint32_t*)nullptr, (const uint32_t*)nullptr, n_tasks, d_scores, d_cells, cnt + 0, cnt + 1, todo2,
+                       d_todo, d_n_todo, n_tasks, d_scores, d_cells, cnt + 0, cnt + 1, todo2,
                        (int32_t*)nullptr, 0);
   }
   if (kernel_ms) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));

@@ -1,0 +1,102 @@
+"""GPU parity of the whole hot path (region loop body of assemble_process, src/assemble.cpp:71-150):
+HIP pipeline through the C-ABI vs the CPU oracle on the same seeded region batches.
+Integer fields and sequences bit-exact; `se` within 1e-6 (north_star tolerance; in practice identical)."""
+import numpy as np
+import pytest
+from otter_amd import abi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def compare(gpu_res, ora, batch):
+    gr, orr = gpu_res["regions"], ora["regions"]
+    for f in ("status", "ic", "fc", "n_valid", "n_alleles", "first_allele"):
+        assert np.array_equal(gr[f], orr[f]), f
+    assert np.array_equal(gpu_res["labels"], ora["labels"])
+    ga, oa = gpu_res["alleles"], ora["alleles"]
+    assert len(ga) == len(oa)
+    for f in ("seq_len", "scov", "acov", "tcov", "ic", "ps", "hp", "region", "label"):
+        assert np.array_equal(ga[f], oa[f]), f
+    assert np.allclose(ga["se"], oa["se"], rtol=0, atol=1e-6)
+    for i in range(len(ga)):
+        gs = gpu_res["seqs"][int(ga[i]["seq_off"]):int(ga[i]["seq_off"]) + int(ga[i]["seq_len"])].tobytes()
+        os_ = ora["seqs"][int(oa[i]["seq_off"]):int(oa[i]["seq_off"]) + int(oa[i]["seq_len"])].tobytes()
+        assert gs == os_, "allele %d sequence differs" % i
+
+
+def run_both(gpu, oracle, batch, **kw):
+    P = abi.default_params(**kw)
+    ora = oracle.assemble_batch(P, batch)
+    res = gpu.assemble(P, batch)
+    compare(res, ora, batch)
+    st = gpu.assemble_stats()
+    os_ = ora["stats"][0]
+    for f in ("edit_tasks", "edit_cells", "edit_seq_bytes", "affine_tasks", "affine_cells", "affine_seq_bytes", "allele_bytes", "algorithmic_bytes"):
+        assert int(st[f]) == int(os_[f]), f
+    return res, st
+
+
+def test_config0_hifi_500bp(gpu, oracle):
+    """BASELINE config 0: 100 regions x 500 bp, 10x HiFi spanning reads."""
+    b = synth.make_batch(**synth.CONFIGS[0])
+    res, st = run_both(gpu, oracle, b)
+    assert int(st["n_regions_ok"]) == 100
+
+
+def test_hifi_with_partial_reads(gpu, oracle):
+    b = synth.make_batch(60, len_range=(200, 900), n_reads=14, err="hifi", frac_partial=0.3, seed=3, reads_range=(1, 20))
+    run_both(gpu, oracle, b)
+
+
+def test_ont_kb(gpu, oracle):
+    """config-1-like slice: 1-3 kb ONT, 30 reads."""
+    b = synth.make_batch(24, len_range=(1000, 3000), n_reads=30, err="ont", seed=4)
+    run_both(gpu, oracle, b)
+
+
+def test_realign_flanks(gpu, oracle):
+    """config-2-like slice: -r given, soft-clipped flanks rescued by local re-alignment."""
+    b = synth.make_batch(30, len_range=(300, 900), n_reads=16, err="hifi", realign=True, seed=6)
+    res, st = run_both(gpu, oracle, b, realign=1)
+    assert int(st["affine_tasks"]) > 0
+
+
+def test_haps_mode(gpu, oracle):
+    b = synth.make_batch(30, len_range=(300, 800), n_reads=12, err="hifi", haps=True, frac_partial=0.2, seed=8)
+    # drop the tags of a third of the reads: they become "invalid" and are re-assigned by similarity
+    rng = np.random.default_rng(8)
+    drop = rng.random(len(b["reads"])) < 0.33
+    b["reads"]["ps"][drop] = -1
+    b["reads"]["hp"][drop] = -1
+    run_both(gpu, oracle, b, ignore_haps=0)
+
+
+def test_edge_regions(gpu, oracle):
+    """Empty region, no spanning reads, too many reads (max_cov), single read, two reads, max_alleles 1 and 0."""
+    b = synth.make_batch(8, len_range=(150, 300), n_reads=9, err="hifi", seed=9, frac_partial=0.1)
+    reads, regions = b["reads"].copy(), b["regions"].copy()
+    regions[0]["n_reads"] = 0
+    r1 = regions[1]
+    reads["spanning_r"][r1["first_read"]:r1["first_read"] + r1["n_reads"]] = 0
+    regions[2]["n_reads"] = 1
+    regions[3]["n_reads"] = 2
+    b2 = dict(b, reads=reads, regions=regions)
+    run_both(gpu, oracle, b2)
+    run_both(gpu, oracle, b2, max_cov=5)
+    run_both(gpu, oracle, b2, max_alleles=1)
+    run_both(gpu, oracle, b2, max_alleles=0)
+    run_both(gpu, oracle, b2, max_alleles=3)
+
+
+def test_batch_composition_independence(gpu, oracle):
+    """Results do not depend on how regions are batched (static BED split): shards == whole."""
+    b = synth.make_batch(20, len_range=(200, 600), n_reads=10, err="hifi", seed=10)
+    P = abi.default_params()
+    whole = gpu.assemble(P, b)
+    parts = [gpu.assemble(P, b, region_range=synth.shard_bounds(20, 3, r)) for r in range(3)]
+    seqs_whole = [whole["seqs"][int(a["seq_off"]):int(a["seq_off"]) + int(a["seq_len"])].tobytes() for a in whole["alleles"]]
+    seqs_parts = []
+    for p in parts:
+        seqs_parts += [p["seqs"][int(a["seq_off"]):int(a["seq_off"]) + int(a["seq_len"])].tobytes() for a in p["alleles"]]
+    assert seqs_whole == seqs_parts
+    assert np.array_equal(np.concatenate([p["regions"]["fc"] for p in parts]), whole["regions"]["fc"])
