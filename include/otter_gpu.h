@@ -222,8 +222,10 @@ typedef struct otg_run_stats {
   uint64_t allele_bytes;
   uint64_t algorithmic_bytes;         /* Σ (a+b) + 4·W (+ W/2 for CIGAR scope) + Σ(len+40) */
   double   ms_edit, ms_cluster, ms_reassign, ms_affine, ms_poa, ms_realign, ms_total;
-  double   ms_edit_kernel;            /* dominant kernel: HIP-event time of the edit WFA launches */
+  double   ms_edit_kernel;            /* HIP-event time of the edit WFA kernel launches (tier 1, summed)   */
   uint64_t edit_kernel_launches;
+  double   ms_affine_kernel;          /* HIP-event time of the gap-affine WFA kernel launches (tier 1)     */
+  uint64_t affine_kernel_launches;
 } otg_run_stats;
 
 /* Upload a batch (H2D).  After it returns the inputs are resident in HBM.                       */

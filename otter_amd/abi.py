@@ -76,7 +76,8 @@ run_stats_dt = np.dtype([
     ("affine_tasks", "<u8"), ("affine_cells", "<u8"), ("affine_seq_bytes", "<u8"),
     ("allele_bytes", "<u8"), ("algorithmic_bytes", "<u8"),
     ("ms_edit", "<f8"), ("ms_cluster", "<f8"), ("ms_reassign", "<f8"), ("ms_affine", "<f8"), ("ms_poa", "<f8"),
-    ("ms_realign", "<f8"), ("ms_total", "<f8"), ("ms_edit_kernel", "<f8"), ("edit_kernel_launches", "<u8")], align=True)
+    ("ms_realign", "<f8"), ("ms_total", "<f8"), ("ms_edit_kernel", "<f8"), ("edit_kernel_launches", "<u8"),
+    ("ms_affine_kernel", "<f8"), ("affine_kernel_launches", "<u8")], align=True)
 
 assert align_task_dt.itemsize == 48
 assert read_dt.itemsize == 32

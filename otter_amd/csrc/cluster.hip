@@ -276,6 +276,49 @@ __device__ void nn_chain_average(int N, double* D, Lds& L)
 #undef D_
 }
 
+// hclust_fast(AVERAGE): NN-chain (thread 0) + generate_R_dendrogram<false> (stable sort by height = rank by
+// (dist, position), computed in parallel; union-find relabel by thread 0).  Block-cooperative: call from all
+// threads.  Leaves L.merge (R convention, column-major) and L.height.
+__device__ void hclust_to_merge(int n, double* D, Lds& L, int tid)
+{
+  if (tid == 0) nn_chain_average(n, D, L);
+  __syncthreads();
+  for (int i = tid; i < n - 1; i += blockDim.x) {
+    int rank = 0;
+    const double di = L.zdist[i];
+    for (int j = 0; j < n - 1; ++j) { const double dj = L.zdist[j]; if (dj < di || (dj == di && j < i)) ++rank; }
+    L.zrank[rank] = i;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int i = 0; i < 2 * n - 1; ++i) L.parent[i] = 0;
+    int nextparent = n;
+    for (int k = 0; k < n - 1; ++k) {
+      const int src = L.zrank[k];
+      int a = L.z1[src], b = L.z2[src];
+      // union_find::Find with path compression (fastcluster_dm.hpp:366-383)
+      for (int w = 0; w < 2; ++w) {
+        int idx = w ? b : a;
+        if (L.parent[idx] != 0) {
+          int p = idx;
+          idx = L.parent[idx];
+          if (L.parent[idx] != 0) {
+            do { idx = L.parent[idx]; } while (L.parent[idx] != 0);
+            do { int tmp = L.parent[p]; L.parent[p] = idx; p = tmp; } while (L.parent[p] != idx);
+          }
+        }
+        if (w) b = idx; else a = idx;
+      }
+      L.parent[a] = L.parent[b] = nextparent++;
+      if (a > b) { int t = a; a = b; b = t; }
+      L.merge[k] = (a < n) ? -a - 1 : a - n + 1;
+      L.merge[k + n - 1] = (b < n) ? -b - 1 : b - n + 1;
+      L.height[k] = L.zdist[src];
+    }
+  }
+  __syncthreads();
+}
+
 template <bool FMA>
 __global__ __launch_bounds__(256) void cluster_kernel(
     ClusterArgs A, const double* __restrict__ dist, const uint64_t* __restrict__ dist_off,
@@ -418,41 +461,8 @@ __global__ __launch_bounds__(256) void cluster_kernel(
     double* D = (npairs <= (size_t)DLDS) ? L.dwork : gwork + dist_off[r];
     for (size_t q = tid; q < npairs; q += blockDim.x) D[q] = dv[q];
     __syncthreads();
-    if (tid == 0) nn_chain_average(n, D, L);
-    __syncthreads();
-    // generate_R_dendrogram<false>: std::stable_sort by dist == rank by (dist, original position)
-    for (int i = tid; i < n - 1; i += blockDim.x) {
-      int rank = 0;
-      const double di = L.zdist[i];
-      for (int j = 0; j < n - 1; ++j) { const double dj = L.zdist[j]; if (dj < di || (dj == di && j < i)) ++rank; }
-      L.zrank[rank] = i;
-    }
-    __syncthreads();
+    hclust_to_merge(n, D, L, tid);
     if (tid == 0) {
-      for (int i = 0; i < 2 * n - 1; ++i) L.parent[i] = 0;
-      int nextparent = n;
-      for (int k = 0; k < n - 1; ++k) {
-        const int src = L.zrank[k];
-        int a = L.z1[src], b = L.z2[src];
-        // union_find::Find with path compression (fastcluster_dm.hpp:366-383)
-        for (int w = 0; w < 2; ++w) {
-          int idx = w ? b : a;
-          if (L.parent[idx] != 0) {
-            int p = idx;
-            idx = L.parent[idx];
-            if (L.parent[idx] != 0) {
-              do { idx = L.parent[idx]; } while (L.parent[idx] != 0);
-              do { int tmp = L.parent[p]; L.parent[p] = idx; p = tmp; } while (L.parent[p] != idx);
-            }
-          }
-          if (w) b = idx; else a = idx;
-        }
-        L.parent[a] = L.parent[b] = nextparent++;
-        if (a > b) { int t = a; a = b; b = t; }
-        L.merge[k] = (a < n) ? -a - 1 : a - n + 1;
-        L.merge[k + n - 1] = (b < n) ? -b - 1 : b - n + 1;
-        L.height[k] = L.zdist[src];
-      }
       // cutree_cdist (:185; fastcluster.cpp:95-105)
       int kc;
       for (kc = 0; kc < (n - 1); kc++) if (L.height[kc] >= L.dist_final) break;
@@ -508,6 +518,118 @@ __global__ __launch_bounds__(256) void cluster_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// anallele_cluster (reference: src/otterclust.cpp:463-527) for `otter genotype`: length-ratio matrix
+// (:322-327,367-382) and 3-mer-usage cosine matrix rounded to 3 decimals (:384-420; KUSAGE src/anseqs.cpp:111-147,
+// seq2kcounts :149-166), two average-linkage cuts (cluter_to_e :329-349), genotype = distinct (gt_l, gt_k) pairs in
+// first-seen order, representative = medoid under the LENGTH matrix (:517-524).  One workgroup per region.
+__global__ __launch_bounds__(256) void genotype_kernel(
+    double max_error_l, double max_error_c, const uint8_t* __restrict__ arena, const uint64_t* __restrict__ seq_off,
+    const uint32_t* __restrict__ seq_len, const uint32_t* __restrict__ first_allele, const uint32_t* __restrict__ n_alleles,
+    uint32_t n_regions, const uint64_t* __restrict__ pair_off, double* __restrict__ g_dl, double* __restrict__ g_dk,
+    double* __restrict__ g_work, double* __restrict__ g_kvec, double* __restrict__ g_vnorm,
+    int32_t* __restrict__ gt, int32_t* __restrict__ gt_l, int32_t* __restrict__ gt_k, double* __restrict__ hsd,
+    int32_t* __restrict__ n_gt, int32_t* __restrict__ reps, int32_t* __restrict__ err_out)
+{
+  __shared__ Lds L;
+  const int tid = threadIdx.x;
+  for (uint32_t r = blockIdx.x; r < n_regions; r += gridDim.x) {
+    const int A = (int)n_alleles[r];
+    const uint32_t f = first_allele[r];
+    __syncthreads();
+    if (A == 0) { if (tid == 0) { n_gt[r] = 0; err_out[r] = 0; } continue; }
+    if (A > NMAX) { if (tid == 0) { n_gt[r] = 0; err_out[r] = 10; } continue; }
+    double* dl = g_dl + pair_off[r]; double* dk = g_dk + pair_off[r]; double* wk = g_work + pair_off[r];
+    double* kv = g_kvec + (size_t)f * 65; double* vn = g_vnorm + f;
+    // KUSAGE per allele (3-mers: 64 bins + 1 "invalid" bin)
+    for (int a = tid; a < A; a += blockDim.x) {
+      double* v = kv + (size_t)a * 65;
+      for (int q = 0; q < 65; ++q) v[q] = 0.0;
+      const uint8_t* s = arena + seq_off[f + a];
+      const uint32_t n = seq_len[f + a];
+      if (n >= 3) {
+        for (uint32_t j = 0; j + 3 <= n; ++j) {
+          int idx = 0; bool ok = true;
+          for (int hh = 0; hh < 3; ++hh) {
+            const uint8_t ch = s[j + hh];
+            int c = (ch == 'A' || ch == 'a') ? 0 : (ch == 'C' || ch == 'c') ? 1 : (ch == 'G' || ch == 'g') ? 2 : (ch == 'T' || ch == 't') ? 3 : 4;
+            if (c == 4) { ok = false; break; }
+            idx = 4 * idx + c;
+          }
+          v[ok ? idx : 64] += 1.0;
+        }
+      }
+      int total_counts = 0;
+      for (int q = 0; q < 65; ++q) total_counts += v[q];            // int += double (src/anseqs.cpp:113-114)
+      double norm = 0;
+      for (int q = 0; q < 65; ++q) { const double value = v[q] / total_counts; v[q] = value; norm += value * value; }
+      vn[a] = sqrt(norm);
+      double acc = 0;                                                // hsdiv (:135-147), FP tolerance field
+      for (int q = 0; q < 65; ++q) if (v[q] > 0) acc += (v[q] * log(v[q]));
+      acc = -1 * acc;
+      hsd[f + a] = pow(2.718281828459045235360287471352662498, acc);
+    }
+    __syncthreads();
+    if (A == 1) { if (tid == 0) { gt[f] = gt_l[f] = gt_k[f] = 0; reps[f] = 0; n_gt[r] = 1; err_out[r] = 0; } continue; }
+    // the two matrices
+    for (int i = 0; i < A - 1; ++i) {
+      for (int j = i + 1 + tid; j < A; j += blockDim.x) {
+        const uint32_t x = seq_len[f + i], y = seq_len[f + j];
+        const bool xs = x < y;
+        double d = xs ? (double)(y - x) : (double)(x - y);
+        d = xs ? d / y : d / x;
+        dl[didx(A, i, j)] = d; wk[didx(A, i, j)] = d;
+        const double* vi = kv + (size_t)i * 65; const double* vj = kv + (size_t)j * 65;
+        double dot = 0;
+        for (int q = 0; q < 65; ++q) dot += vi[q] * vj[q];
+        const double cs = dot / (vn[i] * vn[j]);
+        const bool nan_norm = (vn[i] != vn[i]) || (vn[j] != vn[j]);
+        dk[didx(A, i, j)] = 1.0 - (nan_norm ? 0 : (round(cs * 1000.0) / 1000.0));
+      }
+    }
+    __syncthreads();
+    // length clustering
+    hclust_to_merge(A, wk, L, tid);
+    if (tid == 0) {
+      int kc;
+      for (kc = 0; kc < (A - 1); kc++) if (L.height[kc] >= max_error_l) break;
+      cutree_k_dev(A, L.merge, A - kc, L.labels, L.last_merge, L.zz);
+      for (int a = 0; a < A; ++a) gt_l[f + a] = L.labels[a];
+    }
+    __syncthreads();
+    for (size_t q = tid; q < (size_t)A * (A - 1) / 2; q += blockDim.x) wk[q] = dk[q];
+    __syncthreads();
+    hclust_to_merge(A, wk, L, tid);
+    if (tid == 0) {
+      int kc;
+      for (kc = 0; kc < (A - 1); kc++) if (L.height[kc] >= max_error_c) break;
+      cutree_k_dev(A, L.merge, A - kc, L.labels2, L.last_merge, L.zz);
+      for (int a = 0; a < A; ++a) gt_k[f + a] = L.labels2[a];
+      // final clusters: distinct (gt_l, gt_k) in first-seen order (:500-516)
+      int ng = 0;
+      for (int a = 0; a < A; ++a) L.cnt[a] = -1;
+      for (int a = 0; a < A; ++a) {
+        if (L.cnt[a] >= 0) continue;
+        for (int b = a; b < A; ++b) if (L.cnt[b] < 0 && L.labels[b] == L.labels[a] && L.labels2[b] == L.labels2[a]) L.cnt[b] = ng;
+        ++ng;
+      }
+      for (int a = 0; a < A; ++a) { gt[f + a] = L.cnt[a]; reps[f + a] = -1; }
+      for (int g = 0; g < ng; ++g) {                                  // medoid under the length matrix (:517-524)
+        int min_i = -1; double min_sum = 100000000.0;
+        for (int a = 0; a < A; ++a) {
+          if (L.cnt[a] != g) continue;
+          if (min_i < 0) min_i = a;
+          double sm = 0.0;
+          for (int b = 0; b < A; ++b) if (L.cnt[b] == g && a != b) sm += dget(dl, A, a, b);
+          if (sm < min_sum) { min_i = a; min_sum = sm; }
+        }
+        reps[f + g] = min_i;
+      }
+      n_gt[r] = ng; err_out[r] = 0;
+    }
+  }
+}
+
 } // namespace
 
 int otg_launch_cluster(otg_ctx* ctx, const otg_params* P, const double* d_dist, const uint64_t* d_dist_off,
@@ -554,6 +676,26 @@ int otg_launch_cluster(otg_ctx* ctx, const otg_params* P, const double* d_dist, 
   else
     hipLaunchKernelGGL((cluster_kernel<false>), dim3(grid_dim), dim3(256), 0, ctx->stream, A, d_dist, d_dist_off, d_read_len, d_len_off,
                        d_n_valid, n_regions, gwork, d_labels, d_ic, d_fc, d_bounds, d_err);
+  HIP_TRY(ctx, hipGetLastError());
+  return OTG_OK;
+}
+
+int otg_launch_genotype(otg_ctx* ctx, const otg_params* P, const uint8_t* d_arena, const uint64_t* d_seq_off,
+                        const uint32_t* d_seq_len, const uint32_t* d_first, const uint32_t* d_n, uint32_t n_regions,
+                        const uint64_t* d_pair_off, uint64_t n_pairs_total, uint64_t n_alleles_total,
+                        int32_t* d_gt, int32_t* d_gtl, int32_t* d_gtk, double* d_hsd, int32_t* d_ngt, int32_t* d_reps,
+                        int32_t* d_err)
+{
+  if (n_regions == 0) return OTG_OK;
+  double* g_dl = (double*)otg_slot(ctx, SLOT_P20, (n_pairs_total + 1) * 8);
+  double* g_dk = (double*)otg_slot(ctx, SLOT_P21, (n_pairs_total + 1) * 8);
+  double* g_wk = (double*)otg_slot(ctx, SLOT_P22, (n_pairs_total + 1) * 8);
+  double* g_kv = (double*)otg_slot(ctx, SLOT_P23, (n_alleles_total + 1) * 65 * 8);
+  double* g_vn = (double*)otg_slot(ctx, SLOT_P24, (n_alleles_total + 1) * 8);
+  if (!g_dl || !g_dk || !g_wk || !g_kv || !g_vn) return OTG_ERR_HIP;
+  uint32_t grid_dim = n_regions < (uint32_t)ctx->n_cu * 8 ? n_regions : (uint32_t)ctx->n_cu * 8;
+  hipLaunchKernelGGL(genotype_kernel, dim3(grid_dim), dim3(256), 0, ctx->stream, P->gt_max_error, P->gt_max_cosdis, d_arena, d_seq_off,
+                     d_seq_len, d_first, d_n, n_regions, d_pair_off, g_dl, g_dk, g_wk, g_kv, g_vn, d_gt, d_gtl, d_gtk, d_hsd, d_ngt, d_reps, d_err);
   HIP_TRY(ctx, hipGetLastError());
   return OTG_OK;
 }

@@ -330,6 +330,59 @@ int otg_poa_consensus_batch(otg_ctx* ctx, const uint8_t* seq_arena, uint64_t are
   return OTG_OK;
 }
 
+int otg_genotype_cluster_batch(otg_ctx* ctx, const otg_params* params, const uint8_t* seq_arena, uint64_t arena_bytes,
+                               const uint64_t* seq_off, const uint32_t* seq_len,
+                               const uint32_t* first_allele, const uint32_t* n_alleles, uint32_t n_regions,
+                               int32_t* gt_out, int32_t* gt_l_out, int32_t* gt_k_out, double* hsd_out,
+                               int32_t* n_gt_out, int32_t* reps_out)
+{
+  if (!ctx) return otg_fail(nullptr, OTG_ERR_NO_DEVICE, "otg_genotype_cluster_batch: no context (no HIP device?)");
+  if (n_regions == 0) return OTG_OK;
+  if (!params || !seq_arena || !seq_off || !seq_len || !first_allele || !n_alleles || !gt_out || !gt_l_out || !gt_k_out || !hsd_out || !n_gt_out || !reps_out)
+    return otg_fail(ctx, OTG_ERR_ARG, "otg_genotype_cluster_batch: NULL argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  uint64_t na = 0;
+  std::vector<uint64_t> pair_off(n_regions + 1, 0);
+  for (uint32_t r = 0; r < n_regions; ++r) {
+    na = std::max<uint64_t>(na, (uint64_t)first_allele[r] + n_alleles[r]);
+    uint64_t A = n_alleles[r];
+    pair_off[r + 1] = pair_off[r] + A * (A ? A - 1 : 0) / 2;
+  }
+  for (uint64_t i = 0; i < na; ++i) if (seq_off[i] + seq_len[i] > arena_bytes) return otg_fail(ctx, OTG_ERR_ARG, "allele %llu: sequence outside the arena", (unsigned long long)i);
+  uint8_t* d_arena = (uint8_t*)otg_slot(ctx, SLOT_ARENA, arena_bytes + 64);
+  uint64_t* d_off = (uint64_t*)otg_slot(ctx, SLOT_AUX0, (na + 1) * 8);
+  uint32_t* d_len = (uint32_t*)otg_slot(ctx, SLOT_AUX1, (na + 1) * 4);
+  uint32_t* d_first = (uint32_t*)otg_slot(ctx, SLOT_AUX2, (size_t)n_regions * 4);
+  uint32_t* d_n = (uint32_t*)otg_slot(ctx, SLOT_AUX3, (size_t)n_regions * 4);
+  uint64_t* d_poff = (uint64_t*)otg_slot(ctx, SLOT_AUX4, (size_t)(n_regions + 1) * 8);
+  int32_t* d_gt = (int32_t*)otg_slot(ctx, SLOT_AUX5, (na + 1) * 4 * 4);
+  double* d_hsd = (double*)otg_slot(ctx, SLOT_AUX6, (na + 1) * 8);
+  int32_t* d_ngt = (int32_t*)otg_slot(ctx, SLOT_AUX7, (size_t)n_regions * 2 * 4);
+  if (!d_arena || !d_off || !d_len || !d_first || !d_n || !d_poff || !d_gt || !d_hsd || !d_ngt) return OTG_ERR_HIP;
+  int32_t *d_gtl = d_gt + (na + 1), *d_gtk = d_gtl + (na + 1), *d_reps = d_gtk + (na + 1), *d_err = d_ngt + n_regions;
+  HIP_TRY(ctx, hipMemcpyAsync(d_arena, seq_arena, arena_bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_off, seq_off, na * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_len, seq_len, na * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_first, first_allele, (size_t)n_regions * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_n, n_alleles, (size_t)n_regions * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_poff, pair_off.data(), (size_t)(n_regions + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(d_gt, 0xff, (na + 1) * 4 * 4, ctx->stream));
+  int rc = otg_launch_genotype(ctx, params, d_arena, d_off, d_len, d_first, d_n, n_regions, d_poff, pair_off[n_regions], na,
+                               d_gt, d_gtl, d_gtk, d_hsd, d_ngt, d_reps, d_err);
+  if (rc) return rc;
+  std::vector<int32_t> h_err(n_regions);
+  HIP_TRY(ctx, hipMemcpyAsync(gt_out, d_gt, na * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(gt_l_out, d_gtl, na * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(gt_k_out, d_gtk, na * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(reps_out, d_reps, na * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(hsd_out, d_hsd, na * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(n_gt_out, d_ngt, (size_t)n_regions * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(h_err.data(), d_err, (size_t)n_regions * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (uint32_t r = 0; r < n_regions; ++r) if (h_err[r]) return otg_fail(ctx, OTG_ERR_CAPACITY, "region %u: more than 256 alleles", r);
+  return OTG_OK;
+}
+
 } // extern "C"
 
 // ---------------------------------------------------------------------------------------------------

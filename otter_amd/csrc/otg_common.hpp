@@ -91,7 +91,8 @@ int otg_launch_edit_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_t
                          float* kernel_ms, uint64_t* launches);
 int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_task* d_tasks, const uint32_t* d_todo,
                            const uint32_t* d_n_todo, uint32_t n_task_slots, int x, int o, int e, int32_t* d_scores,
-                           const uint64_t* d_cig_off, uint32_t* d_cig_len, uint8_t* d_cig_arena, uint64_t* d_cells);
+                           const uint64_t* d_cig_off, uint32_t* d_cig_len, uint8_t* d_cig_arena, uint64_t* d_cells,
+                           float* kernel_ms = nullptr, uint64_t* launches = nullptr);
 
 // wfa_affine.hip — forward + backtrace + unpack; CIGARs land in d_cig_arena at d_cig_off (precomputed
 // exclusive prefix of pattern_len+text_len per task), lengths in d_cig_len.  Synchronises internally
@@ -112,8 +113,9 @@ int otg_launch_poa(otg_ctx* ctx, const uint8_t* d_seq_arena, const uint8_t* d_ci
                    const otg_poa_graph* h_graphs, uint32_t n_graphs, uint32_t* d_out_len,
                    std::vector<uint64_t>& node_off);
 
-// genotype.hip
+// cluster.hip (genotype_kernel)
 int otg_launch_genotype(otg_ctx* ctx, const otg_params* P, const uint8_t* d_arena, const uint64_t* d_seq_off,
                         const uint32_t* d_seq_len, const uint32_t* d_first, const uint32_t* d_n, uint32_t n_regions,
-                        uint32_t max_alleles_per_region, int32_t* d_gt, int32_t* d_gtl, int32_t* d_gtk,
-                        double* d_hsd, int32_t* d_ngt, int32_t* d_reps);
+                        const uint64_t* d_pair_off, uint64_t n_pairs_total, uint64_t n_alleles_total,
+                        int32_t* d_gt, int32_t* d_gtl, int32_t* d_gtk, double* d_hsd, int32_t* d_ngt, int32_t* d_reps,
+                        int32_t* d_err);

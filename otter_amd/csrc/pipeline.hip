@@ -722,8 +722,10 @@ int otg_assemble_run(otg_ctx* ctx)
     Timer t(ctx);
     hipLaunchKernelGGL(K_realign_prepare, dim3(gr_reads), dim3(TB), 0, st, d_reads, d_regions, d_rr, NR, P.flank, d_tasks, (uint8_t*)B(B_RKIND), d_todo, d_cnt + 16);
     HIP_TRY(ctx, hipMemsetAsync(d_cig_len, 0, (size_t)NR * 4, st));
-    rc = otg_launch_affine_todo(ctx, d_arena, d_tasks, d_todo, d_cnt + 16, NR, P.mismatch, P.gap_open, P.gap_ext, d_scores, d_cig_off, d_cig_len, d_cig, d_cells);
-    if (rc) return rc;
+    { float kms = 0; uint64_t kl = 0;
+      rc = otg_launch_affine_todo(ctx, d_arena, d_tasks, d_todo, d_cnt + 16, NR, P.mismatch, P.gap_open, P.gap_ext, d_scores, d_cig_off, d_cig_len, d_cig, d_cells, &kms, &kl);
+      if (rc) return rc;
+      pl->stats.ms_affine_kernel += kms; pl->stats.affine_kernel_launches += kl; }
     hipLaunchKernelGGL(K_stats, dim3(64), dim3(256), 0, st, d_todo, d_cnt + 16, d_tasks, d_cells, d_stats + 4, d_scores, d_cnt + 41);
     hipLaunchKernelGGL(K_realign_apply, dim3(gr_reads), dim3(TB), 0, st, d_reads, NR, (const uint8_t*)B(B_RKIND), d_cig, d_cig_off, d_cig_len, P.flank, P.min_sim);
     pl->stats.ms_realign = t.ms();
@@ -775,8 +777,10 @@ int otg_assemble_run(otg_ctx* ctx)
     hipLaunchKernelGGL(K_consensus_prepare, dim3((NG + 63) / 64), dim3(64), 0, st, d_reads, d_regions, NG, d_status, d_nvalid, d_ign, d_valid, d_labels,
                        (const int32_t*)B(B_FC), (const uint64_t*)B(B_DIST_OFF), d_dist, d_cig_off, (AlleleSlot*)B(B_ALLELES),
                        (otg_poa_graph*)B(B_GRAPHS), (otg_poa_member*)B(B_MEMBERS), d_tasks, d_todo, d_cnt + 28, (uint32_t*)B(B_SCAN_TMP));
-    rc = otg_launch_affine_todo(ctx, d_arena, d_tasks, d_todo, d_cnt + 28, NR, P.mismatch, P.gap_open, P.gap_ext, d_scores, d_cig_off, d_cig_len, d_cig, d_cells);
-    if (rc) return rc;
+    { float kms = 0; uint64_t kl = 0;
+      rc = otg_launch_affine_todo(ctx, d_arena, d_tasks, d_todo, d_cnt + 28, NR, P.mismatch, P.gap_open, P.gap_ext, d_scores, d_cig_off, d_cig_len, d_cig, d_cells, &kms, &kl);
+      if (rc) return rc;
+      pl->stats.ms_affine_kernel += kms; pl->stats.affine_kernel_launches += kl; }
     hipLaunchKernelGGL(K_stats, dim3(64), dim3(256), 0, st, d_todo, d_cnt + 28, d_tasks, d_cells, d_stats + 4, d_scores, d_cnt + 41);
     hipLaunchKernelGGL(K_member_cigars, dim3(gr_reads), dim3(TB), 0, st, (otg_poa_member*)B(B_MEMBERS), (const otg_poa_graph*)B(B_GRAPHS), NR, d_cig_len);
     pl->stats.ms_affine = t.ms();

@@ -278,7 +278,8 @@ int otg_launch_affine(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_task
 
 int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_task* d_tasks, const uint32_t* d_todo,
                            const uint32_t* d_n_todo, uint32_t n_tasks, int x, int o, int e, int32_t* d_scores,
-                           const uint64_t* d_cig_off, uint32_t* d_cig_len, uint8_t* d_cig_arena, uint64_t* d_cells)
+                           const uint64_t* d_cig_off, uint32_t* d_cig_len, uint8_t* d_cig_arena, uint64_t* d_cells,
+                           float* kernel_ms, uint64_t* launches)
 {
   if (n_tasks == 0) return OTG_OK;
   if (x <= 0 || e <= 0 || o < 0) return otg_fail(ctx, OTG_ERR_ARG, "affine penalties must satisfy x>0, o>=0, e>0");
@@ -331,12 +332,21 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
   if (!wsp) return OTG_ERR_HIP;
   ws.base = wsp; ws2.base = wsp;
 
+  if (kernel_ms) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   hipLaunchKernelGGL((wfa_affine_kernel<WPB>), dim3(grid1), dim3(WPB * 64), 0, ctx->stream, d_arena, d_tasks,
                      d_todo, d_n_todo, n_tasks, xs, oes, es, g, d_scores, d_cig_off, d_cig_len,
                      d_cig_arena, d_cells, cnt + 8, cnt + 9, todo, ws);
+  if (kernel_ms) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   hipLaunchKernelGGL((wfa_affine_kernel<WPB>), dim3(grid2), dim3(WPB * 64), 0, ctx->stream, d_arena, d_tasks,
                      (const uint32_t*)todo, (const uint32_t*)(cnt + 9), 0u, xs, oes, es, g, d_scores, d_cig_off, d_cig_len,
                      d_cig_arena, d_cells, cnt + 10, cnt + 11, (uint32_t*)nullptr, ws2);
   HIP_TRY(ctx, hipGetLastError());
+  if (kernel_ms) {
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *kernel_ms += ms;
+    if (launches) *launches += 1;
+  }
   return OTG_OK;
 }

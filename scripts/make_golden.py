@@ -1,0 +1,64 @@
+"""Generates tests/golden/*.npz by RUNNING THE REFERENCE'S OWN CODE (oracle/_ref/libotter_ref.so, built from
+/root/reference/src/{andistmat,ankde}.cpp, include/hclust-cpp/fastcluster.cpp and src/anppoa.hpp) on seeded
+inputs.  Fixtures are data only (inputs + expected outputs).  Run in the build container:
+    python scripts/make_golden.py"""
+import os
+import sys
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as O  # noqa: E402
+from helpers import cluster_cases, random_poa_specs, build_poa_batch  # noqa: E402
+
+assert O.ref() is not None, "oracle/_ref not built (needs /root/reference)"
+rng = np.random.default_rng(20241008)
+out = os.path.join(ROOT, "tests", "golden")
+
+# G2: hclust_fast(AVERAGE) / cutree_k / cutree_cdist / get_medoid
+cases = [c for c in cluster_cases(rng, 54, nmax=28) if len(c[1]) >= 2]
+rec = {}
+for i, (d, lens) in enumerate(cases):
+    n = len(lens)
+    merge, height = O.hclust_average(n, d, which="ref")
+    cd = float(np.median(d)) if d.size else 0.0
+    rec["d%d" % i] = d
+    rec["merge%d" % i] = merge
+    rec["height%d" % i] = height
+    rec["cut_k2_%d" % i] = O.cutree_k(n, merge, 2, which="ref")
+    rec["cut_k3_%d" % i] = O.cutree_k(n, merge, 3, which="ref")
+    rec["cut_c_%d" % i] = O.cutree_cdist(n, merge, height, cd, which="ref")
+    rec["cd%d" % i] = np.array([cd])
+    ind = np.arange(0, n, 2, dtype=np.uint32)
+    rec["medoid%d" % i] = np.array([O.medoid(n, d, ind, which="ref")])
+rec["n_cases"] = np.array([len(cases)])
+np.savez_compressed(os.path.join(out, "hclust_ref.npz"), **rec)
+
+# G1 (KDE part): KDE::f on grid points and KDE::maximas on the normalised densities
+rec = {}
+kc = [c for c in cluster_cases(rng, 36, nmax=20) if c[0].size >= 3]
+for i, (d, lens) in enumerate(kc):
+    h = 0.015 if i % 2 else 0.01
+    xs = np.array([0.0, 0.0025, 0.1, 0.25, 0.5, 0.99999999999998967])
+    rec["d%d" % i] = d
+    rec["h%d" % i] = np.array([h])
+    rec["xs%d" % i] = xs
+    rec["f%d" % i] = np.array([O.kde_f(h, d, float(x), which="ref") for x in xs])
+    _, _, dens = O.find_clustering_dist(d, h)          # oracle densities (same KDE::f formula), fed to the reference's maximas
+    mx, mn = O.kde_maximas(dens, which="ref")
+    rec["dens%d" % i] = dens
+    rec["max_i%d" % i] = np.array([m[0] for m in mx], dtype=np.int32)
+    rec["max_v%d" % i] = np.array([m[1] for m in mx])
+    rec["min_i%d" % i] = np.array([m[0] for m in mn], dtype=np.int32)
+    rec["min_v%d" % i] = np.array([m[1] for m in mn])
+rec["n_cases"] = np.array([len(kc)])
+np.savez_compressed(os.path.join(out, "kde_ref.npz"), **rec)
+
+# G3: PPOA consensus (reference anppoa.hpp) on op strings
+specs = random_poa_specs(rng, O, 40, 5, 160, err=0.08)
+sarena, carena, members, graphs = build_poa_batch(specs)
+cons = O.poa_consensus_batch(sarena, carena, members, graphs, which="ref")
+np.savez_compressed(os.path.join(out, "poa_ref.npz"), sarena=sarena, carena=carena, members=members, graphs=graphs,
+                    cons=np.frombuffer(b"\n".join(cons), dtype=np.uint8))
+print("golden fixtures written to", out)
