@@ -17,6 +17,7 @@
 #include <chrono>
 #include <cmath>
 #include <vector>
+#include <cstdlib>
 
 enum { AL_NONE = 0, AL_COPY = 1, AL_POA = 2 };
 
@@ -561,14 +562,16 @@ __global__ void K_gather(const uint8_t* __restrict__ arena, const AlleleSlot* __
 
 __global__ void K_region_results(const otg_region* __restrict__ regions, uint32_t n_regions, const int32_t* __restrict__ status,
                                  const int32_t* __restrict__ ic, const int32_t* __restrict__ fc, const uint32_t* __restrict__ n_valid,
-                                 const uint64_t* __restrict__ al_idx, const uint32_t* __restrict__ al_flag, otg_region_result* __restrict__ out)
+                                 const uint64_t* __restrict__ al_idx, const uint32_t* __restrict__ al_flag,
+                                 const int32_t* __restrict__ clerr, otg_region_result* __restrict__ out)
 {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n_regions) return;
   otg_region_result o;
   o.status = status[r]; o.ic = 0; o.fc = 0; o.n_valid = (int32_t)n_valid[r]; o.first_allele = 0; o.n_alleles = 0;
+  if (o.status == OTG_REGION_OK && clerr[r]) o.status = OTG_ERR_FATAL;   // otter_find_clustering_dist exit(1) paths, src/otterclust.cpp:39-109
   if (regions[r].n_reads) o.first_allele = (uint32_t)al_idx[regions[r].first_read];
-  if (status[r] == OTG_REGION_OK) {
+  if (o.status == OTG_REGION_OK) {
     o.ic = ic[r]; o.fc = fc[r];
     uint32_t na = 0;
     for (uint32_t i = 0; i < regions[r].n_reads; ++i) na += al_flag[regions[r].first_read + i];
@@ -580,6 +583,14 @@ __global__ void K_region_results(const otg_region* __restrict__ regions, uint32_
 __global__ void K_fill_f64(double* p, size_t n, double v)
 {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+static void dbg(otg_ctx* ctx, const char* what)
+{
+  if (!getenv("OTG_DEBUG")) return;
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  hipError_t e2 = hipGetLastError();
+  fprintf(stderr, "[otg] %s: %s / %s\n", what, hipGetErrorString(e), hipGetErrorString(e2));
 }
 
 struct Timer {
@@ -730,12 +741,14 @@ int otg_assemble_run(otg_ctx* ctx)
     hipLaunchKernelGGL(K_realign_apply, dim3(gr_reads), dim3(TB), 0, st, d_reads, NR, (const uint8_t*)B(B_RKIND), d_cig, d_cig_off, d_cig_len, P.flank, P.min_sim);
     pl->stats.ms_realign = t.ms();
   }
+  dbg(ctx, "realign done");
   // ------------------------------------------------------------------ partition + fill_dist_matrix
   {
     Timer t(ctx);
     hipLaunchKernelGGL(K_region_prepare, dim3(gr_regions), dim3(TB), 0, st, d_reads, d_regions, NG, P.max_cov, P.ignore_haps, d_status, d_nvalid, d_ign, d_valid, d_vpos, d_vlen);
     hipLaunchKernelGGL(K_pair_tasks, dim3(gr_blocks), dim3(64), 0, st, d_arena, d_reads, d_regions, NG, d_nvalid, d_ign, d_valid, (const uint64_t*)B(B_DIST_OFF), P.max_alleles, d_tasks, d_den, d_dist, d_todo, d_cnt + 20);
     float kms = 0; uint64_t kl = 0;
+    dbg(ctx, "pair tasks done");
     rc = otg_launch_edit_todo(ctx, d_arena, d_tasks, d_todo, d_cnt + 20, (uint32_t)pl->n_pair_slots, d_scores, d_cells, &kms, &kl);
     if (rc) return rc;
     pl->stats.ms_edit_kernel += kms; pl->stats.edit_kernel_launches += kl;
@@ -743,6 +756,7 @@ int otg_assemble_run(otg_ctx* ctx)
     hipLaunchKernelGGL(K_stats, dim3(64), dim3(256), 0, st, d_todo, d_cnt + 20, d_tasks, d_cells, d_stats + 0, d_scores, d_cnt + 40);
     pl->stats.ms_edit = t.ms();
   }
+  dbg(ctx, "edit done");
   // ------------------------------------------------------------------ otter_hclust
   {
     Timer t(ctx);
@@ -752,6 +766,7 @@ int otg_assemble_run(otg_ctx* ctx)
     hipLaunchKernelGGL(K_scatter_labels, dim3(gr_reads), dim3(TB), 0, st, d_rr, d_regions, d_vpos, (const int32_t*)B(B_CLLAB), NR, d_labels);
     pl->stats.ms_cluster = t.ms();
   }
+  dbg(ctx, "cluster done");
   // ------------------------------------------------------------------ invalid_reassignment
   {
     Timer t(ctx);
@@ -767,6 +782,7 @@ int otg_assemble_run(otg_ctx* ctx)
                        (const uint64_t*)B(B_RE_OFF), d_redist, P.min_sim, P.max_error, d_labels, d_status);
     pl->stats.ms_reassign = t.ms();
   }
+  dbg(ctx, "reassign done");
   // ------------------------------------------------------------------ rapid_consensus
   std::vector<uint64_t> node_off;
   {
@@ -774,6 +790,7 @@ int otg_assemble_run(otg_ctx* ctx)
     HIP_TRY(ctx, hipMemsetAsync(d_cig_len, 0, (size_t)NR * 4, st));
     HIP_TRY(ctx, hipMemsetAsync(B(B_ALLELES), 0, (size_t)NR * sizeof(AlleleSlot), st));     // slots of reads outside every region stay empty
     HIP_TRY(ctx, hipMemsetAsync(B(B_GRAPHS), 0, (size_t)NR * sizeof(otg_poa_graph), st));
+    HIP_TRY(ctx, hipMemsetAsync(B(B_MEMBERS), 0, (size_t)(NR + 1) * sizeof(otg_poa_member), st));   // unused member slots: empty op strings
     hipLaunchKernelGGL(K_consensus_prepare, dim3((NG + 63) / 64), dim3(64), 0, st, d_reads, d_regions, NG, d_status, d_nvalid, d_ign, d_valid, d_labels,
                        (const int32_t*)B(B_FC), (const uint64_t*)B(B_DIST_OFF), d_dist, d_cig_off, (AlleleSlot*)B(B_ALLELES),
                        (otg_poa_graph*)B(B_GRAPHS), (otg_poa_member*)B(B_MEMBERS), d_tasks, d_todo, d_cnt + 28, (uint32_t*)B(B_SCAN_TMP));
@@ -784,6 +801,7 @@ int otg_assemble_run(otg_ctx* ctx)
     hipLaunchKernelGGL(K_stats, dim3(64), dim3(256), 0, st, d_todo, d_cnt + 28, d_tasks, d_cells, d_stats + 4, d_scores, d_cnt + 41);
     hipLaunchKernelGGL(K_member_cigars, dim3(gr_reads), dim3(TB), 0, st, (otg_poa_member*)B(B_MEMBERS), (const otg_poa_graph*)B(B_GRAPHS), NR, d_cig_len);
     pl->stats.ms_affine = t.ms();
+    dbg(ctx, "affine done");
     Timer t2(ctx);
     std::vector<otg_poa_graph> h_graphs(NR);
     HIP_TRY(ctx, hipMemcpyAsync(h_graphs.data(), B(B_GRAPHS), (size_t)NR * sizeof(otg_poa_graph), hipMemcpyDeviceToHost, st));
@@ -793,6 +811,7 @@ int otg_assemble_run(otg_ctx* ctx)
     if (rc) return rc;
     pl->stats.ms_poa = t2.ms();
   }
+  dbg(ctx, "consensus done");
   // ------------------------------------------------------------------ allele records, compacted in region order
   {
     uint32_t* d_allen = (uint32_t*)B(B_ALLEN);
@@ -816,8 +835,9 @@ int otg_assemble_run(otg_ctx* ctx)
                        d_aloff, d_alidx, d_rr, d_regions, (const int32_t*)B(B_IC), (const uint8_t*)ctx->pool[SLOT_P17].p, d_nodeoff,
                        (const uint32_t*)ctx->pool[SLOT_P29].p, (const uint32_t*)B(B_POALEN), NR, d_outseq, d_outal);
     hipLaunchKernelGGL(K_region_results, dim3(gr_regions), dim3(TB), 0, st, d_regions, NG, d_status, (const int32_t*)B(B_IC), (const int32_t*)B(B_FC), d_nvalid,
-                       d_alidx, d_alflag, (otg_region_result*)B(B_REGRES));
+                       d_alidx, d_alflag, (const int32_t*)B(B_CLERR), (otg_region_result*)B(B_REGRES));
   }
+  dbg(ctx, "gather done");
   HIP_TRY(ctx, hipGetLastError());
   pl->stats.ms_total = total.ms();
   {
