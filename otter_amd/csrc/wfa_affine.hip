@@ -46,8 +46,10 @@ __global__ __launch_bounds__(WPB * 64) void wfa_affine_kernel(
     uint32_t* __restrict__ ticket, uint32_t* __restrict__ n_overflow, uint32_t* __restrict__ overflow_list,
     AffWs ws)
 {
+  constexpr int QCAP = 2048;
   __shared__ int s_lo[WPB][3][64];
   __shared__ int s_hi[WPB][3][64];
+  __shared__ uint16_t s_queue[WPB][QCAP];
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
   uint8_t* my = ws.base + (size_t)(blockIdx.x * WPB + wib) * ws.stride;
@@ -60,6 +62,8 @@ __global__ __launch_bounds__(WPB * 64) void wfa_affine_kernel(
   int* mlo = s_lo[wib][0]; int* mhi = s_hi[wib][0];
   int* ilo = s_lo[wib][1]; int* ihi = s_hi[wib][1];
   int* dlo = s_lo[wib][2]; int* dhi = s_hi[wib][2];
+  using lds_u16 = __attribute__((address_space(3))) uint16_t;
+  volatile lds_u16* queue = (volatile lds_u16*)&s_queue[wib][0];
   const uint32_t n_todo = n_todo_ptr ? *n_todo_ptr : n_todo_imm;
 
   for (;;) {
@@ -74,7 +78,7 @@ __global__ __launch_bounds__(WPB * 64) void wfa_affine_kernel(
     const int pef = t.pattern_end_free, tef = t.text_end_free;
     const int kb = pl + 1; // ring index of diagonal k is k + kb
     const int kend = tl - pl;
-    bool fail = (pl + tl + 3 > ws.capa);
+    bool fail = (pl + tl + 3 > ws.capa) || (pl + tl + 3 > 65535);   // queue entries are 16-bit diagonal indices
     size_t slab_top = 0;
     uint64_t W = 0;
     int s_end = -1, k_end = 0;
@@ -120,7 +124,44 @@ __global__ __launch_bounds__(WPB * 64) void wfa_affine_kernel(
       int32_t* Ic = ringI + (size_t)si * ws.capa;
       int32_t* Dc = ringD + (size_t)si * ws.capa;
       bool done = false;
-      for (int c = lo; c <= hi && !done; c += 64) {
+      int qn = 0;
+      // drain: diagonals whose 8-byte probe matched fully are extended 16 bytes per iteration from a
+      // wave-compacted LDS queue (entries = k - lo), so no lane waits for the slowest diagonal of its chunk
+      auto drain = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        while (qn > 0) {
+          int wq = 0;
+          for (int q0 = 0; q0 < qn; q0 += 64) {
+            const bool act = q0 + lane < qn;
+            int kk = 0, h = 0, v = 0;
+            bool more = false;
+            if (act) {
+              kk = lo + (int)queue[q0 + lane];
+              h = Mc[kk + kb];
+              v = h - kk;
+              uint64_t a0, a1, b0, b1;
+              __builtin_memcpy(&a0, P + v, 8); __builtin_memcpy(&a1, P + v + 8, 8);
+              __builtin_memcpy(&b0, T + h, 8); __builtin_memcpy(&b1, T + h + 8, 8);
+              const uint64_t xl = a0 ^ b0, xh = a1 ^ b1;
+              int m = xl ? (__builtin_ctzll(xl) >> 3) : (xh ? 8 + (__builtin_ctzll(xh) >> 3) : 16);
+              const int rem = imin(pl - v, tl - h);
+              m = imin(m, rem);
+              v += m; h += m;
+              more = (m == 16) && v < pl && h < tl;
+              Mc[kk + kb] = h;
+            }
+            const unsigned long long mm = __ballot(more);
+            if (more) {
+              const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+              queue[wq + rank] = (uint16_t)(kk - lo);
+            }
+            wq += __builtin_popcountll(mm);
+          }
+          qn = wq;
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        }
+      };
+      for (int c = lo; c <= hi; c += 64) {
         const int k = c + lane;
         const int j = k + kb;
         const bool in = k <= hi;
@@ -149,32 +190,47 @@ __global__ __launch_bounds__(WPB * 64) void wfa_affine_kernel(
         }
         int h = mx, v = mx - k;
         const bool valid = in && mx >= 0 && h <= tl && v <= pl;
-        bool act = valid;
-        for (;;) {
-          const bool go = act && v < pl && h < tl;
-          if (!__any(go)) break;
-          if (go) {
-            uint64_t a, b;
-            __builtin_memcpy(&a, P + v, 8);
-            __builtin_memcpy(&b, T + h, 8);
-            const uint64_t xx = a ^ b;
-            int m = xx ? (__builtin_ctzll(xx) >> 3) : 8;
-            const int rem = imin(pl - v, tl - h);
-            m = imin(m, rem);
-            v += m; h += m;
-            act = (m == 8);
-          } else act = false;
+        bool more = false;
+        if (valid && v < pl && h < tl) {
+          uint64_t a, b;
+          __builtin_memcpy(&a, P + v, 8);
+          __builtin_memcpy(&b, T + h, 8);
+          const uint64_t xx = a ^ b;
+          int m = xx ? (__builtin_ctzll(xx) >> 3) : 8;
+          const int rem = imin(pl - v, tl - h);
+          m = imin(m, rem);
+          v += m; h += m;
+          more = (m == 8) && v < pl && h < tl;
         }
         if (in) {
           Mc[j] = valid ? h : OTG_NULL_OFF;
           Ic[j] = ins; Dc[j] = del;
           btrow[k] = (uint8_t)bits;
         }
-        bool fin;
-        if (ef) fin = valid && ((h >= tl && pl - v <= pef) || (v >= pl && tl - h <= tef));
-        else fin = valid && k == kend && h >= tl;
-        const unsigned long long fm = __ballot(fin);
-        if (fm) { done = true; s_end = s; k_end = c + (int)__builtin_ctzll(fm); }
+        const unsigned long long mq = __ballot(more);
+        if (more) {
+          const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mq, 0u));
+          queue[qn + rank] = (uint16_t)(k - lo);
+        }
+        qn += __builtin_popcountll(mq);
+        if (qn + 64 > QCAP) drain();
+      }
+      drain();
+      // termination (the wavefront is fully extended now)
+      if (!ef) {
+        if (kend >= lo && kend <= hi && Mc[kend + kb] >= tl) { done = true; s_end = s; k_end = kend; }
+      } else {
+        for (int c = lo; c <= hi && !done; c += 64) {      // lowest diagonal first (WFA2 scans k ascending)
+          const int k = c + lane;
+          bool fin = false;
+          if (k <= hi) {
+            const int h = Mc[k + kb];
+            const int v = h - k;
+            fin = h >= 0 && ((h >= tl && pl - v <= pef) || (v >= pl && tl - h <= tef));
+          }
+          const unsigned long long fm = __ballot(fin);
+          if (fm) { done = true; s_end = s; k_end = c + (int)__builtin_ctzll(fm); }
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       if (done) break;
@@ -309,7 +365,7 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
   free_b += ctx->pool[SLOT_WF_WS].cap;
   constexpr int WPB = 4;
   // tier 1: many waves, slab sized for ONT-divergence alignments of the batch's longest reads
-  uint32_t want_waves = std::min<uint32_t>((uint32_t)ctx->n_cu * 8, n_tasks);
+  uint32_t want_waves = std::min<uint32_t>((uint32_t)ctx->n_cu * 20, n_tasks);   // 92 VGPRs -> 5 waves / SIMD
   uint32_t grid1 = (want_waves + WPB - 1) / WPB;
   size_t budget = (size_t)(free_b * 0.6);
   size_t slab1 = (size_t)(0.5 * (double)maxlen * (double)maxlen) + (1 << 16);   // ~ (0.7 L)^2 cells

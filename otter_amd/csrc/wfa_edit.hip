@@ -134,6 +134,171 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// v2 kernel (tiers 1 and 2): 16-bit offsets in LDS (requires sequence lengths < 65535), and the extend step
+// split in two so that no lane waits for the slowest diagonal of its chunk:
+//   sweep : per 64-diagonal chunk compute the new offsets (left neighbour by DPP wave_shr, right neighbour
+//           from LDS), probe 8 bytes, store; diagonals whose probe matched fully are appended to a
+//           wave-compacted queue in LDS (ballot + mbcnt);
+//   drain : the queue is re-read 64 entries at a time, 16 bytes are compared per iteration, finished
+//           diagonals drop out, the rest are re-compacted in place.
+// Work per wavefront is then ~Σ(iterations per diagonal) instead of Σ_chunks max(iterations in chunk).
+using lds_u16 = __attribute__((address_space(3))) uint16_t;
+
+__device__ __forceinline__ int dpp_wave_shr1(int x)
+{
+  // lane i receives lane i-1 (lane 0 keeps its own value); GFX9 DPP wave_shr:1
+  return __builtin_amdgcn_update_dpp(x, x, 0x138, 0xf, 0xf, false);
+}
+
+struct u128 { uint64_t lo, hi; };
+__device__ __forceinline__ u128 load16(const uint8_t* p)
+{
+  u128 v;
+  __builtin_memcpy(&v, p, 16);
+  return v;
+}
+
+template <int CAP, int WPB>
+__global__ __launch_bounds__(WPB * 64) void wfa_edit_kernel_v2(
+    const uint8_t* __restrict__ arena, const otg_align_task* __restrict__ tasks,
+    const uint32_t* __restrict__ todo, const uint32_t* __restrict__ n_todo_ptr, uint32_t n_todo_imm,
+    int32_t* __restrict__ scores, uint64_t* __restrict__ cells,
+    uint32_t* __restrict__ ticket, uint32_t* __restrict__ n_overflow, uint32_t* __restrict__ overflow_list)
+{
+  extern __shared__ __attribute__((aligned(16))) int32_t smem[];
+  const int lane = threadIdx.x & 63;
+  const int wib = threadIdx.x >> 6;
+  volatile lds_u16* wf = (volatile lds_u16*)smem + (size_t)wib * 2 * CAP;
+  volatile lds_u16* queue = wf + CAP;
+  const uint32_t n_todo = n_todo_ptr ? *n_todo_ptr : n_todo_imm;
+  constexpr int NUL = 0xFFFF;
+
+  for (;;) {
+    const uint32_t tk = otg_wave_atomic_add(ticket, 1u);
+    if (tk >= n_todo) break;
+    const uint32_t ti = todo ? todo[tk] : tk;
+    const otg_align_task t = tasks[ti];
+    const uint8_t* P = arena + t.pattern_off;
+    const uint8_t* T = arena + t.text_off;
+    const int pl = (int)t.pattern_len, tl = (int)t.text_len;
+    const bool ef = t.endsfree != 0;
+    const int pef = t.pattern_end_free, tef = t.text_end_free;
+    int lo = ef ? -t.pattern_begin_free : 0, hi = ef ? t.text_begin_free : 0;
+    if (lo < -pl) lo = -pl;
+    if (hi > tl) hi = tl;
+    const int kend = tl - pl;
+    const int kbase = lo - ((CAP - (hi - lo + 1)) >> 1);
+    int lo_prev = lo, hi_prev = hi;
+    int s = 0;
+    uint64_t W = 0;
+    bool done = false;
+    bool overflow = (hi - lo + 1 > CAP) || pl >= 65535 || tl >= 65535;
+
+    while (!overflow) {
+      W += (uint64_t)(hi - lo + 1);
+      int carry = OTG_NULL_OFF;
+      bool any_done = false;
+      int qn = 0;
+      // ---- sweep
+      for (int c = lo; c <= hi; c += 64) {
+        const int k = c + lane;
+        const int j = k - kbase;
+        const bool in = k <= hi;
+        int mx;
+        if (s == 0) {
+          mx = k > 0 ? k : 0;
+        } else {
+          int o = OTG_NULL_OFF, r = OTG_NULL_OFF;
+          if (k >= lo_prev && k <= hi_prev) { const int x = wf[j]; o = x == NUL ? OTG_NULL_OFF : x; }
+          if (k + 1 >= lo_prev && k + 1 <= hi_prev) { const int x = wf[j + 1]; r = x == NUL ? OTG_NULL_OFF : x; }
+          int l = dpp_wave_shr1(o);
+          if (lane == 0) l = carry;
+          carry = __builtin_amdgcn_readlane(o, 63);
+          const int a = l + 1, b = o + 1;
+          mx = a > b ? a : b;
+          mx = r > mx ? r : mx;
+        }
+        int h = mx, v = mx - k;
+        const bool valid = in && mx >= 0 && h <= tl && v <= pl;
+        bool more = false;
+        if (valid && v < pl && h < tl) {
+          const uint64_t x = load8(P + v) ^ load8(T + h);
+          int m = x ? (__builtin_ctzll(x) >> 3) : 8;
+          const int rem = pl - v < tl - h ? pl - v : tl - h;
+          m = m < rem ? m : rem;
+          v += m; h += m;
+          more = (m == 8) && v < pl && h < tl;
+        }
+        if (in) wf[j] = (uint16_t)(valid ? h : NUL);
+        const unsigned long long mm = __ballot(more);
+        if (more) {
+          const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+          queue[qn + rank] = (uint16_t)j;
+        }
+        qn += __builtin_popcountll(mm);
+        bool fin;
+        if (ef) fin = valid && !more && ((h >= tl && pl - v <= pef) || (v >= pl && tl - h <= tef));
+        else fin = false;
+        any_done |= __ballot(fin) != 0ull;
+      }
+      // ---- drain
+      while (qn > 0) {
+        int wq = 0;
+        for (int q0 = 0; q0 < qn; q0 += 64) {
+          const bool act = q0 + lane < qn;
+          int j = 0, h = 0, v = 0;
+          bool more = false;
+          if (act) {
+            j = queue[q0 + lane];
+            h = wf[j];
+            v = h - (j + kbase);
+            const u128 a = load16(P + v), b = load16(T + h);
+            const uint64_t xl = a.lo ^ b.lo, xh = a.hi ^ b.hi;
+            int m = xl ? (__builtin_ctzll(xl) >> 3) : (xh ? 8 + (__builtin_ctzll(xh) >> 3) : 16);
+            const int rem = pl - v < tl - h ? pl - v : tl - h;
+            m = m < rem ? m : rem;
+            v += m; h += m;
+            more = (m == 16) && v < pl && h < tl;
+            wf[j] = (uint16_t)h;
+          }
+          const unsigned long long mm = __ballot(more);
+          if (more) {
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+            queue[wq + rank] = (uint16_t)j;
+          }
+          wq += __builtin_popcountll(mm);
+          if (ef) {
+            const bool fin = act && !more && ((h >= tl && pl - v <= pef) || (v >= pl && tl - h <= tef));
+            any_done |= __ballot(fin) != 0ull;
+          }
+        }
+        qn = wq;
+      }
+      if (!ef && kend >= lo && kend <= hi) {
+        const int x = wf[kend - kbase];
+        any_done = (x != NUL && x >= tl);
+      }
+      if (any_done) { done = true; break; }
+      lo_prev = lo; hi_prev = hi;
+      lo = lo - 1 < -pl ? -pl : lo - 1;
+      hi = hi + 1 > tl ? tl : hi + 1;
+      ++s;
+      if (lo - kbase < 0 || hi - kbase + 1 >= CAP) overflow = true;
+      if (s > pl + tl + 2) break;
+    }
+    if (done) {
+      scores[ti] = s;
+      if (cells) cells[ti] = W;
+    } else if (overflow && overflow_list) {
+      const uint32_t q = otg_wave_atomic_add(n_overflow, 1u);
+      overflow_list[q] = ti;
+    } else {
+      scores[ti] = -1;
+    }
+  }
+}
+
 } // namespace
 
 // Enqueue the three capacity tiers.  Requires: d_arena padded with >= 8 readable bytes after the last
@@ -159,25 +324,22 @@ int otg_launch_edit_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_t
   uint32_t* todo3 = todo + n_tasks;  // overflow of tier 2
   if (kernel_ms) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   {
-    constexpr int CAP = 2048, WPB = 4;
-    const size_t lds = (size_t)CAP * WPB * sizeof(int32_t);
+    constexpr int CAP = 2048, WPB = 4;                         // 2 x 2048 x u16 = 8 KB per wave -> 20 waves / CU
+    const size_t lds = (size_t)CAP * 2 * WPB * sizeof(uint16_t);
     uint32_t want = (n_tasks + WPB - 1) / WPB;
     uint32_t grid = (uint32_t)ctx->n_cu * 5;
     if (grid > want) grid = want;
-    hipLaunchKernelGGL((wfa_edit_kernel<CAP, WPB, false>), dim3(grid), dim3(WPB * 64), lds, ctx->stream, d_arena, d_tasks,
-                       d_todo, d_n_todo, n_tasks, d_scores, d_cells, cnt + 0, cnt + 1, todo2,
-                       (int32_t*)nullptr, 0);
+    hipLaunchKernelGGL((wfa_edit_kernel_v2<CAP, WPB>), dim3(grid), dim3(WPB * 64), lds, ctx->stream, d_arena, d_tasks,
+                       d_todo, d_n_todo, n_tasks, d_scores, d_cells, cnt + 0, cnt + 1, todo2);
   }
   if (kernel_ms) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   if (getenv("OTG_DEBUG")) { hipError_t e = hipStreamSynchronize(ctx->stream); fprintf(stderr, "[otg] tier1 done: %s\n", hipGetErrorString(e)); }
   {
-    constexpr int CAP = 16384, WPB = 2;
-    const size_t lds = (size_t)CAP * WPB * sizeof(int32_t);
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*)wfa_edit_kernel<CAP, WPB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    uint32_t grid = (uint32_t)ctx->n_cu;
-    hipLaunchKernelGGL((wfa_edit_kernel<CAP, WPB, false>), dim3(grid), dim3(WPB * 64), lds, ctx->stream, d_arena, d_tasks,
-                       (const uint32_t*)todo2, (const uint32_t*)(cnt + 1), 0u, d_scores, d_cells, cnt + 2, cnt + 3, todo3,
-                       (int32_t*)nullptr, 0);
+    constexpr int CAP = 8192, WPB = 1;                         // 32 KB per wave -> 5 waves / CU, scores up to ~4000
+    const size_t lds = (size_t)CAP * 2 * WPB * sizeof(uint16_t);
+    uint32_t grid = (uint32_t)ctx->n_cu * 5;
+    hipLaunchKernelGGL((wfa_edit_kernel_v2<CAP, WPB>), dim3(grid), dim3(WPB * 64), lds, ctx->stream, d_arena, d_tasks,
+                       (const uint32_t*)todo2, (const uint32_t*)(cnt + 1), 0u, d_scores, d_cells, cnt + 2, cnt + 3, todo3);
   }
   if (getenv("OTG_DEBUG")) { hipError_t e = hipStreamSynchronize(ctx->stream); fprintf(stderr, "[otg] tier2 done: %s\n", hipGetErrorString(e)); }
   {
