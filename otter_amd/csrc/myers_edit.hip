@@ -1,0 +1,242 @@
+// myers_edit.hip — banded bit-parallel edit distance (Myers 1999 / Hyyrö 2003 block formulation), gfx950.
+//
+// Second engine behind otg_edit_distance_batch / the pipeline's distance stages.  Unit-cost edit distance has a
+// unique optimum, so any exact algorithm returns what WFAlignerEdit::getAlignmentScore() returns
+// (reference call sites src/analignments.cpp:70-71,88-97).  The wavefront kernel (wfa_edit.hip) costs O(s^2) and
+// is unbeatable for HiFi-like pairs (s ~ 0..50); for ONT-error reads (s = 0.1..0.4 L) this kernel costs
+// O(n) wave-steps regardless of s.
+//
+// Mapping: one wave64 per pair.  The DP matrix (pattern = rows, text = columns) is cut into 64-row blocks held as
+// vertical-delta bit-vectors (Pv, Mv: 64-bit).  Lane l owns "superblocks" l, l+64, ... (BPL consecutive blocks each)
+// and at time step t processes column j = t - B of its superblock B: the anti-diagonal skew turns the
+// block-to-block carry (hout -> hin) into a one-lane rotate per step (DPP wave_ror).  Only the Ukkonen band
+// -K <= i - j <= K + d (d = m - n >= 0) is evaluated; a superblock enters the band initialised as in Edlib
+// (Pv = ~0, score = score_above + rows) and the block at the top of the band takes hin = +1.  With
+// 2K + d <= 63*64*BPL + 64 a lane has left its superblock before the next one (B + 64) enters the band.
+// The computed score is exact iff it is <= K; otherwise the task is appended to the overflow list and handled
+// by the next tier (more blocks per lane, finally the wavefront kernel).
+// Symbols: A, C, G, T plus at most one further byte value occurring in the pattern (e.g. N); richer alphabets,
+// text-side free ends and patterns > 16384 bytes go to the wavefront kernel.
+#include "otg_common.hpp"
+#include <cstdlib>
+
+namespace {
+
+constexpr int MAXBLK = 256;           // 64-row blocks per pattern held in LDS (m <= 16384)
+using u64 = unsigned long long;
+using lds_u64 = __attribute__((address_space(3))) u64;
+
+__device__ __forceinline__ int dpp_ror1_i(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x13C, 0xf, 0xf, false); }   // lane i <- lane i-1 (wrap)
+
+// W_p of SURVEY.md §8d for a finished alignment with score s (what the wavefront aligner would have evaluated):
+// per score t the diagonals [max(-pbf - t, -m), min(tbf + t, n)].
+__device__ u64 wfa_cells(int s, int m, int n, int pbf, int tbf, int lane)
+{
+  u64 w = 0;
+  for (int t = lane; t <= s; t += 64) {
+    const int lo = -pbf - t < -m ? -m : -pbf - t;
+    const int hi = tbf + t > n ? n : tbf + t;
+    w += (u64)(hi - lo + 1);
+  }
+  for (int off = 32; off > 0; off >>= 1) w += __shfl_xor(w, off);
+  return w;
+}
+
+template <int BPL, int WPB>
+__global__ __launch_bounds__(WPB * 64) void myers_edit_kernel(
+    const uint8_t* __restrict__ arena, const otg_align_task* __restrict__ tasks,
+    const uint32_t* __restrict__ todo, const uint32_t* __restrict__ n_todo_ptr, uint32_t n_todo_imm,
+    int32_t* __restrict__ scores, uint64_t* __restrict__ cells,
+    uint32_t* __restrict__ ticket, uint32_t* __restrict__ n_overflow, uint32_t* __restrict__ overflow_list)
+{
+  __shared__ u64 s_peq[WPB][MAXBLK][5];
+  const int lane = threadIdx.x & 63;
+  const int wib = threadIdx.x >> 6;
+  volatile lds_u64* peq = (volatile lds_u64*)&s_peq[wib][0][0];
+  const uint32_t n_todo = n_todo_ptr ? *n_todo_ptr : n_todo_imm;
+  constexpr int SB = 64 * BPL;
+
+  for (;;) {
+    const uint32_t tk = otg_wave_atomic_add(ticket, 1u);
+    if (tk >= n_todo) break;
+    const uint32_t ti = todo ? todo[tk] : tk;
+    const otg_align_task tsk = tasks[ti];
+    const bool ef = tsk.endsfree != 0;
+    const uint8_t* P = arena + tsk.pattern_off;
+    const uint8_t* T = arena + tsk.text_off;
+    int m = (int)tsk.pattern_len, n = (int)tsk.text_len;
+    int pbf = ef ? tsk.pattern_begin_free : 0, pef = ef ? tsk.pattern_end_free : 0;
+    bool unsupported = ef && (tsk.text_begin_free != 0 || tsk.text_end_free != 0);
+    if (!ef && m < n) { const uint8_t* q = P; P = T; T = q; const int x = m; m = n; n = x; }   // edit distance is symmetric
+    if (m < n) unsupported = true;
+    if (pbf > m) pbf = m;
+    if (pef > m) pef = m;
+    const int d = m - n;
+    const int nblk = (m + 63) >> 6;
+    const int nsb = (m + SB - 1) / SB;
+    const int K = (63 * SB + 64 - d) / 2;
+    if (nblk > MAXBLK || K < d || K < 1 || n < 1 || pbf > d || pef > d) unsupported = true;
+
+    // ---- pattern match masks per 64-row block into LDS: A, C, G, T, X (one further byte value)
+    int other = -1;
+    bool bad_alpha = false;
+    if (!unsupported) {
+      for (int b = lane; b < nblk; b += 64) {
+        u64 ea = 0, ec = 0, eg = 0, et = 0;
+        const int base = b << 6;
+        for (int r = 0; r < 64; ++r) {
+          const int i = base + r;
+          if (i >= m) break;
+          const uint8_t ch = P[i];
+          const u64 bit = 1ull << r;
+          if (ch == 'A') ea |= bit; else if (ch == 'C') ec |= bit; else if (ch == 'G') eg |= bit; else if (ch == 'T') et |= bit;
+          else { if (other < 0) other = ch; else if (other != ch) bad_alpha = true; }
+        }
+        peq[b * 5 + 0] = ea; peq[b * 5 + 1] = ec; peq[b * 5 + 2] = eg; peq[b * 5 + 3] = et;
+      }
+      // agree on the single extra symbol across lanes
+      const u64 has = __ballot(other >= 0);
+      int x = -1;
+      if (has) x = __builtin_amdgcn_readlane(other, (int)__builtin_ctzll(has));
+      if (__ballot(bad_alpha || (other >= 0 && other != x))) unsupported = true;
+      if (!unsupported) {
+        for (int b = lane; b < nblk; b += 64) {
+          u64 ex = 0;
+          if (x >= 0) {
+            const int base = b << 6;
+            for (int r = 0; r < 64; ++r) { const int i = base + r; if (i >= m) break; if (P[i] == (uint8_t)x) ex |= 1ull << r; }
+          }
+          peq[b * 5 + 4] = ex;
+        }
+      }
+      other = x;
+    }
+    if (unsupported) {
+      if (overflow_list) { const uint32_t q = otg_wave_atomic_add(n_overflow, 1u); overflow_list[q] = ti; }
+      else scores[ti] = -1;
+      continue;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+
+    // ---- skewed sweep
+    int B = lane;                       // current superblock of this lane
+    bool inited = false;
+    u64 Pv[BPL], Mv[BPL], EA[BPL], EC[BPL], EG[BPL], ET[BPL], EX[BPL];
+#pragma unroll
+    for (int q = 0; q < BPL; ++q) { Pv[q] = ~0ull; Mv[q] = 0; EA[q] = EC[q] = EG[q] = ET[q] = EX[q] = 0; }
+    int score = 0, hout = 0;
+    int best = 0x3fffffff;
+    const int i_lo = m - pef;           // the answer is min over rows i in [i_lo, m] of D[i][n]
+    if (i_lo <= 0) best = n;            // D[0][n] = n
+    const int t_end = n - 1 + nsb - 1;
+    int cj = -1; uint8_t c_next = 0;      // one-step-ahead text byte (address is known a step early)
+    for (int t = 0; t <= t_end; ++t) {
+      // values of lane-1 after its previous step
+      const int up_score = dpp_ror1_i(score);
+      const int up_hout = dpp_ror1_i(hout);
+      int jlo = SB * B - K - d; if (jlo < 0) jlo = 0;
+      int jhi = SB * B + SB - 1 + K; if (jhi > n - 1) jhi = n - 1;
+      if (B < nsb && t > jhi + B) {     // this superblock left the band: move to the next one owned by the lane
+        B += 64; inited = false;
+        jlo = SB * B - K - d; if (jlo < 0) jlo = 0;
+        jhi = SB * B + SB - 1 + K; if (jhi > n - 1) jhi = n - 1;
+      }
+      const int j = t - B;
+      const bool active = B < nsb && j >= jlo && j <= jhi;
+      if (active) {
+        if (!inited) {
+#pragma unroll
+          for (int q = 0; q < BPL; ++q) {
+            const int b = B * BPL + q;
+            if (b < nblk) { EA[q] = peq[b * 5 + 0]; EC[q] = peq[b * 5 + 1]; EG[q] = peq[b * 5 + 2]; ET[q] = peq[b * 5 + 3]; EX[q] = peq[b * 5 + 4]; }
+            else { EA[q] = EC[q] = EG[q] = ET[q] = EX[q] = 0; }
+            Mv[q] = 0;
+            if (jlo == 0) {
+              // true first column: D[i][0] = max(0, i - pbf)  ->  vertical delta +1 for rows i > pbf
+              const int r0 = b << 6;                       // row i = r0 + bit + 1
+              const int z = pbf - r0;                      // bits [0, z) are 0
+              Pv[q] = z <= 0 ? ~0ull : (z >= 64 ? 0ull : (~0ull << z));
+            } else Pv[q] = ~0ull;
+          }
+          if (jlo == 0) { const int rows = SB * (B + 1); score = rows > pbf ? rows - pbf : 0; }
+          else score = (up_score - up_hout) + SB;
+          inited = true;
+        }
+        const uint8_t c = (cj == j) ? c_next : T[j];
+        if (j + 1 <= jhi) { c_next = T[j + 1]; cj = j + 1; }
+        int hin = (B > 0 && j <= SB * B - 1 + K) ? up_hout : 1;
+#pragma unroll
+        for (int q = 0; q < BPL; ++q) {
+          u64 Eq = c == 'A' ? EA[q] : c == 'C' ? EC[q] : c == 'G' ? EG[q] : c == 'T' ? ET[q] : ((int)c == other ? EX[q] : 0ull);
+          const u64 pv = Pv[q], mv = Mv[q];
+          const u64 hneg = hin < 0 ? 1ull : 0ull;
+          const u64 Xv = Eq | mv;
+          Eq |= hneg;
+          const u64 Xh = (((Eq & pv) + pv) ^ pv) | Eq;
+          u64 Ph = mv | ~(Xh | pv);
+          u64 Mh = pv & Xh;
+          const int ho = (int)(Ph >> 63) - (int)(Mh >> 63);
+          Ph = (Ph << 1) | (hin > 0 ? 1ull : 0ull);
+          Mh = (Mh << 1) | hneg;
+          Pv[q] = Mh | ~(Xv | Ph);
+          Mv[q] = Ph & Xv;
+          hin = ho;
+        }
+        hout = hin;
+        score += hout;
+        if (j == n - 1) {
+          // last column: collect D[i][n] for the rows of this superblock that may end the alignment
+          const int row_top = SB * B;                     // rows row_top+1 .. row_top+SB
+          if (row_top + SB >= i_lo && row_top < m) {
+            int sc = score;
+#pragma unroll
+            for (int q = BPL - 1; q >= 0; --q) {
+              for (int r = 63; r >= 0; --r) {
+                const int i = row_top + 64 * q + r + 1;
+                if (i <= m && i >= i_lo && i >= 1 && sc < best) best = sc;
+                sc -= (int)((Pv[q] >> r) & 1ull) - (int)((Mv[q] >> r) & 1ull);
+              }
+            }
+          }
+        }
+      }
+    }
+    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(best, off); best = o < best ? o : best; }
+    if (best <= K) {
+      scores[ti] = best;
+      if (cells) {
+        const u64 w = wfa_cells(best, (int)tsk.pattern_len, (int)tsk.text_len, ef ? tsk.pattern_begin_free : 0, ef ? tsk.text_begin_free : 0, lane);
+        cells[ti] = w;
+      }
+    } else if (overflow_list) {
+      const uint32_t q = otg_wave_atomic_add(n_overflow, 1u);
+      overflow_list[q] = ti;
+    } else scores[ti] = -1;
+  }
+}
+
+} // namespace
+
+// One tier of the bit-parallel engine: tasks from (d_todo, d_n_todo) (or all n_tasks when d_todo is null);
+// tasks it cannot finish exactly are appended to overflow_list / n_overflow.
+int otg_launch_myers(otg_ctx* ctx, int bpl, const uint8_t* d_arena, const otg_align_task* d_tasks, const uint32_t* d_todo,
+                     const uint32_t* d_n_todo, uint32_t n_tasks, int32_t* d_scores, uint64_t* d_cells,
+                     uint32_t* ticket, uint32_t* n_overflow, uint32_t* overflow_list)
+{
+  constexpr int WPB = 4;
+  uint32_t want = (n_tasks + WPB - 1) / WPB;
+  uint32_t grid = (uint32_t)ctx->n_cu * 3;      // 40 KB LDS per block -> 3-4 blocks per CU
+  if (grid > want) grid = want;
+  if (grid == 0) return OTG_OK;
+  if (bpl == 1)
+    hipLaunchKernelGGL((myers_edit_kernel<1, WPB>), dim3(grid), dim3(WPB * 64), 0, ctx->stream, d_arena, d_tasks, d_todo, d_n_todo, n_tasks,
+                       d_scores, d_cells, ticket, n_overflow, overflow_list);
+  else if (bpl == 2)
+    hipLaunchKernelGGL((myers_edit_kernel<2, WPB>), dim3(grid), dim3(WPB * 64), 0, ctx->stream, d_arena, d_tasks, d_todo, d_n_todo, n_tasks,
+                       d_scores, d_cells, ticket, n_overflow, overflow_list);
+  else
+    hipLaunchKernelGGL((myers_edit_kernel<4, WPB>), dim3(grid), dim3(WPB * 64), 0, ctx->stream, d_arena, d_tasks, d_todo, d_n_todo, n_tasks,
+                       d_scores, d_cells, ticket, n_overflow, overflow_list);
+  HIP_TRY(ctx, hipGetLastError());
+  return OTG_OK;
+}

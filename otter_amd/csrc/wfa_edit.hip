@@ -164,7 +164,8 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_kernel_v2(
     const uint8_t* __restrict__ arena, const otg_align_task* __restrict__ tasks,
     const uint32_t* __restrict__ todo, const uint32_t* __restrict__ n_todo_ptr, uint32_t n_todo_imm,
     int32_t* __restrict__ scores, uint64_t* __restrict__ cells,
-    uint32_t* __restrict__ ticket, uint32_t* __restrict__ n_overflow, uint32_t* __restrict__ overflow_list)
+    uint32_t* __restrict__ ticket, uint32_t* __restrict__ n_overflow, uint32_t* __restrict__ overflow_list,
+    float cap_coeff)
 {
   extern __shared__ __attribute__((aligned(16))) int32_t smem[];
   const int lane = threadIdx.x & 63;
@@ -194,6 +195,14 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_kernel_v2(
     uint64_t W = 0;
     bool done = false;
     bool overflow = (hi - lo + 1 > CAP) || pl >= 65535 || tl >= 65535;
+    // score cap: beyond ~cap_coeff*sqrt(len) the O(n) bit-parallel tier is cheaper than O(s^2) wavefronts
+    int cap = 0x7fffffff;
+    if (cap_coeff > 0.0f) {
+      cap = (int)(cap_coeff * sqrtf((float)(pl > tl ? pl : tl)));
+      if (cap < 48) cap = 48;
+      const int dlen = pl > tl ? pl - tl : tl - pl;
+      if (!ef && dlen > cap) overflow = true;
+    }
 
     while (!overflow) {
       W += (uint64_t)(hi - lo + 1);
@@ -284,7 +293,7 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_kernel_v2(
       lo = lo - 1 < -pl ? -pl : lo - 1;
       hi = hi + 1 > tl ? tl : hi + 1;
       ++s;
-      if (lo - kbase < 0 || hi - kbase + 1 >= CAP) overflow = true;
+      if (lo - kbase < 0 || hi - kbase + 1 >= CAP || s > cap) overflow = true;
       if (s > pl + tl + 2) break;
     }
     if (done) {
@@ -301,7 +310,7 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_kernel_v2(
 
 } // namespace
 
-// Enqueue the three capacity tiers.  Requires: d_arena padded with >= 8 readable bytes after the last
+// Enqueue the tier chain: wavefront tier 1 (LDS, score-capped) -> bit-parallel BPL 1/2/4 -> wavefront tier 2 -> global.  Requires: d_arena padded with >= 8 readable bytes after the last
 // sequence byte.  Uses SLOT_COUNTERS (16 u32), SLOT_TODO (2*n_tasks u32), SLOT_WF_WS (tier 3 only).
 int otg_launch_edit(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_task* d_tasks, uint32_t n_tasks,
                     int32_t* d_scores, uint64_t* d_cells, float* kernel_ms, uint64_t* launches)
@@ -314,14 +323,20 @@ int otg_launch_edit(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_task* 
 int otg_launch_edit_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_task* d_tasks, const uint32_t* d_todo,
                          const uint32_t* d_n_todo, uint32_t n_tasks, int32_t* d_scores, uint64_t* d_cells,
                          float* kernel_ms, uint64_t* launches)
+
 {
   if (n_tasks == 0) return OTG_OK;
   uint32_t* cnt = (uint32_t*)otg_slot(ctx, SLOT_COUNTERS, 64 * sizeof(uint32_t));
-  uint32_t* todo = (uint32_t*)otg_slot(ctx, SLOT_TODO, 2 * (size_t)n_tasks * sizeof(uint32_t));
+  uint32_t* todo = (uint32_t*)otg_slot(ctx, SLOT_TODO, 6 * (size_t)n_tasks * sizeof(uint32_t));
   if (!cnt || !todo) return OTG_ERR_HIP;
-  HIP_TRY(ctx, hipMemsetAsync(cnt, 0, 64 * sizeof(uint32_t), ctx->stream));
-  uint32_t* todo2 = todo;            // overflow of tier 1
-  uint32_t* todo3 = todo + n_tasks;  // overflow of tier 2
+  HIP_TRY(ctx, hipMemsetAsync(cnt, 0, 8 * sizeof(uint32_t), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(cnt + 16, 0, 16 * sizeof(uint32_t), ctx->stream));
+  uint32_t* listA = todo;                 // overflow of WFA tier 1 (score cap / capacity)
+  uint32_t* listB = todo + n_tasks;       // overflow of bit-parallel BPL 1
+  uint32_t* listC = todo + 2 * (size_t)n_tasks;
+  uint32_t* listD = todo + 3 * (size_t)n_tasks;   // what the bit-parallel tiers could not finish
+  uint32_t* listE = todo + 4 * (size_t)n_tasks;   // overflow of WFA tier 2
+  static const bool no_myers = getenv("OTG_NO_MYERS") != nullptr;
   if (kernel_ms) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   {
     constexpr int CAP = 2048, WPB = 4;                         // 2 x 2048 x u16 = 8 KB per wave -> 20 waves / CU
@@ -330,36 +345,43 @@ int otg_launch_edit_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_t
     uint32_t grid = (uint32_t)ctx->n_cu * 5;
     if (grid > want) grid = want;
     hipLaunchKernelGGL((wfa_edit_kernel_v2<CAP, WPB>), dim3(grid), dim3(WPB * 64), lds, ctx->stream, d_arena, d_tasks,
-                       d_todo, d_n_todo, n_tasks, d_scores, d_cells, cnt + 0, cnt + 1, todo2);
+                       d_todo, d_n_todo, n_tasks, d_scores, d_cells, cnt + 0, cnt + 1, listA, no_myers ? 0.0f : 2.0f);
+  }
+  const uint32_t* cur = listA; const uint32_t* cur_n = cnt + 1;
+  if (!no_myers) {
+    int rc = otg_launch_myers(ctx, 1, d_arena, d_tasks, listA, cnt + 1, n_tasks, d_scores, d_cells, cnt + 2, cnt + 3, listB);
+    if (rc) return rc;
+    rc = otg_launch_myers(ctx, 2, d_arena, d_tasks, listB, cnt + 3, n_tasks, d_scores, d_cells, cnt + 4, cnt + 5, listC);
+    if (rc) return rc;
+    rc = otg_launch_myers(ctx, 4, d_arena, d_tasks, listC, cnt + 5, n_tasks, d_scores, d_cells, cnt + 6, cnt + 7, listD);
+    if (rc) return rc;
+    cur = listD; cur_n = cnt + 7;
   }
   if (kernel_ms) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-  if (getenv("OTG_DEBUG")) { hipError_t e = hipStreamSynchronize(ctx->stream); fprintf(stderr, "[otg] tier1 done: %s\n", hipGetErrorString(e)); }
   {
     constexpr int CAP = 8192, WPB = 1;                         // 32 KB per wave -> 5 waves / CU, scores up to ~4000
     const size_t lds = (size_t)CAP * 2 * WPB * sizeof(uint16_t);
     uint32_t grid = (uint32_t)ctx->n_cu * 5;
     hipLaunchKernelGGL((wfa_edit_kernel_v2<CAP, WPB>), dim3(grid), dim3(WPB * 64), lds, ctx->stream, d_arena, d_tasks,
-                       (const uint32_t*)todo2, (const uint32_t*)(cnt + 1), 0u, d_scores, d_cells, cnt + 2, cnt + 3, todo3);
+                       cur, cur_n, 0u, d_scores, d_cells, cnt + 16, cnt + 17, listE, 0.0f);
   }
-  if (getenv("OTG_DEBUG")) { hipError_t e = hipStreamSynchronize(ctx->stream); fprintf(stderr, "[otg] tier2 done: %s\n", hipGetErrorString(e)); }
   {
-    // tier 3: global-memory wavefront sized for the longest possible pair; only reached by huge inputs
+    // last tier: global-memory wavefront sized for the longest possible pair; only reached by huge inputs
     constexpr int WPB = 4;
     uint32_t grid = (uint32_t)ctx->n_cu;
     int gcap = (int)(2 * (size_t)ctx->max_seq_len + 4);
     int32_t* ws = (int32_t*)otg_slot(ctx, SLOT_WF_WS, (size_t)grid * WPB * (size_t)gcap * sizeof(int32_t));
     if (!ws) return OTG_ERR_HIP;
     hipLaunchKernelGGL((wfa_edit_kernel<0, WPB, true>), dim3(grid), dim3(WPB * 64), 0, ctx->stream, d_arena, d_tasks,
-                       (const uint32_t*)todo3, (const uint32_t*)(cnt + 3), 0u, d_scores, d_cells, cnt + 4, cnt + 5,
+                       (const uint32_t*)listE, (const uint32_t*)(cnt + 17), 0u, d_scores, d_cells, cnt + 18, cnt + 19,
                        (uint32_t*)nullptr, ws, gcap);
   }
   HIP_TRY(ctx, hipGetLastError());
   if (getenv("OTG_DEBUG")) {
-    fprintf(stderr, "[otg] edit tiers enqueued (n_tasks=%u)\n", n_tasks);
-    hipError_t e = hipStreamSynchronize(ctx->stream);
-    uint32_t h[8];
+    hipError_t er = hipStreamSynchronize(ctx->stream);
+    uint32_t h[32];
     (void)hipMemcpy(h, cnt, sizeof(h), hipMemcpyDeviceToHost);
-    fprintf(stderr, "[otg] edit sync: %s; tickets %u/%u/%u overflow %u/%u\n", hipGetErrorString(e), h[0], h[2], h[4], h[1], h[3]);
+    fprintf(stderr, "[otg] edit: %s; wfa1 overflow %u, myers1/2/4 overflow %u/%u/%u, wfa2 overflow %u\n", hipGetErrorString(er), h[1], h[3], h[5], h[7], h[17]);
   }
   if (kernel_ms) {
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));

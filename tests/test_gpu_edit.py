@@ -89,3 +89,47 @@ def test_edit_properties_full_size(gpu):
     assert d[4] <= d[1] + d[3]
     assert d[1] >= abs(len(a) - len(b))
     assert 0 < d[5] <= 50
+
+
+def test_edit_bitparallel_tiers(gpu, oracle):
+    """Pairs that leave the score-capped wavefront tier for the banded bit-parallel tiers (1, 2, 4 blocks per lane)
+    and back to the wavefront tiers: large length differences, ends-free forms, N runs, unsupported alphabets."""
+    rng = np.random.default_rng(15)
+    pairs, forms = [], []
+    for i in range(120):
+        L = int(rng.integers(300, 9000))
+        a = mutate(rng, tr_seq(rng, L), 0.07)
+        frac = [0.0, 0.1, 0.3, 0.6][i % 4]
+        cut = int(len(a) * (1 - frac))
+        b = mutate(rng, a[:cut] if i % 2 else a[len(a) - cut:], [0.07, 0.2][(i // 4) % 2])
+        if i % 9 == 0:
+            a = a[:50] + b"N" * 37 + a[50:]
+        if i % 13 == 0:
+            b = b[:20] + b"nnacgt" + b[20:]          # lower case in the text only: matches nothing
+        if i % 17 == 0:
+            a = a[:30] + b"NRY" + a[30:]            # three non-ACGT symbols in the pattern: wavefront fallback
+        f = None
+        if len(b) > len(a):
+            a, b = b, a
+        if i % 3 == 0:
+            d = len(a) - len(b)
+            f = [(0, d, 0, 0), (d, 0, 0, 0), (d // 2, d // 2, 0, 0)][(i // 3) % 3]
+        pairs.append((a, b)); forms.append(f)
+    pairs += [(b"A" * 5000, b"A" * 4000), (b"ACGT" * 1000, b"TGCA" * 900), (rand_seq(rng, 700), rand_seq(rng, 650))]
+    forms += [None, None, None]
+    arena, tasks = pair_tasks(pairs, forms)
+    got, cells = gpu.edit_distance_batch(arena, tasks, want_cells=True)
+    exp, ecells = oracle.edit_distance_batch(arena, tasks, want_cells=True)
+    assert np.array_equal(got, exp)
+    assert np.array_equal(cells, ecells)
+
+
+def test_edit_text_longer_than_pattern(gpu, oracle):
+    rng = np.random.default_rng(16)
+    pairs = []
+    for i in range(40):
+        a = mutate(rng, tr_seq(rng, int(rng.integers(200, 3000))), 0.07)
+        b = mutate(rng, a, 0.1) + rand_seq(rng, int(rng.integers(0, 400)))
+        pairs.append((a, b) if len(a) <= len(b) else (b, a))
+    arena, tasks = pair_tasks(pairs)
+    assert np.array_equal(gpu.edit_distance_batch(arena, tasks), oracle.edit_distance_batch(arena, tasks))
