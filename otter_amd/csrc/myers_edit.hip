@@ -26,6 +26,7 @@ constexpr int MAXBLK = 256;           // 64-row blocks per pattern held in LDS (
 using u64 = unsigned long long;
 using lds_u64 = __attribute__((address_space(3))) u64;
 
+__device__ __forceinline__ u64 load8(const uint8_t* p) { u64 v; __builtin_memcpy(&v, p, 8); return v; }
 __device__ __forceinline__ int dpp_ror1_i(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x13C, 0xf, 0xf, false); }   // lane i <- lane i-1 (wrap)
 
 // W_p of SURVEY.md §8d for a finished alignment with score s (what the wavefront aligner would have evaluated):
@@ -47,12 +48,12 @@ __global__ __launch_bounds__(WPB * 64) void myers_edit_kernel(
     const uint8_t* __restrict__ arena, const otg_align_task* __restrict__ tasks,
     const uint32_t* __restrict__ todo, const uint32_t* __restrict__ n_todo_ptr, uint32_t n_todo_imm,
     int32_t* __restrict__ scores, uint64_t* __restrict__ cells,
-    uint32_t* __restrict__ ticket, uint32_t* __restrict__ n_overflow, uint32_t* __restrict__ overflow_list)
+    uint32_t* __restrict__ ticket, uint32_t* __restrict__ n_overflow, uint32_t* __restrict__ overflow_list, int maxblk)
 {
-  __shared__ u64 s_peq[WPB][MAXBLK][5];
+  extern __shared__ __attribute__((aligned(16))) u64 s_peq[];     // WPB x maxblk x 5
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
-  volatile lds_u64* peq = (volatile lds_u64*)&s_peq[wib][0][0];
+  volatile lds_u64* peq = (volatile lds_u64*)s_peq + (size_t)wib * maxblk * 5;
   const uint32_t n_todo = n_todo_ptr ? *n_todo_ptr : n_todo_imm;
   constexpr int SB = 64 * BPL;
 
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(WPB * 64) void myers_edit_kernel(
     const int nblk = (m + 63) >> 6;
     const int nsb = (m + SB - 1) / SB;
     const int K = (63 * SB + 64 - d) / 2;
-    if (nblk > MAXBLK || K < d || K < 1 || n < 1 || pbf > d || pef > d) unsupported = true;
+    if (nblk > maxblk || K < d || K < 1 || n < 1 || pbf > d || pef > d) unsupported = true;
 
     // ---- pattern match masks per 64-row block into LDS: A, C, G, T, X (one further byte value)
     int other = -1;
@@ -129,21 +130,43 @@ __global__ __launch_bounds__(WPB * 64) void myers_edit_kernel(
     const int i_lo = m - pef;           // the answer is min over rows i in [i_lo, m] of D[i][n]
     if (i_lo <= 0) best = n;            // D[0][n] = n
     const int t_end = n - 1 + nsb - 1;
-    int cj = -1; uint8_t c_next = 0;      // one-step-ahead text byte (address is known a step early)
+    // per-superblock time window (recomputed only when the lane moves to its next superblock)
+    int t_start, t_stop, t_hin_stop, t_last; bool exact_init;
+    auto setup = [&]() {
+      int jlo = SB * B - K - d; if (jlo < 0) jlo = 0;
+      int jhi = SB * B + SB - 1 + K; if (jhi > n - 1) jhi = n - 1;
+      exact_init = (jlo == 0);
+      if (B < nsb && jlo <= jhi) {
+        t_start = jlo + B; t_stop = jhi + B;
+        int jh = SB * B - 1 + K; if (jh > jhi) jh = jhi;
+        t_hin_stop = B > 0 ? jh + B : -1;              // block above still inside the band
+        t_last = (jhi == n - 1) ? n - 1 + B : -1;
+      } else { t_start = 0x7fffffff; t_stop = B < nsb ? -1 : 0x7ffffffe; t_hin_stop = -1; t_last = -1; }
+    };
+    setup();
+    // text bytes: one unaligned 8-byte load per 8 steps and lane (prefetched 4 steps ahead); byte (t & 7) of c8
+    // is column (t & ~7) - B + (t & 7) = t - B
+    auto load_group = [&](int tg) -> u64 {              // tg = first step of the group
+      int a = tg - B;
+      if (a > n - 1) a = n - 1;
+      if (a >= 0) return load8(T + a);
+      const int sh = -a;
+      return sh < 8 ? (load8(T) << (8 * sh)) : 0ull;
+    };
+    u64 c8 = load_group(0), c8n = 0;
     for (int t = 0; t <= t_end; ++t) {
       // values of lane-1 after its previous step
       const int up_score = dpp_ror1_i(score);
       const int up_hout = dpp_ror1_i(hout);
-      int jlo = SB * B - K - d; if (jlo < 0) jlo = 0;
-      int jhi = SB * B + SB - 1 + K; if (jhi > n - 1) jhi = n - 1;
-      if (B < nsb && t > jhi + B) {     // this superblock left the band: move to the next one owned by the lane
-        B += 64; inited = false;
-        jlo = SB * B - K - d; if (jlo < 0) jlo = 0;
-        jhi = SB * B + SB - 1 + K; if (jhi > n - 1) jhi = n - 1;
+      const int ph = t & 7;
+      if (t > t_stop) {                 // this superblock left the band: move to the next one owned by the lane
+        B += 64; inited = false; setup();
+        c8 = load_group(t - ph);
+        if (ph >= 4) c8n = load_group(t - ph + 8);
       }
-      const int j = t - B;
-      const bool active = B < nsb && j >= jlo && j <= jhi;
-      if (active) {
+      if (ph == 4) c8n = load_group(t + 4);
+      else if (ph == 0 && t > 0) c8 = c8n;
+      if (t >= t_start && t <= t_stop) {
         if (!inited) {
 #pragma unroll
           for (int q = 0; q < BPL; ++q) {
@@ -151,23 +174,28 @@ __global__ __launch_bounds__(WPB * 64) void myers_edit_kernel(
             if (b < nblk) { EA[q] = peq[b * 5 + 0]; EC[q] = peq[b * 5 + 1]; EG[q] = peq[b * 5 + 2]; ET[q] = peq[b * 5 + 3]; EX[q] = peq[b * 5 + 4]; }
             else { EA[q] = EC[q] = EG[q] = ET[q] = EX[q] = 0; }
             Mv[q] = 0;
-            if (jlo == 0) {
+            if (exact_init) {
               // true first column: D[i][0] = max(0, i - pbf)  ->  vertical delta +1 for rows i > pbf
               const int r0 = b << 6;                       // row i = r0 + bit + 1
               const int z = pbf - r0;                      // bits [0, z) are 0
               Pv[q] = z <= 0 ? ~0ull : (z >= 64 ? 0ull : (~0ull << z));
             } else Pv[q] = ~0ull;
           }
-          if (jlo == 0) { const int rows = SB * (B + 1); score = rows > pbf ? rows - pbf : 0; }
+          if (exact_init) { const int rows = SB * (B + 1); score = rows > pbf ? rows - pbf : 0; }
           else score = (up_score - up_hout) + SB;
           inited = true;
         }
-        const uint8_t c = (cj == j) ? c_next : T[j];
-        if (j + 1 <= jhi) { c_next = T[j + 1]; cj = j + 1; }
-        int hin = (B > 0 && j <= SB * B - 1 + K) ? up_hout : 1;
+        const uint32_t c = (uint32_t)(c8 >> (8 * ph)) & 0xffu;
+        const uint32_t code = (c >> 1) & 3u;                               // A C T G -> 0 1 2 3
+        const bool is_acgt = c == ((0x47544341u >> (8 * code)) & 0xffu);
+        const bool is_x = (int)c == other;
+        int hin = t <= t_hin_stop ? up_hout : 1;
 #pragma unroll
         for (int q = 0; q < BPL; ++q) {
-          u64 Eq = c == 'A' ? EA[q] : c == 'C' ? EC[q] : c == 'G' ? EG[q] : c == 'T' ? ET[q] : ((int)c == other ? EX[q] : 0ull);
+          const u64 e01 = (code & 1u) ? EC[q] : EA[q];
+          const u64 e23 = (code & 1u) ? EG[q] : ET[q];
+          u64 Eq = (code & 2u) ? e23 : e01;
+          Eq = is_acgt ? Eq : (is_x ? EX[q] : 0ull);
           const u64 pv = Pv[q], mv = Mv[q];
           const u64 hneg = hin < 0 ? 1ull : 0ull;
           const u64 Xv = Eq | mv;
@@ -184,17 +212,19 @@ __global__ __launch_bounds__(WPB * 64) void myers_edit_kernel(
         }
         hout = hin;
         score += hout;
-        if (j == n - 1) {
+        if (t == t_last) {
           // last column: collect D[i][n] for the rows of this superblock that may end the alignment
           const int row_top = SB * B;                     // rows row_top+1 .. row_top+SB
           if (row_top + SB >= i_lo && row_top < m) {
             int sc = score;
 #pragma unroll
             for (int q = BPL - 1; q >= 0; --q) {
+              const u64 pv = Pv[q], mv = Mv[q];
+#pragma unroll 1
               for (int r = 63; r >= 0; --r) {
                 const int i = row_top + 64 * q + r + 1;
                 if (i <= m && i >= i_lo && i >= 1 && sc < best) best = sc;
-                sc -= (int)((Pv[q] >> r) & 1ull) - (int)((Mv[q] >> r) & 1ull);
+                sc -= (int)((pv >> r) & 1ull) - (int)((mv >> r) & 1ull);
               }
             }
           }
@@ -224,19 +254,25 @@ int otg_launch_myers(otg_ctx* ctx, int bpl, const uint8_t* d_arena, const otg_al
                      uint32_t* ticket, uint32_t* n_overflow, uint32_t* overflow_list)
 {
   constexpr int WPB = 4;
+  int maxblk = (int)((ctx->max_seq_len + 63) / 64) + 1;
+  if (maxblk > MAXBLK) maxblk = MAXBLK;
+  const size_t lds = (size_t)WPB * maxblk * 5 * sizeof(u64);
   uint32_t want = (n_tasks + WPB - 1) / WPB;
-  uint32_t grid = (uint32_t)ctx->n_cu * 3;      // 40 KB LDS per block -> 3-4 blocks per CU
+  uint32_t per_cu = (uint32_t)(160 * 1024 / (lds + 512));
+  if (per_cu > 8) per_cu = 8;
+  if (per_cu < 1) per_cu = 1;
+  uint32_t grid = (uint32_t)ctx->n_cu * per_cu;
   if (grid > want) grid = want;
   if (grid == 0) return OTG_OK;
   if (bpl == 1)
-    hipLaunchKernelGGL((myers_edit_kernel<1, WPB>), dim3(grid), dim3(WPB * 64), 0, ctx->stream, d_arena, d_tasks, d_todo, d_n_todo, n_tasks,
-                       d_scores, d_cells, ticket, n_overflow, overflow_list);
+    hipLaunchKernelGGL((myers_edit_kernel<1, WPB>), dim3(grid), dim3(WPB * 64), lds, ctx->stream, d_arena, d_tasks, d_todo, d_n_todo, n_tasks,
+                       d_scores, d_cells, ticket, n_overflow, overflow_list, maxblk);
   else if (bpl == 2)
-    hipLaunchKernelGGL((myers_edit_kernel<2, WPB>), dim3(grid), dim3(WPB * 64), 0, ctx->stream, d_arena, d_tasks, d_todo, d_n_todo, n_tasks,
-                       d_scores, d_cells, ticket, n_overflow, overflow_list);
+    hipLaunchKernelGGL((myers_edit_kernel<2, WPB>), dim3(grid), dim3(WPB * 64), lds, ctx->stream, d_arena, d_tasks, d_todo, d_n_todo, n_tasks,
+                       d_scores, d_cells, ticket, n_overflow, overflow_list, maxblk);
   else
-    hipLaunchKernelGGL((myers_edit_kernel<4, WPB>), dim3(grid), dim3(WPB * 64), 0, ctx->stream, d_arena, d_tasks, d_todo, d_n_todo, n_tasks,
-                       d_scores, d_cells, ticket, n_overflow, overflow_list);
+    hipLaunchKernelGGL((myers_edit_kernel<4, WPB>), dim3(grid), dim3(WPB * 64), lds, ctx->stream, d_arena, d_tasks, d_todo, d_n_todo, n_tasks,
+                       d_scores, d_cells, ticket, n_overflow, overflow_list, maxblk);
   HIP_TRY(ctx, hipGetLastError());
   return OTG_OK;
 }
