@@ -77,6 +77,43 @@ __device__ __forceinline__ uint32_t otg_wave_atomic_add(uint32_t* ctr, uint32_t 
       : "memory");
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
 }
+
+// ---- match-run extension helpers shared by the wavefront kernels -------------------------------------
+__device__ __forceinline__ uint64_t otg_load8(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+
+// Lane-private: number of equal leading bytes of P+v.. and T+h.., looking at most 64 bytes ahead and at most `rem`.
+// Eight independent 8-byte loads per operand are issued back to back (one latency, not eight).
+__device__ __forceinline__ int otg_match64(const uint8_t* P, const uint8_t* T, int v, int h, int rem)
+{
+  uint64_t x[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) x[i] = (8 * i < rem) ? (otg_load8(P + v + 8 * i) ^ otg_load8(T + h + 8 * i)) : ~0ull;
+  int m = 64;
+#pragma unroll
+  for (int i = 7; i >= 0; --i) if (x[i]) m = 8 * i + (__builtin_ctzll(x[i]) >> 3);
+  return m < rem ? m : rem;
+}
+
+// Wave-cooperative (all arguments wave-uniform): extends ONE diagonal, 64 lanes x 8 bytes = 512 bytes per iteration.
+__device__ __forceinline__ int otg_wave_match(const uint8_t* P, const uint8_t* T, int v, int h, int rem, int lane)
+{
+  int total = 0;
+  while (total < rem) {
+    const int off = total + lane * 8;
+    const bool in = off < rem;
+    uint64_t x = ~0ull;
+    if (in) x = otg_load8(P + v + off) ^ otg_load8(T + h + off);
+    const int m = x ? (int)(__builtin_ctzll(x) >> 3) : 8;
+    const unsigned long long stop = __ballot(m < 8);          // lanes beyond `rem` report a mismatch at byte 0
+    if (stop) {
+      const int first = (int)__builtin_ctzll(stop);
+      total += first * 8 + __builtin_amdgcn_readlane(m, first);
+      break;
+    }
+    total += 512;
+  }
+  return total < rem ? total : rem;
+}
 #endif
 
 // ---- device-resident launch helpers implemented in the .hip files -------------------------------------

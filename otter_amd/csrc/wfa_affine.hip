@@ -19,6 +19,7 @@
 // device for tier 2 (few waves, large slabs).
 #include "otg_common.hpp"
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -35,6 +36,77 @@ struct AffWs {
 
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+
+// Walks the provenance back from (s_end, k_end) and unpacks the op string (shared by both forward kernels).
+// Uniform control flow: every lane follows the same path and stores the same bytes.
+__device__ bool backtrace_unpack(const uint8_t* P, int pl, const uint8_t* T, int tl, int s_end, int k_end, int xs, int oes, int es,
+                                 const int64_t* rowtab, const uint8_t* slab, uint8_t* rev, size_t rev_cap, uint8_t* out, int lane,
+                                 int32_t* score_out, uint32_t* len_out, int g)
+{
+  uint32_t nrev = 0;
+  int k0;
+  {
+    int s = s_end, k = k_end, comp = 0;
+    while (s > 0 || comp != 0) {
+      const int64_t rb = rowtab[s];
+      const uint32_t bits = slab[rb + k];
+      uint8_t op;
+      if (comp == 0) {
+        const uint32_t org = bits & 3u;
+        if (org == 0) { op = 'X'; s -= xs; }
+        else if (org == 1) { op = 'c'; comp = 2; }
+        else { op = 'c'; comp = 1; }
+      } else if (comp == 1) {
+        op = 'I';
+        if (bits & 4u) s -= es; else { s -= oes; comp = 0; }
+        k -= 1;
+      } else {
+        op = 'D';
+        if (bits & 8u) s -= es; else { s -= oes; comp = 0; }
+        k += 1;
+      }
+      if (nrev >= rev_cap || s < 0) { *score_out = -2; *len_out = 0; return false; }
+      rev[nrev] = op;
+      ++nrev;
+    }
+    k0 = k;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  uint32_t pos = 0;
+  int h = k0 > 0 ? k0 : 0, v = k0 < 0 ? -k0 : 0;
+  for (int q = lane; q < h; q += 64) out[q] = 'I';
+  pos += h;
+  for (int q = lane; q < v; q += 64) out[pos + q] = 'D';
+  pos += v;
+  auto emit_matches = [&]() {
+    for (;;) {
+      const int rem = imin(pl - v, tl - h);
+      if (rem <= 0) break;
+      const int n = rem < 64 ? rem : 64;
+      const bool eq = lane < n && P[v + lane] == T[h + lane];
+      const unsigned long long ne = ~__ballot(eq);
+      const int m = ne ? (int)__builtin_ctzll(ne) : 64;
+      if (lane < m) out[pos + lane] = 'M';
+      v += m; h += m; pos += m;
+      if (m < 64) break;
+    }
+  };
+  int state = 0;
+  for (int q = (int)nrev - 1; q >= 0; --q) {
+    if (state == 0) emit_matches();
+    const uint8_t op = rev[q];
+    if (op == 'I') { out[pos] = 'I'; ++pos; ++h; state = 1; }
+    else if (op == 'D') { out[pos] = 'D'; ++pos; ++v; state = 2; }
+    else if (op == 'c') { state = 0; }
+    else { out[pos] = 'X'; ++pos; ++v; ++h; }
+  }
+  emit_matches();
+  { const int n = tl - h; for (int q = lane; q < n; q += 64) out[pos + q] = 'I'; if (n > 0) { pos += n; h = tl; } }
+  { const int n = pl - v; for (int q = lane; q < n; q += 64) out[pos + q] = 'D'; if (n > 0) { pos += n; v = pl; } }
+  *score_out = s_end * g;
+  *len_out = pos;
+  return true;
+}
 
 template <int WPB>
 __global__ __launch_bounds__(WPB * 64) void wfa_affine_kernel(
@@ -242,77 +314,286 @@ __global__ __launch_bounds__(WPB * 64) void wfa_affine_kernel(
       continue;
     }
 
-    // ---------------- backtrace (uniform walk; every lane follows the same path, lane 0 records)
-    uint32_t nrev = 0;
-    int k0;
-    {
-      int s = s_end, k = k_end, comp = 0;
-      bool bt_fail = false;
-      while (s > 0 || comp != 0) {
-        const int64_t rb = rowtab[s];
-        const uint32_t bits = slab[rb + k];
-        uint8_t op;
-        if (comp == 0) {
-          const uint32_t org = bits & 3u;
-          if (org == 0) { op = 'X'; s -= xs; }
-          else if (org == 1) { op = 'c'; comp = 2; }
-          else { op = 'c'; comp = 1; }
-        } else if (comp == 1) {
-          op = 'I';
-          if (bits & 4u) s -= es; else { s -= oes; comp = 0; }
-          k -= 1;
-        } else {
-          op = 'D';
-          if (bits & 8u) s -= es; else { s -= oes; comp = 0; }
-          k += 1;
-        }
-        if (nrev >= ws.rev_cap || s < 0) { bt_fail = true; break; }
-        rev[nrev] = op; /* every lane stores the same byte: keeps the walk free of divergent branches */
-        ++nrev;
+    if (!backtrace_unpack(P, pl, T, tl, s_end, k_end, xs, oes, es, rowtab, slab, rev, ws.rev_cap, cig_arena + cig_off[ti], lane, &scores[ti], &cig_len[ti], g)) continue;
+    if (cells) cells[ti] = W;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// v3 forward kernel (tier 1, gap-extension step 1 after gcd reduction, sequences < 65535):
+//   * I and D wavefronts live in LDS as 16-bit offsets and are updated IN PLACE (I[s][k] needs I[s-1][k-1]:
+//     left neighbour by DPP wave_shr + carry; D[s][k] needs D[s-1][k+1]: the right neighbour is still old in
+//     an ascending sweep);
+//   * the M ring (max(x,o+e)/g + 1 rows) stays in HBM/L2 but as 16-bit rows, the next chunk's three M
+//     operands are prefetched while the current chunk is processed;
+//   * per 64-diagonal chunk the HBM traffic drops from ~2.1 KB (five int32 row reads, three row writes) to
+//     ~0.5 KB (two u16 row reads, one u16 row write, 64 provenance bytes).
+// Same provenance bytes, row table, backtrace and unpack as the generic kernel below (its tier 2).
+using lds_u16 = __attribute__((address_space(3))) uint16_t;
+
+__device__ __forceinline__ int dpp_shr1(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int u16_to_off(uint32_t x) { return x == 0xFFFFu ? OTG_NULL_OFF : (int)x; }
+
+template <int CAP, int QCAP>
+__global__ __launch_bounds__(64) void wfa_affine_kernel_v3(
+    const uint8_t* __restrict__ arena, const otg_align_task* __restrict__ tasks,
+    const uint32_t* __restrict__ todo, const uint32_t* __restrict__ n_todo_ptr, uint32_t n_todo_imm,
+    int xs, int oes, int es, int g,
+    int32_t* __restrict__ scores, const uint64_t* __restrict__ cig_off, uint32_t* __restrict__ cig_len,
+    uint8_t* __restrict__ cig_arena, uint64_t* __restrict__ cells,
+    uint32_t* __restrict__ ticket, uint32_t* __restrict__ n_overflow, uint32_t* __restrict__ overflow_list,
+    AffWs ws)
+{
+  __shared__ uint16_t s_I[CAP];
+  __shared__ uint16_t s_D[CAP];
+  __shared__ uint16_t s_q[QCAP];
+  __shared__ int s_mlo[64];
+  __shared__ int s_mhi[64];
+  const int lane = threadIdx.x & 63;
+  volatile lds_u16* LI = (volatile lds_u16*)&s_I[0];
+  volatile lds_u16* LD = (volatile lds_u16*)&s_D[0];
+  volatile lds_u16* queue = (volatile lds_u16*)&s_q[0];
+  uint8_t* my = ws.base + (size_t)blockIdx.x * ws.stride;
+  uint16_t* ringM = (uint16_t*)my;
+  int64_t* rowtab = (int64_t*)(my + ws.off_rowtab);
+  uint8_t* rev = my + ws.off_rev;
+  uint8_t* slab = my + ws.off_slab;
+  const uint32_t n_todo = n_todo_ptr ? *n_todo_ptr : n_todo_imm;
+
+  for (;;) {
+    const uint32_t tk = otg_wave_atomic_add(ticket, 1u);
+    if (tk >= n_todo) break;
+    const uint32_t ti = todo ? todo[tk] : tk;
+    const otg_align_task t = tasks[ti];
+    const uint8_t* P = arena + t.pattern_off;
+    const uint8_t* T = arena + t.text_off;
+    const int pl = (int)t.pattern_len, tl = (int)t.text_len;
+    const bool ef = t.endsfree != 0;
+    const int pef = t.pattern_end_free, tef = t.text_end_free;
+    const int kb = pl + 1;
+    const int kend = tl - pl;
+    bool fail = (pl + tl + 3 > ws.capa) || pl >= 65535 || tl >= 65535 || es != 1;
+    size_t slab_top = 0;
+    uint64_t W = 0;
+    int s_end = -1, k_end = 0;
+    int idlo = 1, idhi = 0;                       // range of the I/D wavefronts of the previous score (null)
+    int kbase = 0;
+
+    for (int s = 0; !fail; ++s) {
+      if (s >= ws.nrows) { fail = true; break; }
+      const int sm = s % ws.rm;
+      int lo, hi;
+      const uint16_t *Mx = nullptr, *Mo = nullptr;
+      int mxlo = 1, mxhi = 0, molo = 1, mohi = 0;
+      if (s == 0) {
+        lo = ef ? imax(-t.pattern_begin_free, -pl) : 0;
+        hi = ef ? imin(t.text_begin_free, tl) : 0;
+        kbase = lo - ((CAP - (hi - lo + 1)) >> 1);
+        if (hi - lo + 3 > CAP) { fail = true; break; }
+      } else {
+        lo = 1 << 30; hi = -(1 << 30);
+        if (s - xs >= 0) { const int q = (s - xs) % ws.rm; mxlo = s_mlo[q]; mxhi = s_mhi[q]; Mx = ringM + (size_t)q * ws.capa; }
+        if (s - oes >= 0) { const int q = (s - oes) % ws.rm; molo = s_mlo[q]; mohi = s_mhi[q]; Mo = ringM + (size_t)q * ws.capa; }
+        if (mxhi >= mxlo) { lo = imin(lo, mxlo); hi = imax(hi, mxhi); }
+        if (mohi >= molo) { lo = imin(lo, molo - 1); hi = imax(hi, mohi + 1); }
+        if (idhi >= idlo) { lo = imin(lo, idlo + 1); hi = imax(hi, idhi + 1); lo = imin(lo, idlo - 1); hi = imax(hi, idhi - 1); }
+        if (lo < -pl) lo = -pl;
+        if (hi > tl) hi = tl;
       }
-      k0 = k;
-      if (bt_fail) {
-        scores[ti] = -2; cig_len[ti] = 0;
+      if (hi < lo) {   // null wavefront
+        s_mlo[sm] = 1; s_mhi[sm] = 0; rowtab[s] = -1; idlo = 1; idhi = 0;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        if (s > 2 * (oes + es * (pl + tl)) + 8) fail = true;
         continue;
       }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-
-    // ---------------- forward unpack
-    uint8_t* out = cig_arena + cig_off[ti];
-    uint32_t pos = 0;
-    int h = k0 > 0 ? k0 : 0, v = k0 < 0 ? -k0 : 0;
-    for (int q = lane; q < h; q += 64) out[q] = 'I';
-    pos += h;
-    for (int q = lane; q < v; q += 64) out[pos + q] = 'D';
-    pos += v;
-    auto emit_matches = [&]() {
-      for (;;) {
-        const int rem = imin(pl - v, tl - h);
-        if (rem <= 0) break;
-        const int n = rem < 64 ? rem : 64;
-        const bool eq = lane < n && P[v + lane] == T[h + lane];
-        const unsigned long long ne = ~__ballot(eq);
-        const int m = ne ? (int)__builtin_ctzll(ne) : 64;
-        if (lane < m) out[pos + lane] = 'M';
-        v += m; h += m; pos += m;
-        if (m < 64) break;
+      if (lo - kbase < 1 || hi - kbase + 2 >= CAP) { fail = true; break; }       // LDS window exhausted -> tier 2
+      const int width = hi - lo + 1;
+      if (slab_top + (size_t)width > ws.slab_bytes) { fail = true; break; }
+      uint8_t* btrow = slab + slab_top - lo;
+      rowtab[s] = (int64_t)slab_top - lo; s_mlo[sm] = lo; s_mhi[sm] = hi;
+      slab_top += (size_t)width;
+      W += 3ull * (uint64_t)width;
+      uint16_t* Mc = ringM + (size_t)sm * ws.capa;
+      bool done = false;
+      int qn = 0;
+      // drain: queued diagonals (probe matched all 8 bytes).  Pass 1 looks 16 bytes ahead; survivors are in long
+      // match runs: 64 bytes per pass, and once <= 4 diagonals remain the whole wave extends them one at a time
+      // (512 bytes per iteration) — TR reads have exact runs of hundreds of bases.
+      auto drain = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        int pass = 0;
+        while (qn > 0) {
+          if (qn <= 4 && pass > 0) {
+            for (int e = 0; e < qn; ++e) {
+              const int kk = lo + (int)queue[e];
+              int h = Mc[kk + kb];
+              int v = h - kk;
+              const int m = otg_wave_match(P, T, v, h, imin(pl - v, tl - h), lane);
+              Mc[kk + kb] = (uint16_t)(h + m);
+            }
+            qn = 0;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            break;
+          }
+          int wq = 0;
+          for (int q0 = 0; q0 < qn; q0 += 64) {
+            const bool act = q0 + lane < qn;
+            int kk = 0, h = 0, v = 0;
+            bool more = false;
+            if (act) {
+              kk = lo + (int)queue[q0 + lane];
+              h = Mc[kk + kb];
+              v = h - kk;
+              const int rem = imin(pl - v, tl - h);
+              int m, full;
+              if (pass == 0) {
+                const uint64_t xl = otg_load8(P + v) ^ otg_load8(T + h), xh = otg_load8(P + v + 8) ^ otg_load8(T + h + 8);
+                m = xl ? (__builtin_ctzll(xl) >> 3) : (xh ? 8 + (__builtin_ctzll(xh) >> 3) : 16);
+                m = imin(m, rem); full = 16;
+              } else { m = otg_match64(P, T, v, h, rem); full = 64; }
+              v += m; h += m;
+              more = (m == full) && v < pl && h < tl;
+              Mc[kk + kb] = (uint16_t)h;
+            }
+            const unsigned long long mm = __ballot(more);
+            if (more) {
+              const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+              queue[wq + rank] = (uint16_t)(kk - lo);
+            }
+            wq += __builtin_popcountll(mm);
+          }
+          qn = wq; ++pass;
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        }
+      };
+      // unconditional, index-clamped loads (no branches -> the compiler can keep several of them in flight
+      // with counted vmcnt waits); out-of-range lanes are nulled by a select afterwards
+      const uint16_t* MoP = Mo ? Mo : ringM;
+      const uint16_t* MxP = Mx ? Mx : ringM;
+      // raw 32-bit words (two adjacent 16-bit offsets) are queued untouched: any conversion right after the
+      // load would force a wait for it
+      auto load_m = [&](int c, uint32_t& w0, uint32_t& w1) {
+        const int jc = imin(imax(c + lane + kb, 0), ws.capa - 2);
+        __builtin_memcpy(&w0, MoP + jc, 4);      // Mo[k], Mo[k+1]
+        __builtin_memcpy(&w1, MxP + jc, 4);      // Mx[k] (low half)
+      };
+      // M-ring operands are prefetched PF chunks ahead through a rotating register queue (the ring rows of
+      // ~2000 resident waves do not fit L2: loaded latency is several chunk-times)
+      constexpr int PF = 4;
+      uint32_t q_w0[PF], q_w1[PF];
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        q_w0[u] = q_w1[u] = 0xFFFFFFFFu;
+        load_m(lo + 64 * u, q_w0[u], q_w1[u]);
       }
-    };
-    int state = 0;
-    for (int q = (int)nrev - 1; q >= 0; --q) {
-      if (state == 0) emit_matches();
-      const uint8_t op = rev[q];
-      if (op == 'I') { out[pos] = 'I'; ++pos; ++h; state = 1; }
-      else if (op == 'D') { out[pos] = 'D'; ++pos; ++v; state = 2; }
-      else if (op == 'c') { state = 0; }
-      else { out[pos] = 'X'; ++pos; ++v; ++h; }
+      int carryI = OTG_NULL_OFF, carryMo = OTG_NULL_OFF;
+      // software pipeline: the 8-byte sequence probe of chunk c is issued in iteration c and consumed in
+      // iteration c+1, so its latency overlaps the LDS/compute work of the next chunk
+      bool p_pending = false, p_in = false, p_valid = false, p_probe = false;
+      int p_k = 0, p_h = 0, p_v = 0;
+      uint64_t p_a = 0, p_b = 0;
+      auto finish = [&]() {
+        int h = p_h, v = p_v;
+        bool more = false;
+        if (p_probe) {
+          const uint64_t xx = p_a ^ p_b;
+          int m = xx ? (__builtin_ctzll(xx) >> 3) : 8;
+          const int rem = imin(pl - v, tl - h);
+          m = imin(m, rem);
+          v += m; h += m;
+          more = (m == 8) && v < pl && h < tl;
+        }
+        if (p_in) Mc[p_k + kb] = (uint16_t)(p_valid ? h : 0xFFFF);
+        const unsigned long long mq = __ballot(more);
+        if (more) {
+          const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mq, 0u));
+          queue[qn + rank] = (uint16_t)(p_k - lo);
+        }
+        qn += __builtin_popcountll(mq);
+      };
+      for (int c = lo; c <= hi; c += 64) {
+        const int k = c + lane;
+        const int jl = k - kbase;
+        const bool in = k <= hi;
+        int mx, ins = OTG_NULL_OFF, del = OTG_NULL_OFF;
+        uint32_t bits = 0;
+        {
+          const uint32_t w0 = q_w0[0], w1 = q_w1[0];
+#pragma unroll
+          for (int u = 0; u + 1 < PF; ++u) { q_w0[u] = q_w0[u + 1]; q_w1[u] = q_w1[u + 1]; }
+          load_m(c + 64 * PF, q_w0[PF - 1], q_w1[PF - 1]);      // clamped address: always legal
+          const int mo = (Mo && k >= molo && k <= mohi) ? u16_to_off(w0 & 0xFFFFu) : OTG_NULL_OFF;
+          const int mor = (Mo && k + 1 >= molo && k + 1 <= mohi) ? u16_to_off(w0 >> 16) : OTG_NULL_OFF;
+          const int mm = (Mx && k >= mxlo && k <= mxhi) ? u16_to_off(w1 & 0xFFFFu) : OTG_NULL_OFF;
+          const int iold = (k >= idlo && k <= idhi) ? u16_to_off(LI[jl]) : OTG_NULL_OFF;          // I[s-1][k]
+          const int dx = (k + 1 >= idlo && k + 1 <= idhi) ? u16_to_off(LD[jl + 1]) : OTG_NULL_OFF; // D[s-1][k+1]
+          int ix = dpp_shr1(iold);                                                                 // I[s-1][k-1]
+          if (lane == 0) ix = carryI;
+          carryI = __builtin_amdgcn_readlane(iold, 63);
+          int io = dpp_shr1(mo);                                                                   // M[s-o-e][k-1]
+          if (lane == 0) io = carryMo;
+          carryMo = __builtin_amdgcn_readlane(mo, 63);
+          const int dop = mor;                                                                     // M[s-o-e][k+1]
+          if (ix >= io) { ins = ix; bits |= 4u; } else ins = io;
+          ins += 1;
+          if (dx >= dop) { del = dx; bits |= 8u; } else del = dop;
+          const int mis = mm + 1;
+          mx = imax(del, imax(mis, ins));
+          uint32_t org = 0;
+          if (mx == ins) org = 2;
+          if (mx == del) org = 1;
+          if (mx == mis) org = 0;
+          bits |= org;
+          if (ins < 0) ins = OTG_NULL_OFF;
+          if (del < 0) del = OTG_NULL_OFF;
+          if (s == 0) { mx = k > 0 ? k : 0; ins = OTG_NULL_OFF; del = OTG_NULL_OFF; bits = 0; }   // selects, not a branch
+        }
+        const int h = mx, v = mx - k;
+        const bool valid = in && mx >= 0 && h <= tl && v <= pl;
+        const bool probe = valid && v < pl && h < tl;
+        // retire the previous chunk first: its probe was issued one iteration ago, only this iteration's two
+        // prefetch loads are younger, so the wait is a counted vmcnt and not a drain
+        if (p_pending) finish();
+        uint64_t a, b;
+        { const int vc = imin(imax(v, 0), pl), hc = imin(imax(h, 0), tl);      // clamped: always inside arena + slack
+          __builtin_memcpy(&a, P + vc, 8); __builtin_memcpy(&b, T + hc, 8); }
+        if (in) {
+          // offsets beyond the sequence ends cannot lead to a valid cell any more (they only grow): store them as null
+          LI[jl] = (uint16_t)((ins < 0 || ins > 65534) ? 0xFFFF : ins);
+          LD[jl] = (uint16_t)((del < 0 || del > 65534) ? 0xFFFF : del);
+          btrow[k] = (uint8_t)bits;
+        }
+        p_pending = true; p_in = in; p_valid = valid; p_probe = probe; p_k = k; p_h = h; p_v = v; p_a = a; p_b = b;
+        if (qn + 128 > QCAP) { finish(); p_pending = false; drain(); }
+      }
+      if (p_pending) finish();
+      drain();
+      idlo = s == 0 ? 1 : lo; idhi = s == 0 ? 0 : hi;
+      if (!ef) {
+        if (kend >= lo && kend <= hi) { const int x = u16_to_off(Mc[kend + kb]); if (x >= tl) { done = true; s_end = s; k_end = kend; } }
+      } else {
+        for (int c = lo; c <= hi && !done; c += 64) {
+          const int k = c + lane;
+          bool fin = false;
+          if (k <= hi) {
+            const int h = u16_to_off(Mc[k + kb]);
+            const int v = h - k;
+            fin = h >= 0 && ((h >= tl && pl - v <= pef) || (v >= pl && tl - h <= tef));
+          }
+          const unsigned long long fm = __ballot(fin);
+          if (fm) { done = true; s_end = s; k_end = c + (int)__builtin_ctzll(fm); }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      if (done) break;
     }
-    emit_matches();
-    { const int n = tl - h; for (int q = lane; q < n; q += 64) out[pos + q] = 'I'; if (n > 0) { pos += n; h = tl; } }
-    { const int n = pl - v; for (int q = lane; q < n; q += 64) out[pos + q] = 'D'; if (n > 0) { pos += n; v = pl; } }
-    scores[ti] = s_end * g;
-    cig_len[ti] = pos;
+
+    if (fail || s_end < 0) {
+      if (overflow_list) { const uint32_t q = otg_wave_atomic_add(n_overflow, 1u); overflow_list[q] = ti; }
+      else { scores[ti] = -1; cig_len[ti] = 0; }
+      continue;
+    }
+    if (!backtrace_unpack(P, pl, T, tl, s_end, k_end, xs, oes, es, rowtab, slab, rev, ws.rev_cap, cig_arena + cig_off[ti], lane, &scores[ti], &cig_len[ti], g)) continue;
     if (cells) cells[ti] = W;
   }
 }
@@ -345,7 +626,7 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
   uint32_t* cnt = (uint32_t*)otg_slot(ctx, SLOT_COUNTERS, 64 * sizeof(uint32_t));
   uint32_t* todo = (uint32_t*)otg_slot(ctx, SLOT_TODO, 2 * (size_t)n_tasks * sizeof(uint32_t));
   if (!cnt || !todo) return OTG_ERR_HIP;
-  HIP_TRY(ctx, hipMemsetAsync(cnt + 8, 0, 8 * sizeof(uint32_t), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(cnt + 8, 0, 8 * sizeof(uint32_t), ctx->stream));   // tickets / overflow counters of the three tiers
 
   const size_t maxlen = ctx->max_seq_len;
   AffWs ws;
@@ -361,41 +642,52 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
 
   size_t free_b = 0, total_b = 0;
   HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
-  // reuse what SLOT_WF_WS already holds
-  free_b += ctx->pool[SLOT_WF_WS].cap;
-  constexpr int WPB = 4;
-  // tier 1: many waves, slab sized for ONT-divergence alignments of the batch's longest reads
-  uint32_t want_waves = std::min<uint32_t>((uint32_t)ctx->n_cu * 20, n_tasks);   // 92 VGPRs -> 5 waves / SIMD
-  uint32_t grid1 = (want_waves + WPB - 1) / WPB;
-  size_t budget = (size_t)(free_b * 0.6);
-  size_t slab1 = (size_t)(0.5 * (double)maxlen * (double)maxlen) + (1 << 16);   // ~ (0.7 L)^2 cells
+  free_b += ctx->pool[SLOT_WF_WS].cap;       // what SLOT_WF_WS already holds is reusable
+  const size_t budget = (size_t)(free_b * 0.6);
+  // slab sized for ONT-divergence alignments of the batch's longest reads: ~ (0.7 L)^2 provenance bytes
+  size_t slab1 = (size_t)(0.5 * (double)maxlen * (double)maxlen) + (1 << 16);
   if (slab1 > ((size_t)96 << 20)) slab1 = (size_t)96 << 20;
-  while (grid1 > 1 && (ws.off_slab + slab1) * (size_t)grid1 * WPB > budget) {
-    if (slab1 > ((size_t)4 << 20)) slab1 /= 2; else grid1 = (grid1 + 1) / 2;
-  }
-  ws.slab_bytes = slab1 & ~(size_t)255;
-  ws.stride = ws.off_slab + ws.slab_bytes;
-  size_t need1 = ws.stride * (size_t)grid1 * WPB;
-  // tier 2: few waves, slab = worst case useful size
-  AffWs ws2 = ws;
-  uint32_t grid2 = 8;
-  size_t slab2 = std::min<size_t>((size_t)2 * maxlen * (size_t)(ws.nrows) , budget / (grid2 * WPB));
-  if (slab2 > ws.off_slab + 256) slab2 -= ws.off_slab + 256;
-  ws2.slab_bytes = slab2 & ~(size_t)255;
-  ws2.stride = ws2.off_slab + ws2.slab_bytes;
-  size_t need2 = ws2.stride * (size_t)grid2 * WPB;
-  uint8_t* wsp = (uint8_t*)otg_slot(ctx, SLOT_WF_WS, std::max(need1, need2));
+  auto fit = [&](uint32_t& nwaves, size_t& slab) {
+    while (nwaves > 1 && (ws.off_slab + slab) * (size_t)nwaves > budget) {
+      if (slab > ((size_t)4 << 20)) slab /= 2; else nwaves = (nwaves + 1) / 2;
+    }
+  };
+  // tier A: v3, LDS window 4096 diagonals, 7 single-wave blocks per CU
+  AffWs wsA = ws; uint32_t wavesA = std::min<uint32_t>((uint32_t)ctx->n_cu * 7, n_tasks); size_t slabA = slab1;
+  fit(wavesA, slabA);
+  wsA.slab_bytes = slabA & ~(size_t)255; wsA.stride = wsA.off_slab + wsA.slab_bytes;
+  // tier B: v3, LDS window 12288 diagonals, 3 blocks per CU
+  AffWs wsB = ws; uint32_t wavesB = (uint32_t)ctx->n_cu * 3; size_t slabB = slab1;
+  fit(wavesB, slabB);
+  wsB.slab_bytes = slabB & ~(size_t)255; wsB.stride = wsB.off_slab + wsB.slab_bytes;
+  // tier C: generic kernel (global int32 rings), few waves with the largest useful slabs
+  constexpr int WPB = 4;
+  AffWs wsC = ws; uint32_t gridC = 8;
+  size_t slabC = std::min<size_t>((size_t)2 * maxlen * (size_t)(ws.nrows), budget / (gridC * WPB));
+  if (slabC > ws.off_slab + 256) slabC -= ws.off_slab + 256;
+  wsC.slab_bytes = slabC & ~(size_t)255; wsC.stride = wsC.off_slab + wsC.slab_bytes;
+  const size_t need = std::max(std::max(wsA.stride * wavesA, wsB.stride * wavesB), wsC.stride * (size_t)gridC * WPB);
+  uint8_t* wsp = (uint8_t*)otg_slot(ctx, SLOT_WF_WS, need);
   if (!wsp) return OTG_ERR_HIP;
-  ws.base = wsp; ws2.base = wsp;
-
+  wsA.base = wsB.base = wsC.base = wsp;
+  uint32_t* listA = todo;                  // overflow of tier A
+  uint32_t* listB = todo + n_tasks;        // overflow of tier B
+  static const bool no_v3 = getenv("OTG_NO_AFFINE_V3") != nullptr;
   if (kernel_ms) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  hipLaunchKernelGGL((wfa_affine_kernel<WPB>), dim3(grid1), dim3(WPB * 64), 0, ctx->stream, d_arena, d_tasks,
-                     d_todo, d_n_todo, n_tasks, xs, oes, es, g, d_scores, d_cig_off, d_cig_len,
-                     d_cig_arena, d_cells, cnt + 8, cnt + 9, todo, ws);
+  const uint32_t* cur = d_todo; const uint32_t* cur_n = d_n_todo; uint32_t cur_imm = n_tasks;
+  if (!no_v3 && es == 1) {
+    hipLaunchKernelGGL((wfa_affine_kernel_v3<4096, 2048>), dim3(wavesA), dim3(64), 0, ctx->stream, d_arena, d_tasks,
+                       d_todo, d_n_todo, n_tasks, xs, oes, es, g, d_scores, d_cig_off, d_cig_len,
+                       d_cig_arena, d_cells, cnt + 8, cnt + 9, listA, wsA);
+    hipLaunchKernelGGL((wfa_affine_kernel_v3<12288, 2048>), dim3(wavesB), dim3(64), 0, ctx->stream, d_arena, d_tasks,
+                       (const uint32_t*)listA, (const uint32_t*)(cnt + 9), 0u, xs, oes, es, g, d_scores, d_cig_off, d_cig_len,
+                       d_cig_arena, d_cells, cnt + 10, cnt + 11, listB, wsB);
+    cur = listB; cur_n = cnt + 11; cur_imm = 0;
+  }
   if (kernel_ms) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-  hipLaunchKernelGGL((wfa_affine_kernel<WPB>), dim3(grid2), dim3(WPB * 64), 0, ctx->stream, d_arena, d_tasks,
-                     (const uint32_t*)todo, (const uint32_t*)(cnt + 9), 0u, xs, oes, es, g, d_scores, d_cig_off, d_cig_len,
-                     d_cig_arena, d_cells, cnt + 10, cnt + 11, (uint32_t*)nullptr, ws2);
+  hipLaunchKernelGGL((wfa_affine_kernel<WPB>), dim3(gridC), dim3(WPB * 64), 0, ctx->stream, d_arena, d_tasks,
+                     cur, cur_n, cur_imm, xs, oes, es, g, d_scores, d_cig_off, d_cig_len,
+                     d_cig_arena, d_cells, cnt + 12, cnt + 13, (uint32_t*)nullptr, wsC);
   HIP_TRY(ctx, hipGetLastError());
   if (kernel_ms) {
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));

@@ -251,8 +251,24 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_kernel_v2(
         else fin = false;
         any_done |= __ballot(fin) != 0ull;
       }
-      // ---- drain
+      // ---- drain: 16 bytes in the first pass, then 64 bytes per pass; when <= 4 diagonals are left the whole
+      // wave extends them one at a time, 512 bytes per iteration (HiFi / TR reads: exact runs of hundreds of bases)
+      int pass = 0;
       while (qn > 0) {
+        if (qn <= 4 && pass > 0) {
+          for (int q = 0; q < qn; ++q) {
+            const int j = queue[q];
+            int h = wf[j];
+            int v = h - (j + kbase);
+            const int rem = pl - v < tl - h ? pl - v : tl - h;
+            const int m = otg_wave_match(P, T, v, h, rem, lane);
+            h += m; v += m;
+            wf[j] = (uint16_t)h;
+            if (ef && ((h >= tl && pl - v <= pef) || (v >= pl && tl - h <= tef))) any_done = true;
+          }
+          qn = 0;
+          break;
+        }
         int wq = 0;
         for (int q0 = 0; q0 < qn; q0 += 64) {
           const bool act = q0 + lane < qn;
@@ -262,13 +278,16 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_kernel_v2(
             j = queue[q0 + lane];
             h = wf[j];
             v = h - (j + kbase);
-            const u128 a = load16(P + v), b = load16(T + h);
-            const uint64_t xl = a.lo ^ b.lo, xh = a.hi ^ b.hi;
-            int m = xl ? (__builtin_ctzll(xl) >> 3) : (xh ? 8 + (__builtin_ctzll(xh) >> 3) : 16);
             const int rem = pl - v < tl - h ? pl - v : tl - h;
-            m = m < rem ? m : rem;
+            int m, full;
+            if (pass == 0) {
+              const u128 a = load16(P + v), b = load16(T + h);
+              const uint64_t xl = a.lo ^ b.lo, xh = a.hi ^ b.hi;
+              m = xl ? (__builtin_ctzll(xl) >> 3) : (xh ? 8 + (__builtin_ctzll(xh) >> 3) : 16);
+              m = m < rem ? m : rem; full = 16;
+            } else { m = otg_match64(P, T, v, h, rem); full = 64; }
             v += m; h += m;
-            more = (m == 16) && v < pl && h < tl;
+            more = (m == full) && v < pl && h < tl;
             wf[j] = (uint16_t)h;
           }
           const unsigned long long mm = __ballot(more);
@@ -282,7 +301,7 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_kernel_v2(
             any_done |= __ballot(fin) != 0ull;
           }
         }
-        qn = wq;
+        qn = wq; ++pass;
       }
       if (!ef && kend >= lo && kend <= hi) {
         const int x = wf[kend - kbase];

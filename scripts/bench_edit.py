@@ -1,7 +1,9 @@
 """Micro-benchmark of the L1 batched aligners on config-2-like pairs (ONT, 1-5 kb)."""
 import sys, time
 import numpy as np
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import otter_amd
 from otter_amd import abi, synth
 
