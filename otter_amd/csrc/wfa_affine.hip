@@ -320,19 +320,23 @@ __global__ __launch_bounds__(WPB * 64) void wfa_affine_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------
-// v3 forward kernel (tier 1, gap-extension step 1 after gcd reduction, sequences < 65535):
-//   * I and D wavefronts live in LDS as 16-bit offsets and are updated IN PLACE (I[s][k] needs I[s-1][k-1]:
-//     left neighbour by DPP wave_shr + carry; D[s][k] needs D[s-1][k+1]: the right neighbour is still old in
-//     an ascending sweep);
-//   * the M ring (max(x,o+e)/g + 1 rows) stays in HBM/L2 but as 16-bit rows, the next chunk's three M
-//     operands are prefetched while the current chunk is processed;
+// v3 forward kernel (tier 1; gap-extension step 1 after gcd reduction, sequences < 32767):
+//   * I and D wavefronts live in LDS as SIGNED 16-bit offsets (null = any negative value) and are updated
+//     IN PLACE (I[s][k] needs I[s-1][k-1]: left neighbour by DPP wave_shr + carry; D[s][k] needs D[s-1][k+1]:
+//     the right neighbour is still old in an ascending sweep);
+//   * the M ring (max(x,o+e)/g + 1 rows) stays in HBM/L2 as signed 16-bit rows; rows and the LDS arrays are
+//     null-filled once per task and ranges only grow, so there are NO per-lane range predicates: whatever lies
+//     outside a row's range reads as null; an unreachable score maps to a permanently null row;
+//   * operands are software-pipelined: M-ring words 4 chunks ahead (raw dwords, sign-extended on use), LDS
+//     words and the 8-byte sequence probe 1 chunk ahead, so every wait in the sweep is a counted one;
 //   * per 64-diagonal chunk the HBM traffic drops from ~2.1 KB (five int32 row reads, three row writes) to
-//     ~0.5 KB (two u16 row reads, one u16 row write, 64 provenance bytes).
-// Same provenance bytes, row table, backtrace and unpack as the generic kernel below (its tier 2).
+//     ~0.7 KB (two dword row reads, one 16-bit row write, 64 provenance bytes).
+// Same provenance bytes, row table, backtrace and unpack as the generic kernel (its last tier).
+using lds_i16 = __attribute__((address_space(3))) int16_t;
 using lds_u16 = __attribute__((address_space(3))) uint16_t;
+using lds_u32 = __attribute__((address_space(3))) uint32_t;
 
 __device__ __forceinline__ int dpp_shr1(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x138, 0xf, 0xf, false); }
-__device__ __forceinline__ int u16_to_off(uint32_t x) { return x == 0xFFFFu ? OTG_NULL_OFF : (int)x; }
 
 template <int CAP, int QCAP>
 __global__ __launch_bounds__(64) void wfa_affine_kernel_v3(
@@ -344,21 +348,23 @@ __global__ __launch_bounds__(64) void wfa_affine_kernel_v3(
     uint32_t* __restrict__ ticket, uint32_t* __restrict__ n_overflow, uint32_t* __restrict__ overflow_list,
     AffWs ws)
 {
-  __shared__ uint16_t s_I[CAP];
-  __shared__ uint16_t s_D[CAP];
+  __shared__ __attribute__((aligned(16))) int16_t s_I[CAP];
+  __shared__ __attribute__((aligned(16))) int16_t s_D[CAP];
   __shared__ uint16_t s_q[QCAP];
   __shared__ int s_mlo[64];
   __shared__ int s_mhi[64];
   const int lane = threadIdx.x & 63;
-  volatile lds_u16* LI = (volatile lds_u16*)&s_I[0];
-  volatile lds_u16* LD = (volatile lds_u16*)&s_D[0];
+  volatile lds_i16* LI = (volatile lds_i16*)&s_I[0];
+  volatile lds_i16* LD = (volatile lds_i16*)&s_D[0];
   volatile lds_u16* queue = (volatile lds_u16*)&s_q[0];
   uint8_t* my = ws.base + (size_t)blockIdx.x * ws.stride;
-  uint16_t* ringM = (uint16_t*)my;
+  int16_t* ringM = (int16_t*)my;                          // rm rows + one permanently null row
+  int16_t* nullrow = ringM + (size_t)ws.rm * ws.capa;
   int64_t* rowtab = (int64_t*)(my + ws.off_rowtab);
   uint8_t* rev = my + ws.off_rev;
   uint8_t* slab = my + ws.off_slab;
   const uint32_t n_todo = n_todo_ptr ? *n_todo_ptr : n_todo_imm;
+  constexpr int NUL16 = -32768;
 
   for (;;) {
     const uint32_t tk = otg_wave_atomic_add(ticket, 1u);
@@ -370,50 +376,61 @@ __global__ __launch_bounds__(64) void wfa_affine_kernel_v3(
     const int pl = (int)t.pattern_len, tl = (int)t.text_len;
     const bool ef = t.endsfree != 0;
     const int pef = t.pattern_end_free, tef = t.text_end_free;
-    const int kb = pl + 1;
+    const int kb = pl + 4;                        // ring index of diagonal k (4 entries of slack on the left)
     const int kend = tl - pl;
-    bool fail = (pl + tl + 3 > ws.capa) || pl >= 65535 || tl >= 65535 || es != 1;
+    bool fail = (pl + tl + 12 > ws.capa) || pl >= 32766 || tl >= 32766 || es != 1;
     size_t slab_top = 0;
     uint64_t W = 0;
     int s_end = -1, k_end = 0;
     int idlo = 1, idhi = 0;                       // range of the I/D wavefronts of the previous score (null)
     int kbase = 0;
+    if (!fail) {
+      // null-fill: LDS I/D arrays, the ring rows this task can touch, the null row
+      volatile lds_u32* li32 = (volatile lds_u32*)&s_I[0];
+      volatile lds_u32* ld32 = (volatile lds_u32*)&s_D[0];
+      for (int q = lane; q < CAP / 2; q += 64) { li32[q] = 0x80008000u; ld32[q] = 0x80008000u; }
+      const int nfill = (pl + tl + 12 + 1) / 2;   // dwords per row
+      uint32_t* r32 = (uint32_t*)ringM;
+      const int row_dw = ws.capa / 2;
+      for (int r = 0; r <= ws.rm; ++r) for (int q = lane; q < nfill; q += 64) r32[(size_t)r * row_dw + q] = 0x80008000u;
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    }
 
     for (int s = 0; !fail; ++s) {
       if (s >= ws.nrows) { fail = true; break; }
       const int sm = s % ws.rm;
       int lo, hi;
-      const uint16_t *Mx = nullptr, *Mo = nullptr;
+      const int16_t *MxP = nullrow, *MoP = nullrow;
       int mxlo = 1, mxhi = 0, molo = 1, mohi = 0;
       if (s == 0) {
         lo = ef ? imax(-t.pattern_begin_free, -pl) : 0;
         hi = ef ? imin(t.text_begin_free, tl) : 0;
         kbase = lo - ((CAP - (hi - lo + 1)) >> 1);
-        if (hi - lo + 3 > CAP) { fail = true; break; }
+        if (hi - lo + 140 > CAP) { fail = true; break; }
       } else {
         lo = 1 << 30; hi = -(1 << 30);
-        if (s - xs >= 0) { const int q = (s - xs) % ws.rm; mxlo = s_mlo[q]; mxhi = s_mhi[q]; Mx = ringM + (size_t)q * ws.capa; }
-        if (s - oes >= 0) { const int q = (s - oes) % ws.rm; molo = s_mlo[q]; mohi = s_mhi[q]; Mo = ringM + (size_t)q * ws.capa; }
+        if (s - xs >= 0) { const int q = (s - xs) % ws.rm; mxlo = s_mlo[q]; mxhi = s_mhi[q]; if (mxhi >= mxlo) MxP = ringM + (size_t)q * ws.capa; }
+        if (s - oes >= 0) { const int q = (s - oes) % ws.rm; molo = s_mlo[q]; mohi = s_mhi[q]; if (mohi >= molo) MoP = ringM + (size_t)q * ws.capa; }
         if (mxhi >= mxlo) { lo = imin(lo, mxlo); hi = imax(hi, mxhi); }
         if (mohi >= molo) { lo = imin(lo, molo - 1); hi = imax(hi, mohi + 1); }
-        if (idhi >= idlo) { lo = imin(lo, idlo + 1); hi = imax(hi, idhi + 1); lo = imin(lo, idlo - 1); hi = imax(hi, idhi - 1); }
+        if (idhi >= idlo) { lo = imin(lo, idlo - 1); hi = imax(hi, idhi + 1); }
         if (lo < -pl) lo = -pl;
         if (hi > tl) hi = tl;
       }
-      if (hi < lo) {   // null wavefront
+      if (hi < lo) {   // null wavefront (I/D of the previous score are null too, see header)
         s_mlo[sm] = 1; s_mhi[sm] = 0; rowtab[s] = -1; idlo = 1; idhi = 0;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         if (s > 2 * (oes + es * (pl + tl)) + 8) fail = true;
         continue;
       }
-      if (lo - kbase < 1 || hi - kbase + 2 >= CAP) { fail = true; break; }       // LDS window exhausted -> tier 2
+      if (lo - kbase < 2 || hi - kbase + 132 >= CAP) { fail = true; break; }     // LDS window exhausted -> next tier
       const int width = hi - lo + 1;
       if (slab_top + (size_t)width > ws.slab_bytes) { fail = true; break; }
       uint8_t* btrow = slab + slab_top - lo;
       rowtab[s] = (int64_t)slab_top - lo; s_mlo[sm] = lo; s_mhi[sm] = hi;
       slab_top += (size_t)width;
       W += 3ull * (uint64_t)width;
-      uint16_t* Mc = ringM + (size_t)sm * ws.capa;
+      int16_t* Mc = ringM + (size_t)sm * ws.capa;
       bool done = false;
       int qn = 0;
       // drain: queued diagonals (probe matched all 8 bytes).  Pass 1 looks 16 bytes ahead; survivors are in long
@@ -426,10 +443,10 @@ __global__ __launch_bounds__(64) void wfa_affine_kernel_v3(
           if (qn <= 4 && pass > 0) {
             for (int e = 0; e < qn; ++e) {
               const int kk = lo + (int)queue[e];
-              int h = Mc[kk + kb];
-              int v = h - kk;
+              const int h = Mc[kk + kb];
+              const int v = h - kk;
               const int m = otg_wave_match(P, T, v, h, imin(pl - v, tl - h), lane);
-              Mc[kk + kb] = (uint16_t)(h + m);
+              Mc[kk + kb] = (int16_t)(h + m);
             }
             qn = 0;
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -453,7 +470,7 @@ __global__ __launch_bounds__(64) void wfa_affine_kernel_v3(
               } else { m = otg_match64(P, T, v, h, rem); full = 64; }
               v += m; h += m;
               more = (m == full) && v < pl && h < tl;
-              Mc[kk + kb] = (uint16_t)h;
+              Mc[kk + kb] = (int16_t)h;
             }
             const unsigned long long mm = __ballot(more);
             if (more) {
@@ -466,27 +483,21 @@ __global__ __launch_bounds__(64) void wfa_affine_kernel_v3(
           __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         }
       };
-      // unconditional, index-clamped loads (no branches -> the compiler can keep several of them in flight
-      // with counted vmcnt waits); out-of-range lanes are nulled by a select afterwards
-      const uint16_t* MoP = Mo ? Mo : ringM;
-      const uint16_t* MxP = Mx ? Mx : ringM;
       // raw 32-bit words (two adjacent 16-bit offsets) are queued untouched: any conversion right after the
-      // load would force a wait for it
+      // load would force a wait for it.  Index k + kb - 1 .. : w0 = {Mo[k-1] | Mo[k]} is not used; we load
+      // {Mo[k], Mo[k+1]} and take Mo[k-1] from the left lane (DPP) like the reference recurrence needs.
       auto load_m = [&](int c, uint32_t& w0, uint32_t& w1) {
-        const int jc = imin(imax(c + lane + kb, 0), ws.capa - 2);
+        const int jc = imin(c + lane + kb, ws.capa - 2);
         __builtin_memcpy(&w0, MoP + jc, 4);      // Mo[k], Mo[k+1]
         __builtin_memcpy(&w1, MxP + jc, 4);      // Mx[k] (low half)
       };
-      // M-ring operands are prefetched PF chunks ahead through a rotating register queue (the ring rows of
-      // ~2000 resident waves do not fit L2: loaded latency is several chunk-times)
       constexpr int PF = 4;
       uint32_t q_w0[PF], q_w1[PF];
 #pragma unroll
-      for (int u = 0; u < PF; ++u) {
-        q_w0[u] = q_w1[u] = 0xFFFFFFFFu;
-        load_m(lo + 64 * u, q_w0[u], q_w1[u]);
-      }
-      int carryI = OTG_NULL_OFF, carryMo = OTG_NULL_OFF;
+      for (int u = 0; u < PF; ++u) load_m(lo + 64 * u, q_w0[u], q_w1[u]);
+      // LDS operands one chunk ahead (the current chunk only overwrites its own 64 entries)
+      int n_iold = LI[lo + lane - kbase], n_dx = LD[lo + lane - kbase + 1];
+      int carryI = NUL16, carryMo = NUL16;
       // software pipeline: the 8-byte sequence probe of chunk c is issued in iteration c and consumed in
       // iteration c+1, so its latency overlaps the LDS/compute work of the next chunk
       bool p_pending = false, p_in = false, p_valid = false, p_probe = false;
@@ -503,7 +514,7 @@ __global__ __launch_bounds__(64) void wfa_affine_kernel_v3(
           v += m; h += m;
           more = (m == 8) && v < pl && h < tl;
         }
-        if (p_in) Mc[p_k + kb] = (uint16_t)(p_valid ? h : 0xFFFF);
+        if (p_in) Mc[p_k + kb] = (int16_t)(p_valid ? h : NUL16);
         const unsigned long long mq = __ballot(more);
         if (more) {
           const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mq, 0u));
@@ -515,52 +526,47 @@ __global__ __launch_bounds__(64) void wfa_affine_kernel_v3(
         const int k = c + lane;
         const int jl = k - kbase;
         const bool in = k <= hi;
-        int mx, ins = OTG_NULL_OFF, del = OTG_NULL_OFF;
-        uint32_t bits = 0;
-        {
-          const uint32_t w0 = q_w0[0], w1 = q_w1[0];
+        const uint32_t w0 = q_w0[0], w1 = q_w1[0];
 #pragma unroll
-          for (int u = 0; u + 1 < PF; ++u) { q_w0[u] = q_w0[u + 1]; q_w1[u] = q_w1[u + 1]; }
-          load_m(c + 64 * PF, q_w0[PF - 1], q_w1[PF - 1]);      // clamped address: always legal
-          const int mo = (Mo && k >= molo && k <= mohi) ? u16_to_off(w0 & 0xFFFFu) : OTG_NULL_OFF;
-          const int mor = (Mo && k + 1 >= molo && k + 1 <= mohi) ? u16_to_off(w0 >> 16) : OTG_NULL_OFF;
-          const int mm = (Mx && k >= mxlo && k <= mxhi) ? u16_to_off(w1 & 0xFFFFu) : OTG_NULL_OFF;
-          const int iold = (k >= idlo && k <= idhi) ? u16_to_off(LI[jl]) : OTG_NULL_OFF;          // I[s-1][k]
-          const int dx = (k + 1 >= idlo && k + 1 <= idhi) ? u16_to_off(LD[jl + 1]) : OTG_NULL_OFF; // D[s-1][k+1]
-          int ix = dpp_shr1(iold);                                                                 // I[s-1][k-1]
-          if (lane == 0) ix = carryI;
-          carryI = __builtin_amdgcn_readlane(iold, 63);
-          int io = dpp_shr1(mo);                                                                   // M[s-o-e][k-1]
-          if (lane == 0) io = carryMo;
-          carryMo = __builtin_amdgcn_readlane(mo, 63);
-          const int dop = mor;                                                                     // M[s-o-e][k+1]
-          if (ix >= io) { ins = ix; bits |= 4u; } else ins = io;
-          ins += 1;
-          if (dx >= dop) { del = dx; bits |= 8u; } else del = dop;
-          const int mis = mm + 1;
-          mx = imax(del, imax(mis, ins));
-          uint32_t org = 0;
-          if (mx == ins) org = 2;
-          if (mx == del) org = 1;
-          if (mx == mis) org = 0;
-          bits |= org;
-          if (ins < 0) ins = OTG_NULL_OFF;
-          if (del < 0) del = OTG_NULL_OFF;
-          if (s == 0) { mx = k > 0 ? k : 0; ins = OTG_NULL_OFF; del = OTG_NULL_OFF; bits = 0; }   // selects, not a branch
-        }
+        for (int u = 0; u + 1 < PF; ++u) { q_w0[u] = q_w0[u + 1]; q_w1[u] = q_w1[u + 1]; }
+        load_m(c + 64 * PF, q_w0[PF - 1], q_w1[PF - 1]);      // clamped address: always legal
+        const int iold = n_iold;                              // I[s-1][k]
+        const int dx = n_dx;                                  // D[s-1][k+1]
+        n_iold = LI[jl + 64]; n_dx = LD[jl + 65];
+        const int mo = (int)(int16_t)(w0 & 0xFFFFu);          // M[s-o-e][k]
+        const int dop = (int)w0 >> 16;                        // M[s-o-e][k+1]
+        const int mm = (int)(int16_t)(w1 & 0xFFFFu);          // M[s-x][k]
+        int ix = dpp_shr1(iold);                              // I[s-1][k-1]
+        if (lane == 0) ix = carryI;
+        carryI = __builtin_amdgcn_readlane(iold, 63);
+        int io = dpp_shr1(mo);                                // M[s-o-e][k-1]
+        if (lane == 0) io = carryMo;
+        carryMo = __builtin_amdgcn_readlane(mo, 63);
+        uint32_t bits = 0;
+        int ins, del;
+        if (ix >= io) { ins = ix; bits |= 4u; } else ins = io;
+        ins += 1;
+        if (dx >= dop) { del = dx; bits |= 8u; } else del = dop;
+        const int mis = mm + 1;
+        int mx = imax(del, imax(mis, ins));
+        uint32_t org = 0;
+        if (mx == ins) org = 2;
+        if (mx == del) org = 1;
+        if (mx == mis) org = 0;
+        bits |= org;
+        if (s == 0) { mx = k > 0 ? k : 0; ins = NUL16; del = NUL16; bits = 0; }   // selects, not a branch
         const int h = mx, v = mx - k;
         const bool valid = in && mx >= 0 && h <= tl && v <= pl;
         const bool probe = valid && v < pl && h < tl;
-        // retire the previous chunk first: its probe was issued one iteration ago, only this iteration's two
+        // retire the previous chunk first: its probe was issued one iteration ago, only this iteration's
         // prefetch loads are younger, so the wait is a counted vmcnt and not a drain
         if (p_pending) finish();
         uint64_t a, b;
         { const int vc = imin(imax(v, 0), pl), hc = imin(imax(h, 0), tl);      // clamped: always inside arena + slack
-          __builtin_memcpy(&a, P + vc, 8); __builtin_memcpy(&b, T + hc, 8); }
+          a = otg_load8(P + vc); b = otg_load8(T + hc); }
         if (in) {
-          // offsets beyond the sequence ends cannot lead to a valid cell any more (they only grow): store them as null
-          LI[jl] = (uint16_t)((ins < 0 || ins > 65534) ? 0xFFFF : ins);
-          LD[jl] = (uint16_t)((del < 0 || del > 65534) ? 0xFFFF : del);
+          LI[jl] = (int16_t)(ins < 0 ? NUL16 : ins);
+          LD[jl] = (int16_t)(del < 0 ? NUL16 : del);
           btrow[k] = (uint8_t)bits;
         }
         p_pending = true; p_in = in; p_valid = valid; p_probe = probe; p_k = k; p_h = h; p_v = v; p_a = a; p_b = b;
@@ -570,13 +576,13 @@ __global__ __launch_bounds__(64) void wfa_affine_kernel_v3(
       drain();
       idlo = s == 0 ? 1 : lo; idhi = s == 0 ? 0 : hi;
       if (!ef) {
-        if (kend >= lo && kend <= hi) { const int x = u16_to_off(Mc[kend + kb]); if (x >= tl) { done = true; s_end = s; k_end = kend; } }
+        if (kend >= lo && kend <= hi) { const int x = Mc[kend + kb]; if (x >= tl) { done = true; s_end = s; k_end = kend; } }
       } else {
         for (int c = lo; c <= hi && !done; c += 64) {
           const int k = c + lane;
           bool fin = false;
           if (k <= hi) {
-            const int h = u16_to_off(Mc[k + kb]);
+            const int h = Mc[k + kb];
             const int v = h - k;
             fin = h >= 0 && ((h >= tl && pl - v <= pef) || (v >= pl && tl - h <= tef));
           }
@@ -630,7 +636,7 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
 
   const size_t maxlen = ctx->max_seq_len;
   AffWs ws;
-  ws.capa = (int)(2 * maxlen + 8);
+  ws.capa = (int)(2 * maxlen + 16) & ~1;
   ws.rm = std::max(xs, oes) + 1;
   ws.ri = es + 1;
   ws.nrows = (int)(2 * (size_t)oes + (size_t)es * 2 * maxlen + 16);
