@@ -338,8 +338,8 @@ using lds_u32 = __attribute__((address_space(3))) uint32_t;
 
 __device__ __forceinline__ int dpp_shr1(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x138, 0xf, 0xf, false); }
 
-template <int CAP, int QCAP>
-__global__ __launch_bounds__(64) void wfa_affine_kernel_v3(
+template <int CAP, int QCAP, int NW>
+__global__ __launch_bounds__(NW * 64) void wfa_affine_kernel_v3(
     const uint8_t* __restrict__ arena, const otg_align_task* __restrict__ tasks,
     const uint32_t* __restrict__ todo, const uint32_t* __restrict__ n_todo_ptr, uint32_t n_todo_imm,
     int xs, int oes, int es, int g,
@@ -350,13 +350,16 @@ __global__ __launch_bounds__(64) void wfa_affine_kernel_v3(
 {
   __shared__ __attribute__((aligned(16))) int16_t s_I[CAP];
   __shared__ __attribute__((aligned(16))) int16_t s_D[CAP];
-  __shared__ uint16_t s_q[QCAP];
+  __shared__ uint16_t s_q[NW][QCAP];
   __shared__ int s_mlo[64];
   __shared__ int s_mhi[64];
+  __shared__ int s_misc[16];
   const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;               // NW waves cooperate on ONE alignment: wave wv sweeps a contiguous 1/NW of each wavefront
   volatile lds_i16* LI = (volatile lds_i16*)&s_I[0];
   volatile lds_i16* LD = (volatile lds_i16*)&s_D[0];
-  volatile lds_u16* queue = (volatile lds_u16*)&s_q[0];
+  volatile lds_u16* queue = (volatile lds_u16*)&s_q[wv][0];
+  volatile __attribute__((address_space(3))) int* misc = (volatile __attribute__((address_space(3))) int*)&s_misc[0];
   uint8_t* my = ws.base + (size_t)blockIdx.x * ws.stride;
   int16_t* ringM = (int16_t*)my;                          // rm rows + one permanently null row
   int16_t* nullrow = ringM + (size_t)ws.rm * ws.capa;
@@ -367,7 +370,9 @@ __global__ __launch_bounds__(64) void wfa_affine_kernel_v3(
   constexpr int NUL16 = -32768;
 
   for (;;) {
-    const uint32_t tk = otg_wave_atomic_add(ticket, 1u);
+    if (wv == 0) misc[0] = (int)otg_wave_atomic_add(ticket, 1u);
+    __syncthreads();
+    const uint32_t tk = (uint32_t)misc[0];
     if (tk >= n_todo) break;
     const uint32_t ti = todo ? todo[tk] : tk;
     const otg_align_task t = tasks[ti];
@@ -388,13 +393,13 @@ __global__ __launch_bounds__(64) void wfa_affine_kernel_v3(
       // null-fill: LDS I/D arrays, the ring rows this task can touch, the null row
       volatile lds_u32* li32 = (volatile lds_u32*)&s_I[0];
       volatile lds_u32* ld32 = (volatile lds_u32*)&s_D[0];
-      for (int q = lane; q < CAP / 2; q += 64) { li32[q] = 0x80008000u; ld32[q] = 0x80008000u; }
+      for (int q = (int)threadIdx.x; q < CAP / 2; q += NW * 64) { li32[q] = 0x80008000u; ld32[q] = 0x80008000u; }
       const int nfill = (pl + tl + 12 + 1) / 2;   // dwords per row
       uint32_t* r32 = (uint32_t*)ringM;
       const int row_dw = ws.capa / 2;
-      for (int r = 0; r <= ws.rm; ++r) for (int q = lane; q < nfill; q += 64) r32[(size_t)r * row_dw + q] = 0x80008000u;
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      for (int r = 0; r <= ws.rm; ++r) for (int q = (int)threadIdx.x; q < nfill; q += NW * 64) r32[(size_t)r * row_dw + q] = 0x80008000u;
     }
+    __syncthreads();
 
     for (int s = 0; !fail; ++s) {
       if (s >= ws.nrows) { fail = true; break; }
@@ -418,8 +423,9 @@ __global__ __launch_bounds__(64) void wfa_affine_kernel_v3(
         if (hi > tl) hi = tl;
       }
       if (hi < lo) {   // null wavefront (I/D of the previous score are null too, see header)
-        s_mlo[sm] = 1; s_mhi[sm] = 0; rowtab[s] = -1; idlo = 1; idhi = 0;
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        if (wv == 0) { s_mlo[sm] = 1; s_mhi[sm] = 0; rowtab[s] = -1; }
+        idlo = 1; idhi = 0;
+        __syncthreads();
         if (s > 2 * (oes + es * (pl + tl)) + 8) fail = true;
         continue;
       }
@@ -427,7 +433,14 @@ __global__ __launch_bounds__(64) void wfa_affine_kernel_v3(
       const int width = hi - lo + 1;
       if (slab_top + (size_t)width > ws.slab_bytes) { fail = true; break; }
       uint8_t* btrow = slab + slab_top - lo;
-      rowtab[s] = (int64_t)slab_top - lo; s_mlo[sm] = lo; s_mhi[sm] = hi;
+      // this wave's share of the wavefront: chunks [c0, c1)
+      const int nch = (width + 63) >> 6;
+      const int c0 = lo + 64 * ((nch * wv) / NW), c1 = lo + 64 * ((nch * (wv + 1)) / NW);
+      // values at the share boundaries that a neighbouring wave overwrites during its own sweep
+      const int bI = (c0 > lo) ? (int)LI[c0 - 1 - kbase] : NUL16;              // I[s-1][c0-1]
+      const int bD = (c1 <= hi) ? (int)LD[c1 - kbase] : NUL16;                 // D[s-1][c1]
+      __syncthreads();
+      if (wv == 0) { rowtab[s] = (int64_t)slab_top - lo; s_mlo[sm] = lo; s_mhi[sm] = hi; misc[1] = 0; }
       slab_top += (size_t)width;
       W += 3ull * (uint64_t)width;
       int16_t* Mc = ringM + (size_t)sm * ws.capa;
@@ -494,10 +507,11 @@ __global__ __launch_bounds__(64) void wfa_affine_kernel_v3(
       constexpr int PF = 4;
       uint32_t q_w0[PF], q_w1[PF];
 #pragma unroll
-      for (int u = 0; u < PF; ++u) load_m(lo + 64 * u, q_w0[u], q_w1[u]);
+      for (int u = 0; u < PF; ++u) load_m(c0 + 64 * u, q_w0[u], q_w1[u]);
       // LDS operands one chunk ahead (the current chunk only overwrites its own 64 entries)
-      int n_iold = LI[lo + lane - kbase], n_dx = LD[lo + lane - kbase + 1];
-      int carryI = NUL16, carryMo = NUL16;
+      int n_iold = LI[c0 + lane - kbase], n_dx = LD[c0 + lane - kbase + 1];
+      int carryI = bI;
+      int carryMo = (c0 > lo) ? (int)MoP[c0 - 1 + kb] : NUL16;
       // software pipeline: the 8-byte sequence probe of chunk c is issued in iteration c and consumed in
       // iteration c+1, so its latency overlaps the LDS/compute work of the next chunk
       bool p_pending = false, p_in = false, p_valid = false, p_probe = false;
@@ -522,7 +536,7 @@ __global__ __launch_bounds__(64) void wfa_affine_kernel_v3(
         }
         qn += __builtin_popcountll(mq);
       };
-      for (int c = lo; c <= hi; c += 64) {
+      for (int c = c0; c < c1; c += 64) {
         const int k = c + lane;
         const int jl = k - kbase;
         const bool in = k <= hi;
@@ -531,7 +545,8 @@ __global__ __launch_bounds__(64) void wfa_affine_kernel_v3(
         for (int u = 0; u + 1 < PF; ++u) { q_w0[u] = q_w0[u + 1]; q_w1[u] = q_w1[u + 1]; }
         load_m(c + 64 * PF, q_w0[PF - 1], q_w1[PF - 1]);      // clamped address: always legal
         const int iold = n_iold;                              // I[s-1][k]
-        const int dx = n_dx;                                  // D[s-1][k+1]
+        int dx = n_dx;                                        // D[s-1][k+1]
+        if (lane == 63 && c + 64 >= c1) dx = bD;              // first diagonal of the next wave's share
         n_iold = LI[jl + 64]; n_dx = LD[jl + 65];
         const int mo = (int)(int16_t)(w0 & 0xFFFFu);          // M[s-o-e][k]
         const int dop = (int)w0 >> 16;                        // M[s-o-e][k+1]
@@ -575,25 +590,38 @@ __global__ __launch_bounds__(64) void wfa_affine_kernel_v3(
       if (p_pending) finish();
       drain();
       idlo = s == 0 ? 1 : lo; idhi = s == 0 ? 0 : hi;
-      if (!ef) {
-        if (kend >= lo && kend <= hi) { const int x = Mc[kend + kb]; if (x >= tl) { done = true; s_end = s; k_end = kend; } }
-      } else {
-        for (int c = lo; c <= hi && !done; c += 64) {
-          const int k = c + lane;
-          bool fin = false;
-          if (k <= hi) {
-            const int h = Mc[k + kb];
-            const int v = h - k;
-            fin = h >= 0 && ((h >= tl && pl - v <= pef) || (v >= pl && tl - h <= tef));
+      // termination: the first diagonal (ascending) whose fully extended offset satisfies the end condition
+      {
+        int cand = 0x7fffffff;
+        if (!ef) {
+          if (kend >= c0 && kend < c1 && kend <= hi) { const int x = Mc[kend + kb]; if (x >= tl) cand = kend; }
+        } else {
+          for (int c = c0; c < c1 && cand == 0x7fffffff; c += 64) {
+            const int k = c + lane;
+            bool fin = false;
+            if (k <= hi) {
+              const int h = Mc[k + kb];
+              const int v = h - k;
+              fin = h >= 0 && ((h >= tl && pl - v <= pef) || (v >= pl && tl - h <= tef));
+            }
+            const unsigned long long fm = __ballot(fin);
+            if (fm) cand = c + (int)__builtin_ctzll(fm);
           }
-          const unsigned long long fm = __ballot(fin);
-          if (fm) { done = true; s_end = s; k_end = c + (int)__builtin_ctzll(fm); }
         }
+        misc[4 + wv] = cand;
       }
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      __syncthreads();
+      {
+        int best = 0x7fffffff;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { const int x = misc[4 + w]; best = x < best ? x : best; }
+        if (best != 0x7fffffff) { done = true; s_end = s; k_end = best; }
+      }
       if (done) break;
     }
+    __syncthreads();
 
+    if (wv != 0) continue;            // wave 0 reports / unpacks; the others wait at the next ticket barrier
     if (fail || s_end < 0) {
       if (overflow_list) { const uint32_t q = otg_wave_atomic_add(n_overflow, 1u); overflow_list[q] = ti; }
       else { scores[ti] = -1; cig_len[ti] = 0; }
@@ -659,7 +687,8 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
     }
   };
   // tier A: v3, LDS window 4096 diagonals, 7 single-wave blocks per CU
-  AffWs wsA = ws; uint32_t wavesA = std::min<uint32_t>((uint32_t)ctx->n_cu * 7, n_tasks); size_t slabA = slab1;
+  constexpr int NWA = 4;                     // waves cooperating on one alignment
+  AffWs wsA = ws; uint32_t wavesA = std::min<uint32_t>((uint32_t)ctx->n_cu * 6, n_tasks); size_t slabA = slab1;   // blocks (one alignment each)
   fit(wavesA, slabA);
   wsA.slab_bytes = slabA & ~(size_t)255; wsA.stride = wsA.off_slab + wsA.slab_bytes;
   // tier B: v3, LDS window 12288 diagonals, 3 blocks per CU
@@ -682,10 +711,10 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
   if (kernel_ms) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   const uint32_t* cur = d_todo; const uint32_t* cur_n = d_n_todo; uint32_t cur_imm = n_tasks;
   if (!no_v3 && es == 1) {
-    hipLaunchKernelGGL((wfa_affine_kernel_v3<4096, 2048>), dim3(wavesA), dim3(64), 0, ctx->stream, d_arena, d_tasks,
+    hipLaunchKernelGGL((wfa_affine_kernel_v3<4096, 512, NWA>), dim3(wavesA), dim3(NWA * 64), 0, ctx->stream, d_arena, d_tasks,
                        d_todo, d_n_todo, n_tasks, xs, oes, es, g, d_scores, d_cig_off, d_cig_len,
                        d_cig_arena, d_cells, cnt + 8, cnt + 9, listA, wsA);
-    hipLaunchKernelGGL((wfa_affine_kernel_v3<12288, 2048>), dim3(wavesB), dim3(64), 0, ctx->stream, d_arena, d_tasks,
+    hipLaunchKernelGGL((wfa_affine_kernel_v3<12288, 512, NWA>), dim3(wavesB), dim3(NWA * 64), 0, ctx->stream, d_arena, d_tasks,
                        (const uint32_t*)listA, (const uint32_t*)(cnt + 9), 0u, xs, oes, es, g, d_scores, d_cig_off, d_cig_len,
                        d_cig_arena, d_cells, cnt + 10, cnt + 11, listB, wsB);
     cur = listB; cur_n = cnt + 11; cur_imm = 0;
