@@ -364,7 +364,7 @@ int otg_launch_edit_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_t
     uint32_t grid = (uint32_t)ctx->n_cu * 5;
     if (grid > want) grid = want;
     hipLaunchKernelGGL((wfa_edit_kernel_v2<CAP, WPB>), dim3(grid), dim3(WPB * 64), lds, ctx->stream, d_arena, d_tasks,
-                       d_todo, d_n_todo, n_tasks, d_scores, d_cells, cnt + 0, cnt + 1, listA, no_myers ? 0.0f : 2.0f);
+                       d_todo, d_n_todo, n_tasks, d_scores, d_cells, cnt + 0, cnt + 1, listA, no_myers ? 0.0f : 1.0f);
   }
   const uint32_t* cur = listA; const uint32_t* cur_n = cnt + 1;
   if (!no_myers) {
