@@ -6,61 +6,78 @@
 // is unbeatable for HiFi-like pairs (s ~ 0..50); for ONT-error reads (s = 0.1..0.4 L) this kernel costs
 // O(n) wave-steps regardless of s.
 //
-// Mapping: one wave64 per pair.  The DP matrix (pattern = rows, text = columns) is cut into 64-row blocks held as
-// vertical-delta bit-vectors (Pv, Mv: 64-bit).  Lane l owns "superblocks" l, l+64, ... (BPL consecutive blocks each)
-// and at time step t processes column j = t - B of its superblock B: the anti-diagonal skew turns the
-// block-to-block carry (hout -> hin) into a one-lane rotate per step (DPP wave_ror).  Only the Ukkonen band
-// -K <= i - j <= K + d (d = m - n >= 0) is evaluated; a superblock enters the band initialised as in Edlib
-// (Pv = ~0, score = score_above + rows) and the block at the top of the band takes hin = +1.  With
-// 2K + d <= 63*64*BPL + 64 a lane has left its superblock before the next one (B + 64) enters the band.
+// Mapping: a GROUP of GL lanes (16, 32 or 64) per pair, 64/GL pairs per wave.  The DP matrix (pattern = rows,
+// text = columns) is cut into 64-row blocks held as vertical-delta bit-vectors (Pv, Mv: 64-bit).  Lane l of a
+// group owns "superblocks" l, l+GL, ... (BPL consecutive blocks each) and at time step t processes column
+// j = t - B of its superblock B: the anti-diagonal skew turns the block-to-block carry (hout -> hin) into a
+// one-lane rotate per step (DPP row_ror for 16-lane groups, ds_bpermute for 32, wave_ror for 64).  Only the
+// Ukkonen band -K <= i - j <= K + d (d = m - n >= 0) is evaluated; a superblock enters the band initialised as in
+// Edlib (Pv = ~0, score = score_above + rows) and the block at the top of the band takes hin = +1.  With
+// 2K + d <= (GL-1)*64*BPL + 64 a lane has left its superblock before the next one (B + GL) enters the band, so
+// narrow bands (within-allele pairs) run four to a wave and only wide ones need the whole wave.
 // The computed score is exact iff it is <= K; otherwise the task is appended to the overflow list and handled
-// by the next tier (more blocks per lane, finally the wavefront kernel).
-// Symbols: A, C, G, T plus at most one further byte value occurring in the pattern (e.g. N); richer alphabets,
-// text-side free ends and patterns > 16384 bytes go to the wavefront kernel.
+// by the next tier (larger group / more blocks per lane, finally the wavefront kernel).
+// Pattern match masks (A, C, G, T + at most one further byte value occurring in the pattern, e.g. N) are built
+// once per pair into an L2-resident scratch and fetched when a lane moves to its next superblock; richer
+// alphabets, text-side free ends and patterns > 16384 bytes go to the wavefront kernel.
 #include "otg_common.hpp"
 #include <cstdlib>
 
 namespace {
 
-constexpr int MAXBLK = 256;           // 64-row blocks per pattern held in LDS (m <= 16384)
+constexpr int MAXBLK = 256;           // 64-row blocks per pattern (m <= 16384)
 using u64 = unsigned long long;
-using lds_u64 = __attribute__((address_space(3))) u64;
 
 __device__ __forceinline__ u64 load8(const uint8_t* p) { u64 v; __builtin_memcpy(&v, p, 8); return v; }
-__device__ __forceinline__ int dpp_ror1_i(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x13C, 0xf, 0xf, false); }   // lane i <- lane i-1 (wrap)
+
+// lane i <- lane i-1 within its group of GL lanes (wrap-around)
+template <int GL>
+__device__ __forceinline__ int group_ror1(int x, int lane)
+{
+  if (GL == 64) return __builtin_amdgcn_update_dpp(x, x, 0x13C, 0xf, 0xf, false);   // wave_ror:1
+  if (GL == 16) return __builtin_amdgcn_update_dpp(x, x, 0x121, 0xf, 0xf, false);   // row_ror:1
+  const int src = (lane & ~(GL - 1)) | ((lane - 1) & (GL - 1));
+  return __builtin_amdgcn_ds_bpermute(src << 2, x);
+}
 
 // W_p of SURVEY.md §8d for a finished alignment with score s (what the wavefront aligner would have evaluated):
-// per score t the diagonals [max(-pbf - t, -m), min(tbf + t, n)].
-__device__ u64 wfa_cells(int s, int m, int n, int pbf, int tbf, int lane)
+// per score t the diagonals [max(-pbf - t, -m), min(tbf + t, n)]; the lanes of the group stride over t.
+template <int GL>
+__device__ u64 wfa_cells(int s, int m, int n, int pbf, int tbf, int gl)
 {
   u64 w = 0;
-  for (int t = lane; t <= s; t += 64) {
+  for (int t = gl; t <= s; t += GL) {
     const int lo = -pbf - t < -m ? -m : -pbf - t;
     const int hi = tbf + t > n ? n : tbf + t;
     w += (u64)(hi - lo + 1);
   }
-  for (int off = 32; off > 0; off >>= 1) w += __shfl_xor(w, off);
+  for (int off = GL / 2; off > 0; off >>= 1) w += __shfl_xor(w, off, GL);
   return w;
 }
 
-template <int BPL, int WPB>
+template <int BPL, int GL, int WPB>
 __global__ __launch_bounds__(WPB * 64) void myers_edit_kernel(
     const uint8_t* __restrict__ arena, const otg_align_task* __restrict__ tasks,
     const uint32_t* __restrict__ todo, const uint32_t* __restrict__ n_todo_ptr, uint32_t n_todo_imm,
     int32_t* __restrict__ scores, uint64_t* __restrict__ cells,
-    uint32_t* __restrict__ ticket, uint32_t* __restrict__ n_overflow, uint32_t* __restrict__ overflow_list, int maxblk)
+    uint32_t* __restrict__ ticket, uint32_t* __restrict__ n_overflow, uint32_t* __restrict__ overflow_list,
+    u64* __restrict__ peq_ws, int maxblk)
 {
-  extern __shared__ __attribute__((aligned(16))) u64 s_peq[];     // WPB x maxblk x 5
+  constexpr int G = 64 / GL;            // pairs per wave
+  constexpr int SB = 64 * BPL;
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
-  volatile lds_u64* peq = (volatile lds_u64*)s_peq + (size_t)wib * maxblk * 5;
+  const int gl = lane & (GL - 1);       // lane within its group
+  const int grp = lane / GL;
+  u64* peq = peq_ws + ((size_t)(blockIdx.x * WPB + wib) * G + grp) * (size_t)maxblk * 5;
   const uint32_t n_todo = n_todo_ptr ? *n_todo_ptr : n_todo_imm;
-  constexpr int SB = 64 * BPL;
 
   for (;;) {
-    const uint32_t tk = otg_wave_atomic_add(ticket, 1u);
-    if (tk >= n_todo) break;
-    const uint32_t ti = todo ? todo[tk] : tk;
+    const uint32_t tk0 = otg_wave_atomic_add(ticket, (uint32_t)G);
+    if (tk0 >= n_todo) break;
+    const uint32_t tk = tk0 + (uint32_t)grp;
+    const bool has_task = tk < n_todo;
+    const uint32_t ti = has_task ? (todo ? todo[tk] : tk) : (todo ? todo[tk0] : tk0);
     const otg_align_task tsk = tasks[ti];
     const bool ef = tsk.endsfree != 0;
     const uint8_t* P = arena + tsk.pattern_off;
@@ -75,14 +92,15 @@ __global__ __launch_bounds__(WPB * 64) void myers_edit_kernel(
     const int d = m - n;
     const int nblk = (m + 63) >> 6;
     const int nsb = (m + SB - 1) / SB;
-    const int K = (63 * SB + 64 - d) / 2;
+    const int K = ((GL - 1) * SB + 64 - d) / 2;
     if (nblk > maxblk || K < d || K < 1 || n < 1 || pbf > d || pef > d) unsupported = true;
+    if (!has_task) unsupported = true;
 
-    // ---- pattern match masks per 64-row block into LDS: A, C, G, T, X (one further byte value)
+    // ---- pattern match masks per 64-row block: A, C, G, T, X (one further byte value), built by the group
     int other = -1;
     bool bad_alpha = false;
     if (!unsupported) {
-      for (int b = lane; b < nblk; b += 64) {
+      for (int b = gl; b < nblk; b += GL) {
         u64 ea = 0, ec = 0, eg = 0, et = 0;
         const int base = b << 6;
         for (int r = 0; r < 64; ++r) {
@@ -95,13 +113,20 @@ __global__ __launch_bounds__(WPB * 64) void myers_edit_kernel(
         }
         peq[b * 5 + 0] = ea; peq[b * 5 + 1] = ec; peq[b * 5 + 2] = eg; peq[b * 5 + 3] = et;
       }
-      // agree on the single extra symbol across lanes
-      const u64 has = __ballot(other >= 0);
+    }
+    // agree on the single extra symbol across the lanes of the group
+    {
+      const u64 gmask = (GL == 64) ? ~0ull : (((1ull << GL) - 1ull) << (grp * GL));
+      const u64 has = __ballot(other >= 0) & gmask;
       int x = -1;
-      if (has) x = __builtin_amdgcn_readlane(other, (int)__builtin_ctzll(has));
-      if (__ballot(bad_alpha || (other >= 0 && other != x))) unsupported = true;
+      const int src = has ? (int)__builtin_ctzll(has) : lane;
+      const int xo = __shfl(other, src);
+      if (has) x = xo;
+      const u64 bad = __ballot(bad_alpha || (other >= 0 && other != x)) & gmask;
+      if (bad) unsupported = true;
+      other = x;
       if (!unsupported) {
-        for (int b = lane; b < nblk; b += 64) {
+        for (int b = gl; b < nblk; b += GL) {
           u64 ex = 0;
           if (x >= 0) {
             const int base = b << 6;
@@ -110,17 +135,11 @@ __global__ __launch_bounds__(WPB * 64) void myers_edit_kernel(
           peq[b * 5 + 4] = ex;
         }
       }
-      other = x;
-    }
-    if (unsupported) {
-      if (overflow_list) { const uint32_t q = otg_wave_atomic_add(n_overflow, 1u); overflow_list[q] = ti; }
-      else scores[ti] = -1;
-      continue;
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 
     // ---- skewed sweep
-    int B = lane;                       // current superblock of this lane
+    int B = gl;                         // current superblock of this lane
     bool inited = false;
     u64 Pv[BPL], Mv[BPL], EA[BPL], EC[BPL], EG[BPL], ET[BPL], EX[BPL];
 #pragma unroll
@@ -129,19 +148,19 @@ __global__ __launch_bounds__(WPB * 64) void myers_edit_kernel(
     int best = 0x3fffffff;
     const int i_lo = m - pef;           // the answer is min over rows i in [i_lo, m] of D[i][n]
     if (i_lo <= 0) best = n;            // D[0][n] = n
-    const int t_end = n - 1 + nsb - 1;
+    const int t_end = unsupported ? -1 : n - 1 + nsb - 1;
     // per-superblock time window (recomputed only when the lane moves to its next superblock)
     int t_start, t_stop, t_hin_stop, t_last; bool exact_init;
     auto setup = [&]() {
       int jlo = SB * B - K - d; if (jlo < 0) jlo = 0;
       int jhi = SB * B + SB - 1 + K; if (jhi > n - 1) jhi = n - 1;
       exact_init = (jlo == 0);
-      if (B < nsb && jlo <= jhi) {
+      if (!unsupported && B < nsb && jlo <= jhi) {
         t_start = jlo + B; t_stop = jhi + B;
         int jh = SB * B - 1 + K; if (jh > jhi) jh = jhi;
         t_hin_stop = B > 0 ? jh + B : -1;              // block above still inside the band
         t_last = (jhi == n - 1) ? n - 1 + B : -1;
-      } else { t_start = 0x7fffffff; t_stop = B < nsb ? -1 : 0x7ffffffe; t_hin_stop = -1; t_last = -1; }
+      } else { t_start = 0x7fffffff; t_stop = 0x7ffffffe; t_hin_stop = -1; t_last = -1; }
     };
     setup();
     // text bytes: one unaligned 8-byte load per 8 steps and lane (prefetched 4 steps ahead); byte (t & 7) of c8
@@ -154,13 +173,17 @@ __global__ __launch_bounds__(WPB * 64) void myers_edit_kernel(
       return sh < 8 ? (load8(T) << (8 * sh)) : 0ull;
     };
     u64 c8 = load_group(0), c8n = 0;
-    for (int t = 0; t <= t_end; ++t) {
-      // values of lane-1 after its previous step
-      const int up_score = dpp_ror1_i(score);
-      const int up_hout = dpp_ror1_i(hout);
+    // the wave runs until its longest pair is done
+    int t_end_w = t_end;
+    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(t_end_w, off); t_end_w = o > t_end_w ? o : t_end_w; }
+    t_end_w = __builtin_amdgcn_readfirstlane(t_end_w);
+    for (int t = 0; t <= t_end_w; ++t) {
+      // values of lane-1 (within the group) after its previous step
+      const int up_score = group_ror1<GL>(score, lane);
+      const int up_hout = group_ror1<GL>(hout, lane);
       const int ph = t & 7;
       if (t > t_stop) {                 // this superblock left the band: move to the next one owned by the lane
-        B += 64; inited = false; setup();
+        B += GL; inited = false; setup();
         c8 = load_group(t - ph);
         if (ph >= 4) c8n = load_group(t - ph + 8);
       }
@@ -231,48 +254,56 @@ __global__ __launch_bounds__(WPB * 64) void myers_edit_kernel(
         }
       }
     }
-    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(best, off); best = o < best ? o : best; }
-    if (best <= K) {
-      scores[ti] = best;
-      if (cells) {
-        const u64 w = wfa_cells(best, (int)tsk.pattern_len, (int)tsk.text_len, ef ? tsk.pattern_begin_free : 0, ef ? tsk.text_begin_free : 0, lane);
-        cells[ti] = w;
-      }
-    } else if (overflow_list) {
-      const uint32_t q = otg_wave_atomic_add(n_overflow, 1u);
-      overflow_list[q] = ti;
-    } else scores[ti] = -1;
+    for (int off = GL / 2; off > 0; off >>= 1) { const int o = __shfl_xor(best, off, GL); best = o < best ? o : best; }
+    const bool ok = !unsupported && best <= K;
+    u64 w = 0;
+    if (cells) w = wfa_cells<GL>(ok ? best : -1, (int)tsk.pattern_len, (int)tsk.text_len, ef ? tsk.pattern_begin_free : 0, ef ? tsk.text_begin_free : 0, gl);
+    if (has_task && gl == 0) {
+      if (ok) { scores[ti] = best; if (cells) cells[ti] = w; }
+      else if (overflow_list) { const uint32_t q = atomicAdd(n_overflow, 1u); overflow_list[q] = ti; }
+      else scores[ti] = -1;
+    }
   }
+}
+
+template <int BPL, int GL>
+int launch_one(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_task* d_tasks, const uint32_t* d_todo,
+               const uint32_t* d_n_todo, uint32_t n_tasks, int32_t* d_scores, uint64_t* d_cells,
+               uint32_t* ticket, uint32_t* n_overflow, uint32_t* overflow_list)
+{
+  constexpr int WPB = 4, G = 64 / GL;
+  int maxblk = (int)((ctx->max_seq_len + 63) / 64) + 1;
+  if (maxblk > MAXBLK) maxblk = MAXBLK;
+  uint32_t want = (n_tasks + WPB * G - 1) / (WPB * G);
+  const uint32_t grid_max = (uint32_t)ctx->n_cu * 8;      // 32 waves / CU when the VGPR budget allows
+  uint32_t grid = grid_max < want ? grid_max : want;
+  if (grid == 0) return OTG_OK;
+  u64* ws = (u64*)otg_slot(ctx, SLOT_AUX8, (size_t)grid_max * WPB * 4 * (size_t)MAXBLK * 5 * sizeof(u64));
+  if (!ws) return OTG_ERR_HIP;
+  hipLaunchKernelGGL((myers_edit_kernel<BPL, GL, WPB>), dim3(grid), dim3(WPB * 64), 0, ctx->stream, d_arena, d_tasks, d_todo, d_n_todo, n_tasks,
+                     d_scores, d_cells, ticket, n_overflow, overflow_list, ws, maxblk);
+  return OTG_OK;
 }
 
 } // namespace
 
 // One tier of the bit-parallel engine: tasks from (d_todo, d_n_todo) (or all n_tasks when d_todo is null);
 // tasks it cannot finish exactly are appended to overflow_list / n_overflow.
-int otg_launch_myers(otg_ctx* ctx, int bpl, const uint8_t* d_arena, const otg_align_task* d_tasks, const uint32_t* d_todo,
+// tier: 0 = 16-lane groups (4 pairs / wave), 1 = 32-lane groups, 2 = whole wave, 3 = whole wave x 2 blocks per lane,
+//       4 = whole wave x 4 blocks per lane.
+int otg_launch_myers(otg_ctx* ctx, int tier, const uint8_t* d_arena, const otg_align_task* d_tasks, const uint32_t* d_todo,
                      const uint32_t* d_n_todo, uint32_t n_tasks, int32_t* d_scores, uint64_t* d_cells,
                      uint32_t* ticket, uint32_t* n_overflow, uint32_t* overflow_list)
 {
-  constexpr int WPB = 4;
-  int maxblk = (int)((ctx->max_seq_len + 63) / 64) + 1;
-  if (maxblk > MAXBLK) maxblk = MAXBLK;
-  const size_t lds = (size_t)WPB * maxblk * 5 * sizeof(u64);
-  uint32_t want = (n_tasks + WPB - 1) / WPB;
-  uint32_t per_cu = (uint32_t)(160 * 1024 / (lds + 512));
-  if (per_cu > 8) per_cu = 8;
-  if (per_cu < 1) per_cu = 1;
-  uint32_t grid = (uint32_t)ctx->n_cu * per_cu;
-  if (grid > want) grid = want;
-  if (grid == 0) return OTG_OK;
-  if (bpl == 1)
-    hipLaunchKernelGGL((myers_edit_kernel<1, WPB>), dim3(grid), dim3(WPB * 64), lds, ctx->stream, d_arena, d_tasks, d_todo, d_n_todo, n_tasks,
-                       d_scores, d_cells, ticket, n_overflow, overflow_list, maxblk);
-  else if (bpl == 2)
-    hipLaunchKernelGGL((myers_edit_kernel<2, WPB>), dim3(grid), dim3(WPB * 64), lds, ctx->stream, d_arena, d_tasks, d_todo, d_n_todo, n_tasks,
-                       d_scores, d_cells, ticket, n_overflow, overflow_list, maxblk);
-  else
-    hipLaunchKernelGGL((myers_edit_kernel<4, WPB>), dim3(grid), dim3(WPB * 64), lds, ctx->stream, d_arena, d_tasks, d_todo, d_n_todo, n_tasks,
-                       d_scores, d_cells, ticket, n_overflow, overflow_list, maxblk);
+  int rc;
+  switch (tier) {
+    case 0: rc = launch_one<1, 16>(ctx, d_arena, d_tasks, d_todo, d_n_todo, n_tasks, d_scores, d_cells, ticket, n_overflow, overflow_list); break;
+    case 1: rc = launch_one<1, 32>(ctx, d_arena, d_tasks, d_todo, d_n_todo, n_tasks, d_scores, d_cells, ticket, n_overflow, overflow_list); break;
+    case 2: rc = launch_one<1, 64>(ctx, d_arena, d_tasks, d_todo, d_n_todo, n_tasks, d_scores, d_cells, ticket, n_overflow, overflow_list); break;
+    case 3: rc = launch_one<2, 64>(ctx, d_arena, d_tasks, d_todo, d_n_todo, n_tasks, d_scores, d_cells, ticket, n_overflow, overflow_list); break;
+    default: rc = launch_one<4, 64>(ctx, d_arena, d_tasks, d_todo, d_n_todo, n_tasks, d_scores, d_cells, ticket, n_overflow, overflow_list); break;
+  }
+  if (rc) return rc;
   HIP_TRY(ctx, hipGetLastError());
   return OTG_OK;
 }

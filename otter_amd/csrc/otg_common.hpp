@@ -123,7 +123,7 @@ __device__ __forceinline__ int otg_wave_match(const uint8_t* P, const uint8_t* T
 int otg_launch_edit(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_task* d_tasks, uint32_t n_tasks,
                     int32_t* d_scores, uint64_t* d_cells, float* kernel_ms, uint64_t* launches);
 
-int otg_launch_myers(otg_ctx* ctx, int bpl, const uint8_t* d_arena, const otg_align_task* d_tasks, const uint32_t* d_todo,
+int otg_launch_myers(otg_ctx* ctx, int tier, const uint8_t* d_arena, const otg_align_task* d_tasks, const uint32_t* d_todo,
                      const uint32_t* d_n_todo, uint32_t n_tasks, int32_t* d_scores, uint64_t* d_cells,
                      uint32_t* ticket, uint32_t* n_overflow, uint32_t* overflow_list);
 int otg_launch_edit_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_task* d_tasks, const uint32_t* d_todo,

@@ -329,8 +329,8 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_kernel_v2(
 
 } // namespace
 
-// Enqueue the tier chain: wavefront tier 1 (LDS, score-capped) -> bit-parallel BPL 1/2/4 -> wavefront tier 2 -> global.  Requires: d_arena padded with >= 8 readable bytes after the last
-// sequence byte.  Uses SLOT_COUNTERS (16 u32), SLOT_TODO (2*n_tasks u32), SLOT_WF_WS (tier 3 only).
+// Enqueue the tier chain: wavefront tier 1 (LDS, score-capped) -> bit-parallel tiers 0..4 -> wavefront tier 2 -> global.  Requires: d_arena padded with >= 8 readable bytes after the last
+// sequence byte.  Uses SLOT_COUNTERS (16 u32), SLOT_TODO (8*n_tasks u32), SLOT_WF_WS (tier 3 only).
 int otg_launch_edit(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_task* d_tasks, uint32_t n_tasks,
                     int32_t* d_scores, uint64_t* d_cells, float* kernel_ms, uint64_t* launches)
 {
@@ -346,15 +346,17 @@ int otg_launch_edit_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_t
 {
   if (n_tasks == 0) return OTG_OK;
   uint32_t* cnt = (uint32_t*)otg_slot(ctx, SLOT_COUNTERS, 64 * sizeof(uint32_t));
-  uint32_t* todo = (uint32_t*)otg_slot(ctx, SLOT_TODO, 6 * (size_t)n_tasks * sizeof(uint32_t));
+  uint32_t* todo = (uint32_t*)otg_slot(ctx, SLOT_TODO, 8 * (size_t)n_tasks * sizeof(uint32_t));
   if (!cnt || !todo) return OTG_ERR_HIP;
   HIP_TRY(ctx, hipMemsetAsync(cnt, 0, 8 * sizeof(uint32_t), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(cnt + 16, 0, 16 * sizeof(uint32_t), ctx->stream));
-  uint32_t* listA = todo;                 // overflow of WFA tier 1 (score cap / capacity)
-  uint32_t* listB = todo + n_tasks;       // overflow of bit-parallel BPL 1
-  uint32_t* listC = todo + 2 * (size_t)n_tasks;
-  uint32_t* listD = todo + 3 * (size_t)n_tasks;   // what the bit-parallel tiers could not finish
-  uint32_t* listE = todo + 4 * (size_t)n_tasks;   // overflow of WFA tier 2
+  uint32_t* listA = todo;                         // overflow of WFA tier 1 (score cap / capacity)
+  uint32_t* listB = todo + n_tasks;               // overflow of bit-parallel tier 0 (16-lane groups)
+  uint32_t* listC = todo + 2 * (size_t)n_tasks;   // ... tier 1 (32-lane groups)
+  uint32_t* listD = todo + 3 * (size_t)n_tasks;   // ... tier 2 (whole wave)
+  uint32_t* listE = todo + 4 * (size_t)n_tasks;   // ... tier 3 (2 blocks per lane)
+  uint32_t* listF = todo + 5 * (size_t)n_tasks;   // what the bit-parallel tiers could not finish
+  uint32_t* listG = todo + 6 * (size_t)n_tasks;   // overflow of WFA tier 2
   static const bool no_myers = getenv("OTG_NO_MYERS") != nullptr;
   if (kernel_ms) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   {
@@ -368,13 +370,16 @@ int otg_launch_edit_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_t
   }
   const uint32_t* cur = listA; const uint32_t* cur_n = cnt + 1;
   if (!no_myers) {
-    int rc = otg_launch_myers(ctx, 1, d_arena, d_tasks, listA, cnt + 1, n_tasks, d_scores, d_cells, cnt + 2, cnt + 3, listB);
-    if (rc) return rc;
-    rc = otg_launch_myers(ctx, 2, d_arena, d_tasks, listB, cnt + 3, n_tasks, d_scores, d_cells, cnt + 4, cnt + 5, listC);
-    if (rc) return rc;
-    rc = otg_launch_myers(ctx, 4, d_arena, d_tasks, listC, cnt + 5, n_tasks, d_scores, d_cells, cnt + 6, cnt + 7, listD);
-    if (rc) return rc;
-    cur = listD; cur_n = cnt + 7;
+    static const int first = getenv("OTG_MYERS_FIRST") ? atoi(getenv("OTG_MYERS_FIRST")) : 0;
+    uint32_t* const lists[6] = {listA, listB, listC, listD, listE, listF};
+    uint32_t* const tick[5] = {cnt + 2, cnt + 4, cnt + 6, cnt + 20, cnt + 22};
+    uint32_t* const ovf[5] = {cnt + 3, cnt + 5, cnt + 7, cnt + 21, cnt + 23};
+    int li = 0;
+    for (int tier = first < 0 ? 0 : (first > 2 ? 2 : first); tier < 5; ++tier, ++li) {
+      const int rc = otg_launch_myers(ctx, tier, d_arena, d_tasks, cur, cur_n, n_tasks, d_scores, d_cells, tick[li], ovf[li], lists[li + 1]);
+      if (rc) return rc;
+      cur = lists[li + 1]; cur_n = ovf[li];
+    }
   }
   if (kernel_ms) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   {
@@ -382,7 +387,7 @@ int otg_launch_edit_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_t
     const size_t lds = (size_t)CAP * 2 * WPB * sizeof(uint16_t);
     uint32_t grid = (uint32_t)ctx->n_cu * 5;
     hipLaunchKernelGGL((wfa_edit_kernel_v2<CAP, WPB>), dim3(grid), dim3(WPB * 64), lds, ctx->stream, d_arena, d_tasks,
-                       cur, cur_n, 0u, d_scores, d_cells, cnt + 16, cnt + 17, listE, 0.0f);
+                       cur, cur_n, 0u, d_scores, d_cells, cnt + 16, cnt + 17, listG, 0.0f);
   }
   {
     // last tier: global-memory wavefront sized for the longest possible pair; only reached by huge inputs
@@ -392,7 +397,7 @@ int otg_launch_edit_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_t
     int32_t* ws = (int32_t*)otg_slot(ctx, SLOT_WF_WS, (size_t)grid * WPB * (size_t)gcap * sizeof(int32_t));
     if (!ws) return OTG_ERR_HIP;
     hipLaunchKernelGGL((wfa_edit_kernel<0, WPB, true>), dim3(grid), dim3(WPB * 64), 0, ctx->stream, d_arena, d_tasks,
-                       (const uint32_t*)listE, (const uint32_t*)(cnt + 17), 0u, d_scores, d_cells, cnt + 18, cnt + 19,
+                       (const uint32_t*)listG, (const uint32_t*)(cnt + 17), 0u, d_scores, d_cells, cnt + 18, cnt + 19,
                        (uint32_t*)nullptr, ws, gcap);
   }
   HIP_TRY(ctx, hipGetLastError());
@@ -400,7 +405,7 @@ int otg_launch_edit_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_t
     hipError_t er = hipStreamSynchronize(ctx->stream);
     uint32_t h[32];
     (void)hipMemcpy(h, cnt, sizeof(h), hipMemcpyDeviceToHost);
-    fprintf(stderr, "[otg] edit: %s; wfa1 overflow %u, myers1/2/4 overflow %u/%u/%u, wfa2 overflow %u\n", hipGetErrorString(er), h[1], h[3], h[5], h[7], h[17]);
+    fprintf(stderr, "[otg] edit: %s; wfa1 overflow %u, bit-parallel tiers overflow %u/%u/%u/%u/%u, wfa2 overflow %u\n", hipGetErrorString(er), h[1], h[3], h[5], h[7], h[21], h[23], h[17]);
   }
   if (kernel_ms) {
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
