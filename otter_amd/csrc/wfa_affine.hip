@@ -319,6 +319,265 @@ __global__ __launch_bounds__(WPB * 64) void wfa_affine_kernel(
   }
 }
 
+// W_p = 3 * sum of the wavefront widths the un-bounded aligner evaluates.  The ranges follow from the
+// lengths, the free ends and the penalties alone: score 0 spans [lo0, hi0]; the next reachable score is
+// f = min(x, o+e) (same span, widened by one on both sides when it is a gap open); from then on the previous score's
+// I/D wavefronts widen the range by one diagonal per side and score (gap extension 1), clipped to [-pl, tl].
+__device__ uint64_t affine_cells(const otg_align_task& t, int xs, int oes, int s_end)
+{
+  const int pl = (int)t.pattern_len, tl = (int)t.text_len;
+  const bool ef = t.endsfree != 0;
+  const int lo0 = ef ? imax(-t.pattern_begin_free, -pl) : 0, hi0 = ef ? imin(t.text_begin_free, tl) : 0;
+  uint64_t W = (uint64_t)(hi0 - lo0 + 1);
+  const int sf = imin(xs, oes);
+  if (s_end >= sf) {
+    const int lof = oes <= xs ? imax(lo0 - 1, -pl) : lo0, hif = oes <= xs ? imin(hi0 + 1, tl) : hi0;
+    const long long n = s_end - sf;
+    auto ramp = [](long long base, long long room, long long n) -> long long {    // sum_{d=0..n} min(base + d, base + room)
+      return (n + 1) * base + (n <= room ? n * (n + 1) / 2 : room * (room + 1) / 2 + (n - room) * room);
+    };
+    W += (uint64_t)(ramp(hif, tl - hif, n) + ramp(-lof, pl + lof, n) + (n + 1));
+  }
+  return 3ull * W;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Score bound pass.  A banded (64*DPL diagonals, static band around the start and end diagonals), score-only run
+// of the same recurrence, entirely in registers: lane l owns DPL adjacent diagonals, the M ring (OES rows), I and
+// D are VGPR arrays, neighbours come from the lane itself or one DPP shift.  Any alignment it finds is a valid
+// alignment of the pair, so its score U is an UPPER bound of the optimum (equal to it whenever the optimal path
+// stays inside the band, which is the normal case for reads of one allele).  The exact kernel below uses U only
+// to skip cells that cannot lie on an alignment of score <= U (see there), so a loose U costs time, never
+// correctness.  U = INT_MAX when the band cannot hold the start and end diagonals.
+__device__ __forceinline__ int dpp_shl1(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x130, 0xf, 0xf, false); }   // lane i <- lane i+1
+__device__ __forceinline__ int dpp_shr1b(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x138, 0xf, 0xf, false); }  // lane i <- lane i-1
+
+template <int DPL, int XS, int OES>
+__global__ __launch_bounds__(256) void wfa_affine_bound_kernel(
+    const uint8_t* __restrict__ arena, const otg_align_task* __restrict__ tasks,
+    const uint32_t* __restrict__ todo, const uint32_t* __restrict__ n_todo_ptr, uint32_t n_todo_imm,
+    int32_t* __restrict__ bound, uint32_t* __restrict__ ticket)
+{
+  constexpr int NULLV = -(1 << 29);
+  constexpr int R = XS > OES ? XS : OES;
+  constexpr int BAND = 64 * DPL;
+  const int lane = threadIdx.x & 63;
+  const uint32_t n_todo = n_todo_ptr ? *n_todo_ptr : n_todo_imm;
+  for (;;) {
+    const uint32_t tk = otg_wave_atomic_add(ticket, 1u);
+    if (tk >= n_todo) break;
+    const uint32_t ti = todo ? todo[tk] : tk;
+    const otg_align_task t = tasks[ti];
+    const uint8_t* P = arena + t.pattern_off;
+    const uint8_t* T = arena + t.text_off;
+    const int pl = (int)t.pattern_len, tl = (int)t.text_len;
+    const bool ef = t.endsfree != 0;
+    const int pef = ef ? t.pattern_end_free : 0, tef = ef ? t.text_end_free : 0;
+    const int kend = tl - pl;
+    const int lo0 = ef ? imax(-t.pattern_begin_free, -pl) : 0, hi0 = ef ? imin(t.text_begin_free, tl) : 0;
+    const int need_lo = imin(lo0, kend - tef), need_hi = imax(hi0, kend + pef);
+    int result = 0x7fffffff;
+    if (need_hi - need_lo + 1 + 64 <= BAND && pl > 0 && tl > 0 && pl < 32766 && tl < 32766) {
+      const int blo = ((need_lo + need_hi) >> 1) - BAND / 2;
+      const int k0 = blo + lane * DPL;
+      int M[R][DPL], I[DPL], D[DPL], cur[DPL];
+#pragma unroll
+      for (int j = 0; j < DPL; ++j) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) M[r][j] = NULLV;
+        I[j] = NULLV; D[j] = NULLV;
+        const int k = k0 + j;
+        const int h = k > 0 ? k : 0, v = h - k;
+        cur[j] = (k >= lo0 && k <= hi0 && h <= tl && v <= pl) ? h : NULLV;
+      }
+      // extends cur[] along matches and reports whether some diagonal satisfies the end condition
+      auto extend_and_test = [&]() -> bool {
+        uint64_t a[DPL], b[DPL];
+        bool more[DPL];
+#pragma unroll
+        for (int j = 0; j < DPL; ++j) {
+          const int h = cur[j], v = h - (k0 + j);
+          const int vc = imin(imax(v, 0), pl), hc = imin(imax(h, 0), tl);
+          a[j] = otg_load8(P + vc); b[j] = otg_load8(T + hc);
+        }
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < DPL; ++j) {
+          const int h = cur[j], v = h - (k0 + j);
+          const bool act = h >= 0 && v < pl && h < tl;
+          const uint64_t xx = a[j] ^ b[j];
+          int m = xx ? (int)(__builtin_ctzll(xx) >> 3) : 8;
+          m = imin(m, imin(pl - v, tl - h));
+          if (act) cur[j] = h + m;
+          more[j] = act && m == 8 && v + 8 < pl && h + 8 < tl;
+          any = any || more[j];
+        }
+        while (__ballot(any)) {      // another 8 bytes for the diagonals still inside a match run (predicated, no divergence)
+          any = false;
+#pragma unroll
+          for (int j = 0; j < DPL; ++j) {
+            const int h = cur[j], v = h - (k0 + j);
+            const int vc = imin(imax(v, 0), pl), hc = imin(imax(h, 0), tl);
+            a[j] = otg_load8(P + vc); b[j] = otg_load8(T + hc);
+          }
+#pragma unroll
+          for (int j = 0; j < DPL; ++j) {
+            const int h = cur[j], v = h - (k0 + j);
+            const uint64_t xx = a[j] ^ b[j];
+            int m = xx ? (int)(__builtin_ctzll(xx) >> 3) : 8;
+            m = imin(m, imin(pl - v, tl - h));
+            if (more[j]) cur[j] = h + m;
+            more[j] = more[j] && m == 8 && v + 8 < pl && h + 8 < tl;
+            any = any || more[j];
+          }
+        }
+        bool fin = false;
+#pragma unroll
+        for (int j = 0; j < DPL; ++j) {
+          const int h = cur[j], v = h - (k0 + j);
+          fin = fin || (h >= 0 && ((h >= tl && pl - v <= pef) || (v >= pl && tl - h <= tef)));
+        }
+        return __ballot(fin) != 0;
+      };
+      if (extend_and_test()) result = 0;
+      const int smax = 2 * (OES + pl + tl) + 8;
+      for (int s = 1; result == 0x7fffffff && s <= smax; ++s) {
+        // ring shift: M[0] = row s-1
+#pragma unroll
+        for (int j = 0; j < DPL; ++j) {
+#pragma unroll
+          for (int r = R - 1; r > 0; --r) M[r][j] = M[r - 1][j];
+          M[0][j] = cur[j];
+        }
+        int mo_l = dpp_shr1b(M[OES - 1][DPL - 1]), i_l = dpp_shr1b(I[DPL - 1]);
+        int mo_r = dpp_shl1(M[OES - 1][0]), d_r = dpp_shl1(D[0]);
+        if (lane == 0) { mo_l = NULLV; i_l = NULLV; }
+        if (lane == 63) { mo_r = NULLV; d_r = NULLV; }
+        int nI[DPL], nD[DPL];
+#pragma unroll
+        for (int j = 0; j < DPL; ++j) {
+          const int k = k0 + j;
+          const int ml = j > 0 ? M[OES - 1][j - 1] : mo_l, il = j > 0 ? I[j - 1] : i_l;
+          const int mr = j < DPL - 1 ? M[OES - 1][j + 1] : mo_r, dr = j < DPL - 1 ? D[j + 1] : d_r;
+          int ins = imax(il, ml) + 1;
+          int del = imax(dr, mr);
+          const int mis = M[XS - 1][j] + 1;
+          if (ins < 0 || ins > tl || ins - k > pl) ins = NULLV;
+          if (del < 0 || del > tl || del - k > pl) del = NULLV;
+          int mx = imax(del, imax(mis, ins));
+          if (mx < 0 || mx > tl || mx - k > pl) mx = NULLV;
+          nI[j] = ins; nD[j] = del; cur[j] = mx;
+        }
+#pragma unroll
+        for (int j = 0; j < DPL; ++j) { I[j] = nI[j]; D[j] = nD[j]; }
+        if (extend_and_test()) result = s;
+      }
+    }
+    bound[ti] = result;      // wave-uniform value, same store from every lane
+  }
+}
+
+// Sliding variant of the bound pass: ONE diagonal per lane (64-diagonal band) that follows the diagonal with the
+// furthest anti-diagonal progress (checked every second score, one diagonal per move; the state moves with a DPP
+// shift).  Four times cheaper per score than the static 256-diagonal band and not limited by the distance
+// between start and end diagonals; the bound is as valid (any alignment found is an alignment), just looser
+// when the optimal path strays more than ~20 diagonals from the leader.
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+  constexpr int NEG = -2147483647 - 1;
+  v = imax(v, __builtin_amdgcn_update_dpp(NEG, v, 0x111, 0xf, 0xf, false));   // row_shr:1
+  v = imax(v, __builtin_amdgcn_update_dpp(NEG, v, 0x112, 0xf, 0xf, false));   // row_shr:2
+  v = imax(v, __builtin_amdgcn_update_dpp(NEG, v, 0x114, 0xf, 0xf, false));   // row_shr:4
+  v = imax(v, __builtin_amdgcn_update_dpp(NEG, v, 0x118, 0xf, 0xf, false));   // row_shr:8  -> lane 15 of each row = row max
+  v = imax(v, __builtin_amdgcn_update_dpp(NEG, v, 0x142, 0xa, 0xf, false));   // row_bcast:15 into rows 1, 3
+  v = imax(v, __builtin_amdgcn_update_dpp(NEG, v, 0x143, 0xc, 0xf, false));   // row_bcast:31 into rows 2, 3
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+template <int XS, int OES>
+__global__ __launch_bounds__(256) void wfa_affine_bound1_kernel(
+    const uint8_t* __restrict__ arena, const otg_align_task* __restrict__ tasks,
+    const uint32_t* __restrict__ todo, const uint32_t* __restrict__ n_todo_ptr, uint32_t n_todo_imm,
+    int32_t* __restrict__ bound, uint32_t* __restrict__ ticket)
+{
+  static_assert(XS == 2 && OES == 4, "ring roles below are written out for (2,4,1)");
+  constexpr int NULLV = -(1 << 29);
+  const int lane = threadIdx.x & 63;
+  const uint32_t n_todo = n_todo_ptr ? *n_todo_ptr : n_todo_imm;
+  for (;;) {
+    const uint32_t tk = otg_wave_atomic_add(ticket, 1u);
+    if (tk >= n_todo) break;
+    const uint32_t ti = todo ? todo[tk] : tk;
+    const otg_align_task t = tasks[ti];
+    const uint8_t* P = arena + t.pattern_off;
+    const uint8_t* T = arena + t.text_off;
+    const int pl = (int)t.pattern_len, tl = (int)t.text_len;
+    const bool ef = t.endsfree != 0;
+    const int pef = ef ? t.pattern_end_free : 0, tef = ef ? t.text_end_free : 0;
+    const int lo0 = ef ? imax(-t.pattern_begin_free, -pl) : 0, hi0 = ef ? imin(t.text_begin_free, tl) : 0;
+    int result = 0x7fffffff;
+    if (hi0 - lo0 + 1 <= 40 && pl > 0 && tl > 0 && pl < 32766 && tl < 32766) {
+      int bk0 = ((lo0 + hi0) >> 1) - 32;                 // diagonal of lane 0
+      int M1 = NULLV, M2 = NULLV, M3 = NULLV, M4 = NULLV, I = NULLV, D = NULLV, cur;
+      { const int k = bk0 + lane, h = k > 0 ? k : 0, v = h - k;
+        cur = (k >= lo0 && k <= hi0 && h <= tl && v <= pl) ? h : NULLV; }
+      auto extend_and_test = [&]() -> bool {
+        const int k = bk0 + lane;
+        bool more = cur >= 0;
+        do {
+          const int h = cur, v = h - k;
+          const int vc = imin(imax(v, 0), pl), hc = imin(imax(h, 0), tl);
+          const uint64_t xx = otg_load8(P + vc) ^ otg_load8(T + hc);
+          int m = xx ? (int)(__builtin_ctzll(xx) >> 3) : 8;
+          m = imin(m, imin(pl - v, tl - h));
+          if (more) cur = h + m;
+          more = more && m == 8 && v + 8 < pl && h + 8 < tl;
+        } while (__ballot(more));
+        const int h = cur, v = h - k;
+        const bool fin = h >= 0 && ((h >= tl && pl - v <= pef) || (v >= pl && tl - h <= tef));
+        return __ballot(fin) != 0;
+      };
+      if (extend_and_test()) result = 0;
+      const int smax = pl + tl + 64;
+      for (int s = 1; result == 0x7fffffff && s <= smax; ++s) {
+        M4 = M3; M3 = M2; M2 = M1; M1 = cur;             // M1 = row s-1 ... M4 = row s-4
+        if ((s & 1) == 0) {
+          // follow the leader: keep the diagonal with the furthest anti-diagonal inside lanes [24, 40)
+          const int prog = M1 >= 0 ? 2 * M1 - (bk0 + lane) : NULLV;
+          const int best = wave_max_i32(prog);
+          const unsigned long long at = __ballot(prog == best && best > NULLV);
+          if (at) {
+            const int bl = (int)__builtin_ctzll(at);
+            if (bl >= 40) {                               // band moves up: lane i takes over lane i+1
+              M1 = dpp_shl1(M1); M2 = dpp_shl1(M2); M3 = dpp_shl1(M3); M4 = dpp_shl1(M4); I = dpp_shl1(I); D = dpp_shl1(D);
+              if (lane == 63) { M1 = M2 = M3 = M4 = I = D = NULLV; }
+              ++bk0;
+            } else if (bl < 24) {
+              M1 = dpp_shr1b(M1); M2 = dpp_shr1b(M2); M3 = dpp_shr1b(M3); M4 = dpp_shr1b(M4); I = dpp_shr1b(I); D = dpp_shr1b(D);
+              if (lane == 0) { M1 = M2 = M3 = M4 = I = D = NULLV; }
+              --bk0;
+            }
+          }
+        }
+        const int k = bk0 + lane;
+        int mo_l = dpp_shr1b(M4), i_l = dpp_shr1b(I), mo_r = dpp_shl1(M4), d_r = dpp_shl1(D);
+        if (lane == 0) { mo_l = NULLV; i_l = NULLV; }
+        if (lane == 63) { mo_r = NULLV; d_r = NULLV; }
+        int ins = imax(i_l, mo_l) + 1;
+        int del = imax(d_r, mo_r);
+        const int mis = M2 + 1;
+        if (ins < 0 || ins > tl || ins - k > pl) ins = NULLV;
+        if (del < 0 || del > tl || del - k > pl) del = NULLV;
+        int mx = imax(del, imax(mis, ins));
+        if (mx < 0 || mx > tl || mx - k > pl) mx = NULLV;
+        I = ins; D = del; cur = mx;
+        if (extend_and_test()) result = s;
+      }
+    }
+    bound[ti] = result;      // wave-uniform value, same store from every lane
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // v3 forward kernel (tier 1; gap-extension step 1 after gcd reduction, sequences < 32767):
 //   * I and D wavefronts live in LDS as SIGNED 16-bit offsets (null = any negative value) and are updated
@@ -346,7 +605,7 @@ __global__ __launch_bounds__(NW * 64) void wfa_affine_kernel_v3(
     int32_t* __restrict__ scores, const uint64_t* __restrict__ cig_off, uint32_t* __restrict__ cig_len,
     uint8_t* __restrict__ cig_arena, uint64_t* __restrict__ cells,
     uint32_t* __restrict__ ticket, uint32_t* __restrict__ n_overflow, uint32_t* __restrict__ overflow_list,
-    AffWs ws)
+    AffWs ws, const int32_t* __restrict__ bound)
 {
   __shared__ __attribute__((aligned(16))) int16_t s_I[CAP];
   __shared__ __attribute__((aligned(16))) int16_t s_D[CAP];
@@ -383,9 +642,18 @@ __global__ __launch_bounds__(NW * 64) void wfa_affine_kernel_v3(
     const int pef = t.pattern_end_free, tef = t.text_end_free;
     const int kb = pl + 4;                        // ring index of diagonal k (4 entries of slack on the left)
     const int kend = tl - pl;
+    // Score bound U (units of g; INT_MAX = none).  A cell (s, k) of any component can only lie on an alignment of
+    // total score <= U if it can still reach an end diagonal in [elo, ehi] with the remaining budget, and changing
+    // the diagonal by one costs at least one gap extension (es == 1 here): dist(k, [elo, ehi]) <= U - s.  Cells
+    // outside are skipped (read as null).  This cannot change the result: every cell on the optimal path, and
+    // every predecessor that attains (or ties) the maximum of such a cell, lies itself on an alignment of score
+    // <= the optimum <= U and is therefore kept with its true value; dropped cells only lower values that were
+    // not the maximum.  So offsets, provenance bits on the path, the end diagonal and the score are unchanged.
+    const int U = bound ? bound[ti] : 0x7fffffff;
+    const bool bounded = U < 0x40000000;
+    const int elo = kend - (ef ? tef : 0), ehi = kend + (ef ? pef : 0);
     bool fail = (pl + tl + 12 > ws.capa) || pl >= 32766 || tl >= 32766 || es != 1;
     size_t slab_top = 0;
-    uint64_t W = 0;
     int s_end = -1, k_end = 0;
     int idlo = 1, idhi = 0;                       // range of the I/D wavefronts of the previous score (null)
     int kbase = 0;
@@ -410,7 +678,14 @@ __global__ __launch_bounds__(NW * 64) void wfa_affine_kernel_v3(
       if (s == 0) {
         lo = ef ? imax(-t.pattern_begin_free, -pl) : 0;
         hi = ef ? imin(t.text_begin_free, tl) : 0;
-        kbase = lo - ((CAP - (hi - lo + 1)) >> 1);
+        if (bounded) {
+          // the LDS window is centred on the diamond [ (lo0+elo-U)/2, (hi0+ehi+U)/2 ] that all kept cells live in
+          const int dlo = imax(lo - U, (lo + elo - U) >> 1), dhi = imin(hi + U, (hi + ehi + U + 1) >> 1);
+          lo = imax(lo, elo - U); hi = imin(hi, ehi + U);
+          if (hi < lo) { fail = true; break; }
+          kbase = ((dlo + dhi) >> 1) - (CAP >> 1);
+          if (lo - kbase < 2 || hi - kbase + 132 >= CAP) kbase = lo - ((CAP - (hi - lo + 1)) >> 1);
+        } else kbase = lo - ((CAP - (hi - lo + 1)) >> 1);
         if (hi - lo + 140 > CAP) { fail = true; break; }
       } else {
         lo = 1 << 30; hi = -(1 << 30);
@@ -421,6 +696,11 @@ __global__ __launch_bounds__(NW * 64) void wfa_affine_kernel_v3(
         if (idhi >= idlo) { lo = imin(lo, idlo - 1); hi = imax(hi, idhi + 1); }
         if (lo < -pl) lo = -pl;
         if (hi > tl) hi = tl;
+        if (bounded && hi >= lo) {
+          const int room = U - s;
+          lo = imax(lo, elo - room); hi = imin(hi, ehi + room);
+          if (room < 0 || hi < lo) { fail = true; break; }     // cannot happen with a valid bound: next tier decides
+        }
       }
       if (hi < lo) {   // null wavefront (I/D of the previous score are null too, see header)
         if (wv == 0) { s_mlo[sm] = 1; s_mhi[sm] = 0; rowtab[s] = -1; }
@@ -437,12 +717,13 @@ __global__ __launch_bounds__(NW * 64) void wfa_affine_kernel_v3(
       const int nch = (width + 63) >> 6;
       const int c0 = lo + 64 * ((nch * wv) / NW), c1 = lo + 64 * ((nch * (wv + 1)) / NW);
       // values at the share boundaries that a neighbouring wave overwrites during its own sweep
-      const int bI = (c0 > lo) ? (int)LI[c0 - 1 - kbase] : NUL16;              // I[s-1][c0-1]
-      const int bD = (c1 <= hi) ? (int)LD[c1 - kbase] : NUL16;                 // D[s-1][c1]
+      // (with a score bound the previous wavefronts can be WIDER than this one, so the entries just outside
+      // [lo, hi] are read like any other; without one they are null-filled and never written)
+      const int bI = (int)LI[c0 - 1 - kbase];                                  // I[s-1][c0-1]
+      const int bD = (int)LD[c1 - kbase];                                      // D[s-1][c1]
       __syncthreads();
       if (wv == 0) { rowtab[s] = (int64_t)slab_top - lo; s_mlo[sm] = lo; s_mhi[sm] = hi; misc[1] = 0; }
       slab_top += (size_t)width;
-      W += 3ull * (uint64_t)width;
       int16_t* Mc = ringM + (size_t)sm * ws.capa;
       bool done = false;
       int qn = 0;
@@ -511,7 +792,7 @@ __global__ __launch_bounds__(NW * 64) void wfa_affine_kernel_v3(
       // LDS operands one chunk ahead (the current chunk only overwrites its own 64 entries)
       int n_iold = LI[c0 + lane - kbase], n_dx = LD[c0 + lane - kbase + 1];
       int carryI = bI;
-      int carryMo = (c0 > lo) ? (int)MoP[c0 - 1 + kb] : NUL16;
+      int carryMo = (int)MoP[c0 - 1 + kb];
       // software pipeline: the 8-byte sequence probe of chunk c is issued in iteration c and consumed in
       // iteration c+1, so its latency overlaps the LDS/compute work of the next chunk
       bool p_pending = false, p_in = false, p_valid = false, p_probe = false;
@@ -628,7 +909,294 @@ __global__ __launch_bounds__(NW * 64) void wfa_affine_kernel_v3(
       continue;
     }
     if (!backtrace_unpack(P, pl, T, tl, s_end, k_end, xs, oes, es, rowtab, slab, rev, ws.rev_cap, cig_arena + cig_off[ti], lane, &scores[ti], &cig_len[ti], g)) continue;
-    if (cells) cells[ti] = W;
+    if (cells) cells[ti] = affine_cells(t, xs, oes, s_end);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// v4 forward kernel: score-bounded alignments whose whole diamond of kept cells fits an LDS window of CAP
+// diagonals.  Penalties (2,4,1) after gcd reduction (the default 4/6/2).  ALL wavefronts live in LDS as signed
+// 16-bit offsets: I and D updated in place as in v3; M as four rows — a score only reads M rows of its own
+// parity (s-2, s-4), and M[s] overwrites M[s-4] in place during the ascending sweep (left neighbour carried in
+// a register, right neighbour still old), so two rows per parity suffice.  Six arrays x CAP x 2 bytes:
+// 12 KB (CAP 1024) or 24 KB (CAP 2048) per alignment -> 12 / 6 alignments resident per CU, and the only HBM
+// traffic left in the sweep is the 8-byte sequence probe and the provenance byte.  With a bound the ranges
+// first grow and then shrink by one diagonal per side and score; whatever an array holds outside the current
+// range is either null (never written) or a value of an older, wider wavefront that no later score reads
+// (the readers' ranges have shrunk past it), see DESIGN.md §4.
+template <int CAP, int QCAP, int NW>
+__global__ __launch_bounds__(NW * 64) void wfa_affine_kernel_v4(
+    const uint8_t* __restrict__ arena, const otg_align_task* __restrict__ tasks,
+    const uint32_t* __restrict__ todo, const uint32_t* __restrict__ n_todo_ptr, uint32_t n_todo_imm, int g,
+    int32_t* __restrict__ scores, const uint64_t* __restrict__ cig_off, uint32_t* __restrict__ cig_len,
+    uint8_t* __restrict__ cig_arena, uint64_t* __restrict__ cells,
+    uint32_t* __restrict__ ticket, uint32_t* __restrict__ n_overflow, uint32_t* __restrict__ overflow_list,
+    AffWs ws, const int32_t* __restrict__ bound)
+{
+  constexpr int xs = 2, oes = 4, es = 1;
+  __shared__ __attribute__((aligned(16))) int16_t s_I[CAP];
+  __shared__ __attribute__((aligned(16))) int16_t s_D[CAP];
+  __shared__ __attribute__((aligned(16))) int16_t s_M[4][CAP];
+  __shared__ uint16_t s_q[NW][QCAP];
+  __shared__ int s_misc[16];
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  volatile lds_i16* LI = (volatile lds_i16*)&s_I[0];
+  volatile lds_i16* LD = (volatile lds_i16*)&s_D[0];
+  volatile lds_u16* queue = (volatile lds_u16*)&s_q[wv][0];
+  volatile __attribute__((address_space(3))) int* misc = (volatile __attribute__((address_space(3))) int*)&s_misc[0];
+  uint8_t* my = ws.base + (size_t)blockIdx.x * ws.stride;
+  int64_t* rowtab = (int64_t*)(my + ws.off_rowtab);
+  uint8_t* rev = my + ws.off_rev;
+  uint8_t* slab = my + ws.off_slab;
+  const uint32_t n_todo = n_todo_ptr ? *n_todo_ptr : n_todo_imm;
+  constexpr int NUL16 = -32768;
+  auto sync = [&]() { if (NW > 1) __syncthreads(); };
+
+  for (;;) {
+    uint32_t tk;
+    if (NW > 1) {
+      if (wv == 0) misc[0] = (int)otg_wave_atomic_add(ticket, 1u);
+      __syncthreads();
+      tk = (uint32_t)misc[0];
+    } else tk = otg_wave_atomic_add(ticket, 1u);
+    if (tk >= n_todo) break;
+    const uint32_t ti = todo ? todo[tk] : tk;
+    const otg_align_task t = tasks[ti];
+    const uint8_t* P = arena + t.pattern_off;
+    const uint8_t* T = arena + t.text_off;
+    const int pl = (int)t.pattern_len, tl = (int)t.text_len;
+    const bool ef = t.endsfree != 0;
+    const int pef = t.pattern_end_free, tef = t.text_end_free;
+    const int kend = tl - pl;
+    const int U = bound[ti];
+    const int elo = kend - (ef ? tef : 0), ehi = kend + (ef ? pef : 0);
+    int lo0 = ef ? imax(-t.pattern_begin_free, -pl) : 0, hi0 = ef ? imin(t.text_begin_free, tl) : 0;
+    bool fail = U >= 0x40000000 || pl >= 32766 || tl >= 32766;
+    int kbase = 0;
+    if (!fail) {
+      lo0 = imax(lo0, elo - U); hi0 = imin(hi0, ehi + U);
+      // all kept cells lie in [wlo, whi]: the range of score s is within [lo0 - s, hi0 + s] and [elo - (U-s), ehi + (U-s)]
+      const int wlo = imax((lo0 + elo - U) >> 1, -pl) - 1, whi = imin((hi0 + ehi + U + 1) >> 1, tl) + 1;
+      kbase = wlo - 2;
+      if (hi0 < lo0 || whi - kbase + 4 >= CAP) fail = true;
+    }
+    size_t slab_top = 0;
+    int s_end = -1, k_end = 0;
+    // ranges of the last four scores (r1 = s-1 ... r4 = s-4) and of the previous I/D wavefronts; null = lo > hi
+    int r1lo = 1, r1hi = 0, r2lo = 1, r2hi = 0, r3lo = 1, r3hi = 0, r4lo = 1, r4hi = 0, idlo = 1, idhi = 0;
+    if (!fail) {
+      volatile lds_u32* f32 = (volatile lds_u32*)&s_I[0];     // s_I, s_D, s_M are contiguous? not guaranteed: fill each
+      volatile lds_u32* d32 = (volatile lds_u32*)&s_D[0];
+      volatile lds_u32* m32 = (volatile lds_u32*)&s_M[0][0];
+      for (int q = (int)threadIdx.x; q < CAP / 2; q += NW * 64) { f32[q] = 0x80008000u; d32[q] = 0x80008000u; }
+      for (int q = (int)threadIdx.x; q < 2 * CAP; q += NW * 64) m32[q] = 0x80008000u;
+    }
+    sync();
+
+    for (int s = 0; !fail; ++s) {
+      if (s >= ws.nrows) { fail = true; break; }
+      int lo, hi;
+      if (s == 0) { lo = lo0; hi = hi0; }
+      else {
+        lo = 1 << 30; hi = -(1 << 30);
+        if (r2hi >= r2lo) { lo = imin(lo, r2lo); hi = imax(hi, r2hi); }            // M[s-x]
+        if (r4hi >= r4lo) { lo = imin(lo, r4lo - 1); hi = imax(hi, r4hi + 1); }    // M[s-o-e]
+        if (idhi >= idlo) { lo = imin(lo, idlo - 1); hi = imax(hi, idhi + 1); }    // I/D[s-e]
+        if (lo < -pl) lo = -pl;
+        if (hi > tl) hi = tl;
+        if (hi >= lo) {
+          const int room = U - s;
+          lo = imax(lo, elo - room); hi = imin(hi, ehi + room);
+          if (room < 0 || hi < lo) { fail = true; break; }
+        }
+      }
+      r4lo = r3lo; r4hi = r3hi; r3lo = r2lo; r3hi = r2hi; r2lo = r1lo; r2hi = r1hi;
+      if (hi < lo) {   // unreachable score (only before the first gap-open score); nothing is written
+        r1lo = 1; r1hi = 0; idlo = 1; idhi = 0;
+        if (wv == 0) rowtab[s] = -1;
+        if (s > 2 * (oes + es * (pl + tl)) + 8) fail = true;
+        continue;
+      }
+      r1lo = lo; r1hi = hi;
+      if (lo - kbase < 2 || hi - kbase + 3 >= CAP) { fail = true; break; }
+      const int width = hi - lo + 1;
+      if (slab_top + (size_t)width > ws.slab_bytes) { fail = true; break; }
+      uint8_t* btrow = slab + slab_top - lo;
+      if (wv == 0) rowtab[s] = (int64_t)slab_top - lo;
+      slab_top += (size_t)width;
+      const int par = (s & 1) * 2, slot = (s >> 1) & 1;
+      volatile lds_i16* Mn = (volatile lds_i16*)&s_M[par + slot][0];          // M[s-4] on entry, M[s] on exit
+      volatile lds_i16* Mm = (volatile lds_i16*)&s_M[par + (slot ^ 1)][0];    // M[s-2]
+      const int nch = (width + 63) >> 6;
+      const int c0 = lo + 64 * ((nch * wv) / NW), c1 = lo + 64 * ((nch * (wv + 1)) / NW);
+      // values at the share boundaries that a neighbouring wave overwrites during its own sweep
+      int bI = NUL16, bD = NUL16, bMl = NUL16, bMr = NUL16;
+      {
+        const int jl0 = c0 - 1 - kbase, jr0 = imin(c1 - kbase, CAP - 1);
+        bI = (int)LI[jl0]; bMl = (int)Mn[jl0]; bD = (int)LD[jr0]; bMr = (int)Mn[jr0];
+      }
+      sync();
+      bool done = false;
+      int qn = 0;
+      auto drain = [&]() {
+        int pass = 0;
+        while (qn > 0) {
+          if (qn <= 4 && pass > 0) {
+            for (int e = 0; e < qn; ++e) {
+              const int kk = lo + (int)queue[e];
+              const int h = Mn[kk - kbase];
+              const int v = h - kk;
+              const int m = otg_wave_match(P, T, v, h, imin(pl - v, tl - h), lane);
+              Mn[kk - kbase] = (int16_t)(h + m);
+            }
+            qn = 0;
+            break;
+          }
+          int wq = 0;
+          for (int q0 = 0; q0 < qn; q0 += 64) {
+            const bool act = q0 + lane < qn;
+            int kk = 0, h = 0, v = 0;
+            bool more = false;
+            if (act) {
+              kk = lo + (int)queue[q0 + lane];
+              h = Mn[kk - kbase];
+              v = h - kk;
+              const int rem = imin(pl - v, tl - h);
+              int m, full;
+              if (pass == 0) {
+                const uint64_t xl = otg_load8(P + v) ^ otg_load8(T + h), xh = otg_load8(P + v + 8) ^ otg_load8(T + h + 8);
+                m = xl ? (__builtin_ctzll(xl) >> 3) : (xh ? 8 + (__builtin_ctzll(xh) >> 3) : 16);
+                m = imin(m, rem); full = 16;
+              } else { m = otg_match64(P, T, v, h, rem); full = 64; }
+              v += m; h += m;
+              more = (m == full) && v < pl && h < tl;
+              Mn[kk - kbase] = (int16_t)h;
+            }
+            const unsigned long long mm = __ballot(more);
+            if (more) {
+              const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+              queue[wq + rank] = (uint16_t)(kk - lo);
+            }
+            wq += __builtin_popcountll(mm);
+          }
+          qn = wq; ++pass;
+        }
+      };
+      // LDS operands one chunk ahead (clamped index: lanes past the window never store)
+      int jn = imin(c0 + lane - kbase, CAP - 2);
+      int n_iold = LI[jn], n_dx = LD[jn + 1], n_mo = Mn[jn], n_mor = Mn[jn + 1], n_mm = Mm[jn];
+      int carryI = bI, carryMo = bMl;
+      bool p_pending = false, p_in = false, p_valid = false, p_probe = false;
+      int p_k = 0, p_h = 0, p_v = 0;
+      uint64_t p_a = 0, p_b = 0;
+      auto finish = [&]() {
+        int h = p_h, v = p_v;
+        bool more = false;
+        if (p_probe) {
+          const uint64_t xx = p_a ^ p_b;
+          int m = xx ? (__builtin_ctzll(xx) >> 3) : 8;
+          const int rem = imin(pl - v, tl - h);
+          m = imin(m, rem);
+          v += m; h += m;
+          more = (m == 8) && v < pl && h < tl;
+        }
+        if (p_in) Mn[p_k - kbase] = (int16_t)(p_valid ? h : NUL16);
+        const unsigned long long mq = __ballot(more);
+        if (more) {
+          const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mq, 0u));
+          queue[qn + rank] = (uint16_t)(p_k - lo);
+        }
+        qn += __builtin_popcountll(mq);
+      };
+      for (int c = c0; c < c1; c += 64) {
+        const int k = c + lane;
+        const int jl = k - kbase;
+        const bool in = k <= hi;
+        const int iold = n_iold;                              // I[s-1][k]
+        int dx = n_dx;                                        // D[s-1][k+1]
+        const int mo = n_mo;                                  // M[s-o-e][k]
+        int dop = n_mor;                                      // M[s-o-e][k+1]
+        const int mm = n_mm;                                  // M[s-x][k]
+        if (lane == 63 && c + 64 >= c1) { dx = bD; dop = bMr; }   // first diagonal of the next wave's share
+        jn = imin(jl + 64, CAP - 2);
+        n_iold = LI[jn]; n_dx = LD[jn + 1]; n_mo = Mn[jn]; n_mor = Mn[jn + 1]; n_mm = Mm[jn];
+        int ix = dpp_shr1(iold);                              // I[s-1][k-1]
+        if (lane == 0) ix = carryI;
+        carryI = __builtin_amdgcn_readlane(iold, 63);
+        int io = dpp_shr1(mo);                                // M[s-o-e][k-1]
+        if (lane == 0) io = carryMo;
+        carryMo = __builtin_amdgcn_readlane(mo, 63);
+        uint32_t bits = 0;
+        int ins, del;
+        if (ix >= io) { ins = ix; bits |= 4u; } else ins = io;
+        ins += 1;
+        if (dx >= dop) { del = dx; bits |= 8u; } else del = dop;
+        const int mis = mm + 1;
+        int mx = imax(del, imax(mis, ins));
+        uint32_t org = 0;
+        if (mx == ins) org = 2;
+        if (mx == del) org = 1;
+        if (mx == mis) org = 0;
+        bits |= org;
+        if (s == 0) { mx = k > 0 ? k : 0; ins = NUL16; del = NUL16; bits = 0; }   // selects, not a branch
+        const int h = mx, v = mx - k;
+        const bool valid = in && mx >= 0 && h <= tl && v <= pl;
+        const bool probe = valid && v < pl && h < tl;
+        if (p_pending) finish();                              // retire the previous chunk (its probe was issued one iteration ago)
+        uint64_t a, b;
+        { const int vc = imin(imax(v, 0), pl), hc = imin(imax(h, 0), tl);      // clamped: always inside arena + slack
+          a = otg_load8(P + vc); b = otg_load8(T + hc); }
+        if (in) {
+          LI[jl] = (int16_t)(ins < 0 ? NUL16 : ins);
+          LD[jl] = (int16_t)(del < 0 ? NUL16 : del);
+          btrow[k] = (uint8_t)bits;
+        }
+        p_pending = true; p_in = in; p_valid = valid; p_probe = probe; p_k = k; p_h = h; p_v = v; p_a = a; p_b = b;
+        if (qn + 128 > QCAP) { finish(); p_pending = false; drain(); }
+      }
+      if (p_pending) finish();
+      drain();
+      idlo = s == 0 ? 1 : lo; idhi = s == 0 ? 0 : hi;
+      // termination: the first diagonal (ascending) whose fully extended offset satisfies the end condition
+      int cand = 0x7fffffff;
+      if (!ef) {
+        if (kend >= c0 && kend < c1 && kend <= hi) { const int x = Mn[kend - kbase]; if (x >= tl) cand = kend; }
+      } else {
+        for (int c = c0; c < c1 && cand == 0x7fffffff; c += 64) {
+          const int k = c + lane;
+          bool fin = false;
+          if (k <= hi) {
+            const int h = Mn[k - kbase];
+            const int v = h - k;
+            fin = h >= 0 && ((h >= tl && pl - v <= pef) || (v >= pl && tl - h <= tef));
+          }
+          const unsigned long long fm = __ballot(fin);
+          if (fm) cand = c + (int)__builtin_ctzll(fm);
+        }
+      }
+      if (NW > 1) {
+        misc[4 + wv] = cand;
+        __syncthreads();
+        int best = 0x7fffffff;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { const int x = misc[4 + w]; best = x < best ? x : best; }
+        cand = best;
+      }
+      if (cand != 0x7fffffff) { done = true; s_end = s; k_end = cand; }
+      if (done) break;
+    }
+    sync();
+
+    if (wv != 0) continue;            // wave 0 reports / unpacks; the others wait at the next ticket barrier
+    if (fail || s_end < 0) {
+      if (overflow_list) { const uint32_t q = otg_wave_atomic_add(n_overflow, 1u); overflow_list[q] = ti; }
+      else { scores[ti] = -1; cig_len[ti] = 0; }
+      continue;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");      // provenance bytes of the other waves (same CU, through L2)
+    if (!backtrace_unpack(P, pl, T, tl, s_end, k_end, xs, oes, es, rowtab, slab, rev, ws.rev_cap, cig_arena + cig_off[ti], lane, &scores[ti], &cig_len[ti], g)) continue;
+    if (cells) cells[ti] = affine_cells(t, xs, oes, s_end);
   }
 }
 
@@ -658,9 +1226,10 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
   const int xs = x / g, oes = (o + e) / g, es = e / g;
   if (std::max(xs, oes) + 1 > 64 || es + 1 > 64) return otg_fail(ctx, OTG_ERR_ARG, "affine penalties too large after gcd reduction");
   uint32_t* cnt = (uint32_t*)otg_slot(ctx, SLOT_COUNTERS, 64 * sizeof(uint32_t));
-  uint32_t* todo = (uint32_t*)otg_slot(ctx, SLOT_TODO, 2 * (size_t)n_tasks * sizeof(uint32_t));
+  uint32_t* todo = (uint32_t*)otg_slot(ctx, SLOT_TODO, 4 * (size_t)n_tasks * sizeof(uint32_t));
   if (!cnt || !todo) return OTG_ERR_HIP;
-  HIP_TRY(ctx, hipMemsetAsync(cnt + 8, 0, 8 * sizeof(uint32_t), ctx->stream));   // tickets / overflow counters of the three tiers
+  HIP_TRY(ctx, hipMemsetAsync(cnt + 8, 0, 8 * sizeof(uint32_t), ctx->stream));   // tickets / overflow counters of the tiers
+  HIP_TRY(ctx, hipMemsetAsync(cnt + 24, 0, 8 * sizeof(uint32_t), ctx->stream));
 
   const size_t maxlen = ctx->max_seq_len;
   AffWs ws;
@@ -701,22 +1270,74 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
   size_t slabC = std::min<size_t>((size_t)2 * maxlen * (size_t)(ws.nrows), budget / (gridC * WPB));
   if (slabC > ws.off_slab + 256) slabC -= ws.off_slab + 256;
   wsC.slab_bytes = slabC & ~(size_t)255; wsC.stride = wsC.off_slab + wsC.slab_bytes;
-  const size_t need = std::max(std::max(wsA.stride * wavesA, wsB.stride * wavesB), wsC.stride * (size_t)gridC * WPB);
+  // LDS-resident tiers (v4): no rings, provenance slab for a diamond of at most CAP diagonals
+  auto lds_ws = [&](int cap, uint32_t& blocks) {
+    AffWs w = ws;
+    w.off_rowtab = 0;
+    w.off_rev = ((size_t)ws.nrows * sizeof(int64_t) + 255) & ~(size_t)255;
+    w.off_slab = (w.off_rev + ws.rev_cap + 255) & ~(size_t)255;
+    size_t slab = (size_t)cap * (size_t)cap * 5 / 8 + (1 << 16);
+    while (blocks > 1 && (w.off_slab + slab) * (size_t)blocks > budget) blocks = (blocks + 1) / 2;
+    w.slab_bytes = slab & ~(size_t)255; w.stride = w.off_slab + w.slab_bytes;
+    return w;
+  };
+  uint32_t blocksS = std::min<uint32_t>((uint32_t)ctx->n_cu * 12, n_tasks), blocksM = std::min<uint32_t>((uint32_t)ctx->n_cu * 6, n_tasks);
+  AffWs wsS = lds_ws(1024, blocksS), wsM = lds_ws(2048, blocksM);
+  const size_t need = std::max(std::max(std::max(wsA.stride * wavesA, wsB.stride * wavesB), wsC.stride * (size_t)gridC * WPB),
+                               std::max(wsS.stride * blocksS, wsM.stride * blocksM));
   uint8_t* wsp = (uint8_t*)otg_slot(ctx, SLOT_WF_WS, need);
   if (!wsp) return OTG_ERR_HIP;
-  wsA.base = wsB.base = wsC.base = wsp;
+  wsA.base = wsB.base = wsC.base = wsS.base = wsM.base = wsp;
   uint32_t* listA = todo;                  // overflow of tier A
   uint32_t* listB = todo + n_tasks;        // overflow of tier B
+  uint32_t* listS = todo + 2 * (size_t)n_tasks;   // overflow of the LDS tier with 1024 diagonals
+  uint32_t* listM = todo + 3 * (size_t)n_tasks;   // ... 2048 diagonals
   static const bool no_v3 = getenv("OTG_NO_AFFINE_V3") != nullptr;
   if (kernel_ms) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   const uint32_t* cur = d_todo; const uint32_t* cur_n = d_n_todo; uint32_t cur_imm = n_tasks;
+  const int32_t* d_bound_dbg = nullptr;
   if (!no_v3 && es == 1) {
+    // score bound pass (register-resident banded run) for the default (4,6,2) -> (2,4,1) penalties
+    static const bool no_bound = getenv("OTG_NO_AFFINE_BOUND") != nullptr;
+    int32_t* d_bound = nullptr;
+    if (!no_bound && xs == 2 && oes == 4) {
+      d_bound = (int32_t*)otg_slot(ctx, SLOT_BT_POOL, (size_t)n_tasks * sizeof(int32_t));
+      if (!d_bound) return OTG_ERR_HIP;
+      const uint32_t want = (n_tasks + 3) / 4;
+      const uint32_t gridU = std::min<uint32_t>((uint32_t)ctx->n_cu * 8, want);
+      static const bool wide_band = getenv("OTG_AFFINE_BOUND_STATIC") != nullptr;
+      if (wide_band)
+        hipLaunchKernelGGL((wfa_affine_bound_kernel<4, 2, 4>), dim3(gridU), dim3(256), 0, ctx->stream, d_arena, d_tasks,
+                           d_todo, d_n_todo, n_tasks, d_bound, cnt + 14);
+      else
+        hipLaunchKernelGGL((wfa_affine_bound1_kernel<2, 4>), dim3(gridU), dim3(256), 0, ctx->stream, d_arena, d_tasks,
+                           d_todo, d_n_todo, n_tasks, d_bound, cnt + 14);
+      d_bound_dbg = d_bound;
+    }
+    const uint32_t* inA = d_todo; const uint32_t* inA_n = d_n_todo; uint32_t inA_imm = n_tasks;
+    static const bool no_v4 = getenv("OTG_NO_AFFINE_V4") != nullptr;
+    if (d_bound && !no_v4) {
+      static const int nws = getenv("OTG_V4_NWS") ? atoi(getenv("OTG_V4_NWS")) : 2;
+      static const int nwm = getenv("OTG_V4_NWM") ? atoi(getenv("OTG_V4_NWM")) : 2;
+#define OTG_V4_LAUNCH(CAPV, NWV, BLOCKS, TODO, NTODO, IMM, TICK, OVF, LIST, WS)                                              \
+      hipLaunchKernelGGL((wfa_affine_kernel_v4<CAPV, 256, NWV>), dim3(BLOCKS), dim3(NWV * 64), 0, ctx->stream, d_arena, d_tasks, \
+                         TODO, NTODO, IMM, g, d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, TICK, OVF, LIST, WS,       \
+                         (const int32_t*)d_bound)
+      if (nws == 1) OTG_V4_LAUNCH(1024, 1, blocksS, d_todo, d_n_todo, n_tasks, cnt + 24, cnt + 25, listS, wsS);
+      else if (nws == 4) OTG_V4_LAUNCH(1024, 4, blocksS, d_todo, d_n_todo, n_tasks, cnt + 24, cnt + 25, listS, wsS);
+      else OTG_V4_LAUNCH(1024, 2, blocksS, d_todo, d_n_todo, n_tasks, cnt + 24, cnt + 25, listS, wsS);
+      if (nwm == 1) OTG_V4_LAUNCH(2048, 1, blocksM, (const uint32_t*)listS, (const uint32_t*)(cnt + 25), 0u, cnt + 26, cnt + 27, listM, wsM);
+      else if (nwm == 4) OTG_V4_LAUNCH(2048, 4, blocksM, (const uint32_t*)listS, (const uint32_t*)(cnt + 25), 0u, cnt + 26, cnt + 27, listM, wsM);
+      else OTG_V4_LAUNCH(2048, 2, blocksM, (const uint32_t*)listS, (const uint32_t*)(cnt + 25), 0u, cnt + 26, cnt + 27, listM, wsM);
+#undef OTG_V4_LAUNCH
+      inA = listM; inA_n = cnt + 27; inA_imm = 0;
+    }
     hipLaunchKernelGGL((wfa_affine_kernel_v3<4096, 512, NWA>), dim3(wavesA), dim3(NWA * 64), 0, ctx->stream, d_arena, d_tasks,
-                       d_todo, d_n_todo, n_tasks, xs, oes, es, g, d_scores, d_cig_off, d_cig_len,
-                       d_cig_arena, d_cells, cnt + 8, cnt + 9, listA, wsA);
+                       inA, inA_n, inA_imm, xs, oes, es, g, d_scores, d_cig_off, d_cig_len,
+                       d_cig_arena, d_cells, cnt + 8, cnt + 9, listA, wsA, (const int32_t*)d_bound);
     hipLaunchKernelGGL((wfa_affine_kernel_v3<12288, 512, NWA>), dim3(wavesB), dim3(NWA * 64), 0, ctx->stream, d_arena, d_tasks,
                        (const uint32_t*)listA, (const uint32_t*)(cnt + 9), 0u, xs, oes, es, g, d_scores, d_cig_off, d_cig_len,
-                       d_cig_arena, d_cells, cnt + 10, cnt + 11, listB, wsB);
+                       d_cig_arena, d_cells, cnt + 10, cnt + 11, listB, wsB, (const int32_t*)d_bound);
     cur = listB; cur_n = cnt + 11; cur_imm = 0;
   }
   if (kernel_ms) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
@@ -724,6 +1345,48 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
                      cur, cur_n, cur_imm, xs, oes, es, g, d_scores, d_cig_off, d_cig_len,
                      d_cig_arena, d_cells, cnt + 12, cnt + 13, (uint32_t*)nullptr, wsC);
   HIP_TRY(ctx, hipGetLastError());
+  if (getenv("OTG_DEBUG")) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    uint32_t h[32];
+    HIP_TRY(ctx, hipMemcpy(h, cnt, sizeof(h), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[otg] affine: LDS tiers overflow %u / %u, tier A overflow %u, tier B overflow %u\n", h[25], h[27], h[9], h[11]);
+    if (d_bound_dbg) {
+      std::vector<int32_t> hb(n_tasks), hs(n_tasks);
+      HIP_TRY(ctx, hipMemcpy(hb.data(), d_bound_dbg, (size_t)n_tasks * 4, hipMemcpyDeviceToHost));
+      HIP_TRY(ctx, hipMemcpy(hs.data(), d_scores, (size_t)n_tasks * 4, hipMemcpyDeviceToHost));
+      std::vector<otg_align_task> ht(n_tasks);
+      HIP_TRY(ctx, hipMemcpy(ht.data(), d_tasks, (size_t)n_tasks * sizeof(otg_align_task), hipMemcpyDeviceToHost));
+      uint64_t n_inf = 0, n_eq = 0, n_fin = 0, n_inf_band_ok = 0; double su = 0, ss = 0;
+      std::vector<uint32_t> idx;
+      if (d_todo) {
+        uint32_t nt = 0;
+        HIP_TRY(ctx, hipMemcpy(&nt, d_n_todo, 4, hipMemcpyDeviceToHost));
+        idx.resize(nt);
+        HIP_TRY(ctx, hipMemcpy(idx.data(), d_todo, (size_t)nt * 4, hipMemcpyDeviceToHost));
+      } else { idx.resize(n_tasks); for (uint32_t i = 0; i < n_tasks; ++i) idx[i] = i; }
+      uint64_t hist[8] = {0};   // excess U - s: 0, 1-2, 3-5, 6-10, 11-20, 21-50, 51-100, >100
+      for (uint32_t i : idx) {
+        if (hs[i] < 0) continue;
+        if (hb[i] < 0x40000000) { const int ex = hb[i] - hs[i] / g; ++hist[ex <= 0 ? 0 : ex <= 2 ? 1 : ex <= 5 ? 2 : ex <= 10 ? 3 : ex <= 20 ? 4 : ex <= 50 ? 5 : ex <= 100 ? 6 : 7]; }
+        if (hb[i] >= 0x40000000) {
+          ++n_inf;
+          const otg_align_task& t = ht[i];
+          const int pl = (int)t.pattern_len, tl = (int)t.text_len; const bool ef = t.endsfree != 0;
+          const int pef = ef ? t.pattern_end_free : 0, tef = ef ? t.text_end_free : 0, kend = tl - pl;
+          const int lo0 = ef ? std::max(-(int)t.pattern_begin_free, -pl) : 0, hi0 = ef ? std::min((int)t.text_begin_free, tl) : 0;
+          const int nl = std::min(lo0, kend - tef), nh = std::max(hi0, kend + pef);
+          if (nh - nl + 1 + 64 <= 256) { if (n_inf_band_ok < 5) fprintf(stderr, "[otg]   unbounded although band ok: pl %d tl %d ef %d pbf %d pef %d tbf %d tef %d score %d\n", pl, tl, (int)ef, (int)t.pattern_begin_free, pef, (int)t.text_begin_free, tef, hs[i]); ++n_inf_band_ok; }
+          continue;
+        }
+        ++n_fin; su += hb[i]; ss += hs[i] / g; if (hb[i] == hs[i] / g) ++n_eq;
+      }
+      fprintf(stderr, "[otg] affine bound: %llu unbounded, %llu bounded (%llu tight), %llu unbounded with band ok, mean U %.1f mean score %.1f (units of g)\n",
+              (unsigned long long)n_inf, (unsigned long long)n_fin, (unsigned long long)n_eq, (unsigned long long)n_inf_band_ok, n_fin ? su / n_fin : 0.0, n_fin ? ss / n_fin : 0.0);
+      fprintf(stderr, "[otg] affine bound excess histogram (0, 1-2, 3-5, 6-10, 11-20, 21-50, 51-100, >100): %llu %llu %llu %llu %llu %llu %llu %llu\n",
+              (unsigned long long)hist[0], (unsigned long long)hist[1], (unsigned long long)hist[2], (unsigned long long)hist[3],
+              (unsigned long long)hist[4], (unsigned long long)hist[5], (unsigned long long)hist[6], (unsigned long long)hist[7]);
+    }
+  }
   if (kernel_ms) {
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
     float ms = 0;
