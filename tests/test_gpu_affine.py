@@ -76,3 +76,37 @@ def test_affine_cigar_valid_full_size(gpu, oracle):
     assert oracle.cigar_score(a, b, gc[0]) == gs[0]
     assert gc[0].count(b"M") + gc[0].count(b"X") + gc[0].count(b"D") == len(a)
     assert gc[0].count(b"M") + gc[0].count(b"X") + gc[0].count(b"I") == len(b)
+
+
+def test_affine_bounded_tandem_repeats(gpu, oracle):
+    """The default penalties run a banded score-bound pass first and the exact pass only inside the cells that can
+    still reach the end within that bound.  Cases built to stress it: tandem repeats with copy-number changes
+    (the optimal path jumps diagonals, the band may lose it -> loose bound), long end gaps, wide free ends."""
+    rng = np.random.default_rng(25)
+    pairs, forms = [], []
+    for i in range(160):
+        m = int(rng.integers(2, 40))
+        motif = rand_seq(rng, m)
+        n = int(rng.integers(300, 1600)) // m + 1
+        a = rand_seq(rng, 60) + motif * n + rand_seq(rng, 60)
+        dn = int(rng.integers(0, max(2, 200 // m)))
+        n2 = max(1, n + (dn if i % 2 else -dn))
+        b = a[:60] + motif * n2 + a[-60:]
+        a = mutate(rng, a, [0.01, 0.05, 0.1][i % 3])
+        b = mutate(rng, b, [0.01, 0.05, 0.1][(i // 3) % 3])
+        f = None
+        k = i % 8
+        if k == 1: f = (0, len(a) // 2, 0, 0)          # pattern end free
+        elif k == 2: f = (0, 0, 0, len(b) // 2)        # text end free
+        elif k == 3: f = (len(a) // 3, 0, 0, 0)        # pattern begin free
+        elif k == 4: f = (0, 0, len(b) // 3, 0)        # text begin free
+        elif k == 5: f = (7, 9, 5, 3)
+        pairs.append((a, b))
+        forms.append(f)
+    arena, tasks = pair_tasks(pairs, forms)
+    gs, gc, gcells = gpu.affine_align_batch(arena, tasks, want_cells=True)
+    es, ec, ecells = oracle.affine_align_batch(arena, tasks, want_cells=True)
+    assert np.array_equal(gs, es)
+    bad = [i for i in range(len(pairs)) if gc[i] != ec[i]]
+    assert not bad, bad[:10]
+    assert np.array_equal(gcells, ecells)
