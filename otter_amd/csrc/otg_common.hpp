@@ -78,6 +78,20 @@ __device__ __forceinline__ uint32_t otg_wave_atomic_add(uint32_t* ctr, uint32_t 
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
 }
 
+__device__ __forceinline__ int otg_imax(int a, int b) { return a > b ? a : b; }
+// Maximum over the 64 lanes (DPP row shifts + row broadcasts), returned wave-uniform.
+__device__ __forceinline__ int otg_wave_max_i32(int v)
+{
+  constexpr int NEG = -2147483647 - 1;
+  v = otg_imax(v, __builtin_amdgcn_update_dpp(NEG, v, 0x111, 0xf, 0xf, false));   // row_shr:1
+  v = otg_imax(v, __builtin_amdgcn_update_dpp(NEG, v, 0x112, 0xf, 0xf, false));   // row_shr:2
+  v = otg_imax(v, __builtin_amdgcn_update_dpp(NEG, v, 0x114, 0xf, 0xf, false));   // row_shr:4
+  v = otg_imax(v, __builtin_amdgcn_update_dpp(NEG, v, 0x118, 0xf, 0xf, false));   // row_shr:8  -> lane 15 of each row = row max
+  v = otg_imax(v, __builtin_amdgcn_update_dpp(NEG, v, 0x142, 0xa, 0xf, false));   // row_bcast:15 into rows 1, 3
+  v = otg_imax(v, __builtin_amdgcn_update_dpp(NEG, v, 0x143, 0xc, 0xf, false));   // row_bcast:31 into rows 2, 3
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
 // ---- match-run extension helpers shared by the wavefront kernels -------------------------------------
 __device__ __forceinline__ uint64_t otg_load8(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
 

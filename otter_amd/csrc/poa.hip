@@ -19,6 +19,7 @@
 // node initialisation is a separate fully parallel kernel.
 #include "otg_common.hpp"
 #include <vector>
+#include <cstdlib>
 #include <algorithm>
 
 namespace {
@@ -227,6 +228,205 @@ __global__ __launch_bounds__(64) void poa_graph_kernel(PoaDev P)
   P.out_len[g] = len; P.out_start[g] = startpos; P.status[g] = status;
 }
 
+// v2 mapping: one WAVE per graph.  Everything that is sequential in the reference stays sequential but runs
+// wave-uniform (all lanes execute the same instruction on the same address: one memory request, no divergence);
+// the bulk of the threading is data-parallel: op strings are read 64 ops at a time, positions come from ballot
+// prefix counts, and an 'M' that follows an 'M' only bumps the implicit backbone edge ref-1 -> ref (distinct
+// addresses per lane), so only the ops around mismatches and gaps (15-35 % for ONT reads) take the serial path.
+// One wave owns a graph, so plain read-modify-writes replace the atomics of v1.
+__global__ __launch_bounds__(256) void poa_graph_wave_kernel(PoaDev P)
+{
+  const int lane = threadIdx.x & 63;
+  const uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= P.n_graphs) return;
+  const otg_poa_graph G = P.graphs[g];
+  const uint64_t no = P.node_off[g], eo = P.edge_off[g], so = P.start_off[g];
+  const uint32_t node_cap = (uint32_t)(P.node_off[g + 1] - no), edge_cap = (uint32_t)(P.edge_off[g + 1] - eo);
+  uint8_t* nbase = P.node_base + no; uint8_t* isend = P.is_end + no; uint8_t* hdef = P.hdef + no;
+  int32_t* head = P.head + no; int32_t* tail = P.tail + no; uint32_t* indeg = P.indeg + no; uint32_t* bbc = P.bb_cnt + no;
+  float* hw = P.hw + no; int32_t* pred = P.pred + no; uint32_t* queue = P.queue + no;
+  uint32_t* esink = P.e_sink + eo; float* ew = P.e_w + eo; int32_t* enext = P.e_next + eo;
+  uint32_t* starts = P.start_list + so;
+  const int B = (int)G.backbone_len;
+  uint32_t n_nodes = (uint32_t)B, n_edges = 0, n_start = B >= 2 ? 1u : 0u;
+  int status = 0;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+
+  auto new_node = [&](uint8_t base) -> uint32_t {
+    if (n_nodes >= node_cap) { status = 1; return n_nodes - 1; }
+    nbase[n_nodes] = base;
+    return n_nodes++;
+  };
+  auto insert_edge = [&](uint32_t src, uint32_t sink) {     // src/anppoa.hpp:96-110
+    if ((int)src < B - 1 && sink == src + 1) { bbc[src] = bbc[src] + 1u; return; }
+    for (int e = head[src]; e >= 0; e = enext[e]) if (esink[e] == sink) { ew[e] = ew[e] + 1.0f; return; }
+    if (n_edges >= edge_cap) { status = 2; return; }
+    const int e = (int)n_edges++;
+    esink[e] = sink; ew[e] = 1.0f; enext[e] = -1;
+    const int tl_ = tail[src];
+    if (tl_ >= 0) enext[tl_] = e; else head[src] = e;
+    tail[src] = e;
+    indeg[sink] = indeg[sink] + 1u;
+  };
+  auto alt_step = [&](uint32_t prev, uint8_t tc) -> uint32_t {   // :162-186 / :206-233
+    for (int e = head[prev]; e >= 0; e = enext[e]) {
+      const uint32_t sk = esink[e];
+      if ((int)sk >= B && nbase[sk] == tc) { ew[e] = ew[e] + 1.0f; return sk; }
+    }
+    const uint32_t nn = new_node(tc);
+    if (!status) insert_edge(prev, nn);
+    return nn;
+  };
+
+  // ---- insert_alignment for every member, in order (src/anppoa.hpp:112-241)
+  for (uint32_t mi = 0; mi < G.n_members && !status; ++mi) {
+    const otg_poa_member M = P.members[G.first_member + mi];
+    const uint8_t* seq = P.seq_arena + M.seq_off;
+    const uint8_t* cig = P.cig_arena + M.cigar_off;
+    const int clen = (int)M.cigar_len, slen = (int)M.seq_len;
+    const bool spl = M.spanning_l != 0, spr = M.spanning_r != 0;
+    int prev = 0, ref_i = 0, tgt = 0, ci = 0;
+    bool first = true;
+    if (!spl) {
+      first = false;
+      bool stop = false;
+      while (ci < clen && !stop) {     // leading gap ops of a read that does not span the left flank
+        const int i = ci + lane;
+        const uint8_t c = i < clen ? cig[i] : 0;
+        const unsigned long long notdi = ~__ballot(c == 'D' || c == 'I');
+        const int upto = notdi ? (int)__builtin_ctzll(notdi) : 64;
+        const unsigned long long below = upto >= 64 ? ~0ull : ((1ull << upto) - 1ull);
+        const int nD = __builtin_popcountll(__ballot(c == 'D') & below), nI = __builtin_popcountll(__ballot(c == 'I') & below);
+        ref_i += nD; tgt += nI;
+        if (nD) prev = ref_i;
+        ci += upto; stop = upto < 64;
+      }
+    }
+    int lastop = 0;                    // op just before position ci in the main phase (0 = none)
+    while (ci < clen && !status) {
+      const int i = ci + lane;
+      const bool valid = i < clen;
+      const int c = valid ? (int)cig[i] : 0;
+      int pc = __shfl_up(c, 1);
+      if (lane == 0) pc = lastop;
+      const bool isM = c == 'M', isX = c == 'X', isD = c == 'D', isI = c == 'I';
+      const unsigned long long mMXD = __ballot(valid && (isM || isX || isD)), mMXI = __ballot(valid && (isM || isX || isI));
+      const int ref_at = ref_i + __builtin_popcountll(mMXD & lt), tgt_at = tgt + __builtin_popcountll(mMXI & lt);
+      // 'M' after 'M': prev == ref-1, not the first op -> insert_edge(ref-1, ref) is the implicit backbone edge
+      const bool simple = valid && isM && pc == 'M' && ref_at < B;
+      if (simple) {
+        bbc[ref_at - 1] = bbc[ref_at - 1] + 1u;
+        if (B - (ref_at + 1) <= 10 && spr && (uint32_t)ref_at < node_cap) isend[ref_at] = 1;
+      }
+      unsigned long long todo = __ballot(valid && !simple);
+      while (todo && !status) {
+        const int l = (int)__builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const int op = __builtin_amdgcn_readlane(c, l), pop = __builtin_amdgcn_readlane(pc, l);
+        const int r = __builtin_amdgcn_readlane(ref_at, l), tg = __builtin_amdgcn_readlane(tgt_at, l);
+        if (pop == 'M') { prev = r - 1; first = false; }
+        int ref_after = r;
+        if (op == 'M') {
+          if (first || prev == r) first = false;
+          else if ((uint32_t)prev >= n_nodes) { status = 3; break; }    // the reference indexes edges[] out of range here
+          else insert_edge((uint32_t)prev, (uint32_t)r);
+          prev = r; ref_after = r + 1;
+        } else if (op == 'X') {
+          const uint8_t tc = tg < slen ? seq[tg] : 0;
+          if (first) {
+            bool need_new = true;
+            for (uint32_t q = 0; q < n_start; ++q) if (nbase[starts[q]] == tc) { need_new = false; break; }
+            if (need_new) { prev = (int)new_node(tc); starts[n_start++] = (uint32_t)prev; }
+            first = false;
+          } else if ((uint32_t)prev >= n_nodes) { status = 3; break; }
+          else prev = (int)alt_step((uint32_t)prev, tc);
+          ref_after = r + 1;
+        } else if (op == 'D') {
+          ref_after = r + 1;
+          if (first) prev = ref_after;
+        } else if (op == 'I') {
+          const uint8_t tc = tg < slen ? seq[tg] : 0;
+          if (first) { prev = (int)new_node(tc); starts[n_start++] = (uint32_t)prev; first = false; }
+          else if ((uint32_t)prev >= n_nodes) { status = 3; break; }
+          else prev = (int)alt_step((uint32_t)prev, tc);
+        }
+        if (B - ref_after <= 10 && spr && (uint32_t)prev < node_cap) isend[prev] = 1;   // ids not yet created are remembered too
+      }
+      const int nvalid = clen - ci < 64 ? clen - ci : 64;
+      lastop = __builtin_amdgcn_readlane(c, nvalid - 1);
+      ref_i += __builtin_popcountll(mMXD); tgt += __builtin_popcountll(mMXI);
+      if (lastop == 'M') { prev = ref_i - 1; first = false; }
+      ci += 64;
+    }
+  }
+  __threadfence();
+
+  // ---- heaviest path: Kahn sweep pushing (weight, source) along out-edges (wave-uniform)
+  const float c_ = G.c, t_ = G.t;
+  auto damp = [&](float w) -> float {                      // adjust_weights :243-252
+    const float t_applied = t_ * w;
+    const float final_weight = c_ > t_applied ? c_ : t_applied;
+    return w - final_weight;
+  };
+  auto relax = [&](uint32_t u, uint32_t v, float w) {
+    const float cand = hw[u] + w;
+    if (!hdef[v]) { hdef[v] = 1; hw[v] = cand; pred[v] = (int32_t)u; }
+    else if (cand > hw[v] || (cand == hw[v] && (int32_t)u < pred[v])) { hw[v] = cand; pred[v] = (int32_t)u; }
+  };
+  uint32_t qh = 0, qt = 0;
+  if (!status) {
+    for (uint32_t b0 = 0; b0 < n_nodes; b0 += 64) {
+      const uint32_t i = b0 + (uint32_t)lane;
+      const bool z = i < n_nodes && indeg[i] == 0;
+      const unsigned long long zm = __ballot(z);
+      if (z) queue[qt + __builtin_popcountll(zm & lt)] = i;
+      qt += (uint32_t)__builtin_popcountll(zm);
+    }
+    while (qh < qt) {
+      const uint32_t u = queue[qh++];
+      if ((int)u < B - 1) {
+        const uint32_t v = u + 1;
+        relax(u, v, damp(1.0f + (float)bbc[u]));
+        const uint32_t left = indeg[v] - 1;
+        indeg[v] = left;
+        if (left == 0) queue[qt++] = v;
+      }
+      for (int e = head[u]; e >= 0; e = enext[e]) {
+        const uint32_t v = esink[e];
+        relax(u, v, damp(ew[e]));
+        const uint32_t left = indeg[v] - 1;
+        indeg[v] = left;
+        if (left == 0) queue[qt++] = v;
+      }
+    }
+    if (qt != n_nodes) status = 4;    // cycle: the reference would never return
+  }
+  // ---- pick the end node (:346-367: first strictly heaviest in ascending id) and emit the path (:373-378)
+  uint32_t len = 0, startpos = 0;
+  if (!status && n_nodes > 0) {
+    float bw = 0.0f; uint32_t bi = 0xffffffffu;
+    for (uint32_t i = (uint32_t)lane; i < n_nodes; i += 64) {
+      if (isend[i]) { const float w = hw[i]; if (bi == 0xffffffffu || w > bw) { bw = w; bi = i; } }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ow = __shfl_xor(bw, off); const uint32_t oi = (uint32_t)__shfl_xor((int)bi, off);
+      if (oi != 0xffffffffu && (bi == 0xffffffffu || ow > bw || (ow == bw && oi < bi))) { bw = ow; bi = oi; }
+    }
+    const uint32_t h_node = bi == 0xffffffffu ? 0u : bi;
+    uint8_t* out = P.out_arena + P.out_off[g];
+    const uint32_t cap = node_cap;
+    uint32_t pos = cap;
+    int32_t cur = (int32_t)h_node;
+    while (cur >= 0 && pos > 0) {
+      const uint8_t b = nbase[cur];
+      if (b) out[--pos] = b;
+      cur = pred[cur];
+    }
+    startpos = pos; len = cap - pos;
+  }
+  P.out_len[g] = len; P.out_start[g] = startpos; P.status[g] = status;
+}
+
 } // namespace
 
 // h_graphs: host copy (layout sizes); d_* device copies.  Outputs (device): consensus g starts at
@@ -295,7 +495,9 @@ int otg_launch_poa(otg_ctx* ctx, const uint8_t* d_seq_arena, const uint8_t* d_ci
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // host vectors go out of scope after return
   uint32_t gi = n_graphs < (uint32_t)ctx->n_cu * 8 ? n_graphs : (uint32_t)ctx->n_cu * 8;
   hipLaunchKernelGGL(poa_init_kernel, dim3(gi), dim3(256), 0, ctx->stream, P);
-  hipLaunchKernelGGL(poa_graph_kernel, dim3((n_graphs + 63) / 64), dim3(64), 0, ctx->stream, P);
+  static const bool thread_per_graph = getenv("OTG_POA_THREAD") != nullptr;
+  if (thread_per_graph) hipLaunchKernelGGL(poa_graph_kernel, dim3((n_graphs + 63) / 64), dim3(64), 0, ctx->stream, P);
+  else hipLaunchKernelGGL(poa_graph_wave_kernel, dim3((n_graphs + 3) / 4), dim3(256), 0, ctx->stream, P);
   HIP_TRY(ctx, hipGetLastError());
   return OTG_OK;
 }

@@ -482,18 +482,6 @@ __global__ __launch_bounds__(256) void wfa_affine_bound_kernel(
 // shift).  Four times cheaper per score than the static 256-diagonal band and not limited by the distance
 // between start and end diagonals; the bound is as valid (any alignment found is an alignment), just looser
 // when the optimal path strays more than ~20 diagonals from the leader.
-__device__ __forceinline__ int wave_max_i32(int v)
-{
-  constexpr int NEG = -2147483647 - 1;
-  v = imax(v, __builtin_amdgcn_update_dpp(NEG, v, 0x111, 0xf, 0xf, false));   // row_shr:1
-  v = imax(v, __builtin_amdgcn_update_dpp(NEG, v, 0x112, 0xf, 0xf, false));   // row_shr:2
-  v = imax(v, __builtin_amdgcn_update_dpp(NEG, v, 0x114, 0xf, 0xf, false));   // row_shr:4
-  v = imax(v, __builtin_amdgcn_update_dpp(NEG, v, 0x118, 0xf, 0xf, false));   // row_shr:8  -> lane 15 of each row = row max
-  v = imax(v, __builtin_amdgcn_update_dpp(NEG, v, 0x142, 0xa, 0xf, false));   // row_bcast:15 into rows 1, 3
-  v = imax(v, __builtin_amdgcn_update_dpp(NEG, v, 0x143, 0xc, 0xf, false));   // row_bcast:31 into rows 2, 3
-  return __builtin_amdgcn_readlane(v, 63);
-}
-
 template <int XS, int OES>
 __global__ __launch_bounds__(256) void wfa_affine_bound1_kernel(
     const uint8_t* __restrict__ arena, const otg_align_task* __restrict__ tasks,
@@ -544,7 +532,7 @@ __global__ __launch_bounds__(256) void wfa_affine_bound1_kernel(
         if ((s & 1) == 0) {
           // follow the leader: keep the diagonal with the furthest anti-diagonal inside lanes [24, 40)
           const int prog = M1 >= 0 ? 2 * M1 - (bk0 + lane) : NULLV;
-          const int best = wave_max_i32(prog);
+          const int best = otg_wave_max_i32(prog);
           const unsigned long long at = __ballot(prog == best && best > NULLV);
           if (at) {
             const int bl = (int)__builtin_ctzll(at);

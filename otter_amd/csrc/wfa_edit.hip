@@ -165,7 +165,7 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_kernel_v2(
     const uint32_t* __restrict__ todo, const uint32_t* __restrict__ n_todo_ptr, uint32_t n_todo_imm,
     int32_t* __restrict__ scores, uint64_t* __restrict__ cells,
     uint32_t* __restrict__ ticket, uint32_t* __restrict__ n_overflow, uint32_t* __restrict__ overflow_list,
-    float cap_coeff)
+    float cap_coeff, uint32_t* __restrict__ route_cnt, uint32_t* __restrict__ route_lists, uint32_t route_stride, float route_margin)
 {
   extern __shared__ __attribute__((aligned(16))) int32_t smem[];
   const int lane = threadIdx.x & 63;
@@ -201,7 +201,10 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_kernel_v2(
       cap = (int)(cap_coeff * sqrtf((float)(pl > tl ? pl : tl)));
       if (cap < 48) cap = 48;
       const int dlen = pl > tl ? pl - tl : tl - pl;
-      if (!ef && dlen > cap) overflow = true;
+      if (!ef && dlen > cap) {
+        // cannot finish here; with routing, a short run still measures the local divergence for the tier choice
+        if (route_cnt && !overflow) cap = 24; else overflow = true;
+      }
     }
 
     while (!overflow) {
@@ -318,6 +321,33 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_kernel_v2(
     if (done) {
       scores[ti] = s;
       if (cells) cells[ti] = W;
+    } else if (overflow && route_cnt) {
+      // Route to the bit-parallel tier whose band fits the ESTIMATED distance: score so far scaled by the share of
+      // both sequences the furthest wavefront point has covered, plus the length difference.  Only a scheduling
+      // hint: a tier that turns out too narrow passes the pair on, every tier is exact.
+      int amax = 0;
+      if (s > 0) {
+        for (int c = lo_prev; c <= hi_prev; c += 64) {
+          const int k = c + lane;
+          if (k <= hi_prev) { const int x = wf[k - kbase]; if (x != NUL) { const int a = 2 * x - k; amax = a > amax ? a : amax; } }
+        }
+        amax = otg_wave_max_i32(amax);
+      }
+      const int dlen = pl > tl ? pl - tl : tl - pl;
+      const int minlen = pl < tl ? pl : tl;
+      float est = (s > 0 && amax > 0) ? (float)s * (float)(pl + tl) / (float)amax : 0.25f * (float)minlen;
+      if (est > (float)(pl + tl)) est = (float)(pl + tl);
+      // no safety margin: trying a tier that fails costs half of going one tier up straight away, so the median
+      // estimate is the cheapest choice (OTG_EDIT_ROUTE_MARGIN overrides, in percent)
+      const int need = (int)(route_margin * (est + (ef ? 0.0f : (float)dlen)));
+      int tier = 5;
+      if (need <= (16192 - dlen) / 2) tier = 4;
+      if (need <= (8128 - dlen) / 2) tier = 3;
+      if (need <= (4096 - dlen) / 2) tier = 2;
+      if (need <= (2048 - dlen) / 2) tier = 1;
+      if (need <= (1024 - dlen) / 2) tier = 0;
+      const uint32_t q = otg_wave_atomic_add(route_cnt + tier, 1u);
+      route_lists[(size_t)tier * route_stride + q] = ti;
     } else if (overflow && overflow_list) {
       const uint32_t q = otg_wave_atomic_add(n_overflow, 1u);
       overflow_list[q] = ti;
@@ -350,14 +380,16 @@ int otg_launch_edit_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_t
   if (!cnt || !todo) return OTG_ERR_HIP;
   HIP_TRY(ctx, hipMemsetAsync(cnt, 0, 8 * sizeof(uint32_t), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(cnt + 16, 0, 16 * sizeof(uint32_t), ctx->stream));
-  uint32_t* listA = todo;                         // overflow of WFA tier 1 (score cap / capacity)
-  uint32_t* listB = todo + n_tasks;               // overflow of bit-parallel tier 0 (16-lane groups)
-  uint32_t* listC = todo + 2 * (size_t)n_tasks;   // ... tier 1 (32-lane groups)
-  uint32_t* listD = todo + 3 * (size_t)n_tasks;   // ... tier 2 (whole wave)
-  uint32_t* listE = todo + 4 * (size_t)n_tasks;   // ... tier 3 (2 blocks per lane)
-  uint32_t* listF = todo + 5 * (size_t)n_tasks;   // what the bit-parallel tiers could not finish
-  uint32_t* listG = todo + 6 * (size_t)n_tasks;   // overflow of WFA tier 2
+  // lists[t] (t = 0..4) feed the bit-parallel tiers, lists[5] the wide wavefront tier, listG its overflow.  The
+  // first kernel routes every pair it cannot finish to the tier matching its estimated distance; a tier that is too
+  // narrow appends the pair to the next list.  cnt[32 + t] = length of lists[t].
+  uint32_t* const lists = todo;
+  uint32_t* listG = todo + 6 * (size_t)n_tasks;
+  uint32_t* const rc = cnt + 32;
+  HIP_TRY(ctx, hipMemsetAsync(rc, 0, 8 * sizeof(uint32_t), ctx->stream));
   static const bool no_myers = getenv("OTG_NO_MYERS") != nullptr;
+  static const bool no_route = getenv("OTG_NO_EDIT_ROUTE") != nullptr;
+  static const float route_margin = getenv("OTG_EDIT_ROUTE_MARGIN") ? (float)atoi(getenv("OTG_EDIT_ROUTE_MARGIN")) / 100.0f : 1.0f;
   if (kernel_ms) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   {
     constexpr int CAP = 2048, WPB = 4;                         // 2 x 2048 x u16 = 8 KB per wave -> 20 waves / CU
@@ -365,29 +397,28 @@ int otg_launch_edit_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_t
     uint32_t want = (n_tasks + WPB - 1) / WPB;
     uint32_t grid = (uint32_t)ctx->n_cu * 5;
     if (grid > want) grid = want;
+    // without routing everything unfinished goes to lists[0] (or straight to the wide wavefront tier)
     hipLaunchKernelGGL((wfa_edit_kernel_v2<CAP, WPB>), dim3(grid), dim3(WPB * 64), lds, ctx->stream, d_arena, d_tasks,
-                       d_todo, d_n_todo, n_tasks, d_scores, d_cells, cnt + 0, cnt + 1, listA, no_myers ? 0.0f : 1.0f);
+                       d_todo, d_n_todo, n_tasks, d_scores, d_cells, cnt + 0, no_myers ? rc + 5 : rc + 0,
+                       no_myers ? lists + 5 * (size_t)n_tasks : lists, no_myers ? 0.0f : 1.0f,
+                       (no_myers || no_route) ? (uint32_t*)nullptr : rc, lists, n_tasks, route_margin);
   }
-  const uint32_t* cur = listA; const uint32_t* cur_n = cnt + 1;
   if (!no_myers) {
-    static const int first = getenv("OTG_MYERS_FIRST") ? atoi(getenv("OTG_MYERS_FIRST")) : 0;
-    uint32_t* const lists[6] = {listA, listB, listC, listD, listE, listF};
     uint32_t* const tick[5] = {cnt + 2, cnt + 4, cnt + 6, cnt + 20, cnt + 22};
-    uint32_t* const ovf[5] = {cnt + 3, cnt + 5, cnt + 7, cnt + 21, cnt + 23};
-    int li = 0;
-    for (int tier = first < 0 ? 0 : (first > 2 ? 2 : first); tier < 5; ++tier, ++li) {
-      const int rc = otg_launch_myers(ctx, tier, d_arena, d_tasks, cur, cur_n, n_tasks, d_scores, d_cells, tick[li], ovf[li], lists[li + 1]);
-      if (rc) return rc;
-      cur = lists[li + 1]; cur_n = ovf[li];
+    for (int tier = 0; tier < 5; ++tier) {
+      const int rc_ = otg_launch_myers(ctx, tier, d_arena, d_tasks, lists + (size_t)tier * n_tasks, rc + tier, n_tasks, d_scores, d_cells,
+                                       tick[tier], rc + tier + 1, lists + (size_t)(tier + 1) * n_tasks);
+      if (rc_) return rc_;
     }
   }
+  const uint32_t* cur = lists + 5 * (size_t)n_tasks; const uint32_t* cur_n = rc + 5;
   if (kernel_ms) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   {
     constexpr int CAP = 8192, WPB = 1;                         // 32 KB per wave -> 5 waves / CU, scores up to ~4000
     const size_t lds = (size_t)CAP * 2 * WPB * sizeof(uint16_t);
     uint32_t grid = (uint32_t)ctx->n_cu * 5;
     hipLaunchKernelGGL((wfa_edit_kernel_v2<CAP, WPB>), dim3(grid), dim3(WPB * 64), lds, ctx->stream, d_arena, d_tasks,
-                       cur, cur_n, 0u, d_scores, d_cells, cnt + 16, cnt + 17, listG, 0.0f);
+                       cur, cur_n, 0u, d_scores, d_cells, cnt + 16, cnt + 17, listG, 0.0f, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, 1.0f);
   }
   {
     // last tier: global-memory wavefront sized for the longest possible pair; only reached by huge inputs
@@ -403,9 +434,10 @@ int otg_launch_edit_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_t
   HIP_TRY(ctx, hipGetLastError());
   if (getenv("OTG_DEBUG")) {
     hipError_t er = hipStreamSynchronize(ctx->stream);
-    uint32_t h[32];
+    uint32_t h[40];
     (void)hipMemcpy(h, cnt, sizeof(h), hipMemcpyDeviceToHost);
-    fprintf(stderr, "[otg] edit: %s; wfa1 overflow %u, bit-parallel tiers overflow %u/%u/%u/%u/%u, wfa2 overflow %u\n", hipGetErrorString(er), h[1], h[3], h[5], h[7], h[21], h[23], h[17]);
+    fprintf(stderr, "[otg] edit: %s; inputs of the bit-parallel tiers 0..4: %u %u %u %u %u, wide wavefront tier %u, its overflow %u\n",
+            hipGetErrorString(er), h[32], h[33], h[34], h[35], h[36], h[37], h[17]);
   }
   if (kernel_ms) {
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
