@@ -912,7 +912,7 @@ __global__ __launch_bounds__(NW * 64) void wfa_affine_kernel_v3(
 // first grow and then shrink by one diagonal per side and score; whatever an array holds outside the current
 // range is either null (never written) or a value of an older, wider wavefront that no later score reads
 // (the readers' ranges have shrunk past it), see DESIGN.md §4.
-template <int CAP, int QCAP, int NW>
+template <int CAP, int QCAP, int NW, int SEQB>
 __global__ __launch_bounds__(NW * 64) void wfa_affine_kernel_v4(
     const uint8_t* __restrict__ arena, const otg_align_task* __restrict__ tasks,
     const uint32_t* __restrict__ todo, const uint32_t* __restrict__ n_todo_ptr, uint32_t n_todo_imm, int g,
@@ -927,6 +927,12 @@ __global__ __launch_bounds__(NW * 64) void wfa_affine_kernel_v4(
   __shared__ __attribute__((aligned(16))) int16_t s_M[4][CAP];
   __shared__ uint16_t s_q[NW][QCAP];
   __shared__ int s_misc[16];
+  // Both sequences are packed to 2 bits per base into LDS once per alignment (pattern at word 0, text at word
+  // offT): a probe is two unaligned 64-bit LDS reads covering 32 bases, so match runs almost never outlive the
+  // probe and the sweep does not touch HBM except for the provenance byte.  Sequences with a byte outside ACGT
+  // cannot be packed; those alignments go to the byte-compare tier.
+  __shared__ uint32_t s_seq[SEQB / 4];
+  volatile lds_u32* SQ = (volatile lds_u32*)&s_seq[0];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   volatile lds_i16* LI = (volatile lds_i16*)&s_I[0];
@@ -961,6 +967,8 @@ __global__ __launch_bounds__(NW * 64) void wfa_affine_kernel_v4(
     const int elo = kend - (ef ? tef : 0), ehi = kend + (ef ? pef : 0);
     int lo0 = ef ? imax(-t.pattern_begin_free, -pl) : 0, hi0 = ef ? imin(t.text_begin_free, tl) : 0;
     bool fail = U >= 0x40000000 || pl >= 32766 || tl >= 32766;
+    const int offT = (pl + 15) / 16 + 3;                 // in words; three words of slack: a probe reads three words from its own
+    if ((offT + (tl + 15) / 16 + 3) * 4 > SEQB) fail = true;
     int kbase = 0;
     if (!fail) {
       lo0 = imax(lo0, elo - U); hi0 = imin(hi0, ehi + U);
@@ -979,8 +987,62 @@ __global__ __launch_bounds__(NW * 64) void wfa_affine_kernel_v4(
       volatile lds_u32* m32 = (volatile lds_u32*)&s_M[0][0];
       for (int q = (int)threadIdx.x; q < CAP / 2; q += NW * 64) { f32[q] = 0x80008000u; d32[q] = 0x80008000u; }
       for (int q = (int)threadIdx.x; q < 2 * CAP; q += NW * 64) m32[q] = 0x80008000u;
+      // pack: word q holds bases 16q .. 16q+15, base b in bits 2(b&15)..+1, code = (byte >> 1) & 3 (A C T G -> 0 1 2 3)
+      bool bad = false;
+      auto pack = [&](const uint8_t* S, int len, int woff) {
+        for (int q = (int)threadIdx.x; q < (len + 15) / 16; q += NW * 64) {
+          uint32_t w = 0;
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int b0 = 16 * q + 8 * j;
+            uint64_t x = b0 < len + 8 ? otg_load8(S + (b0 < len ? b0 : len)) : 0ull;     // stays within 8 bytes past the end
+#pragma unroll
+            for (int t2 = 0; t2 < 8; ++t2) {
+              const uint32_t c = (uint32_t)(x >> (8 * t2)) & 0xffu;
+              const uint32_t code = (c >> 1) & 3u;
+              if (b0 + t2 < len && c != ((0x47544341u >> (8 * code)) & 0xffu)) bad = true;
+              w |= code << (2 * (8 * j + t2));
+            }
+          }
+          SQ[woff + q] = w;
+        }
+      };
+      pack(P, pl, 0);
+      pack(T, tl, offT);
+      if (NW > 1) { if (threadIdx.x == 0) misc[2] = 0; __syncthreads(); if (bad) misc[2] = 1; __syncthreads(); fail = misc[2] != 0; }
+      else fail = __ballot(bad) != 0ull;
     }
     sync();
+    // 32 bases (64 bits) of the packed pattern / text starting at base position pos
+    auto ld32b = [&](int woff, int pos) -> uint64_t {
+      const int w = woff + (pos >> 4);
+      const uint32_t sh = (uint32_t)(pos & 15) * 2u;
+      const uint32_t d0 = SQ[w], d1 = SQ[w + 1], d2 = SQ[w + 2];
+      return (uint64_t)__builtin_amdgcn_alignbit(d1, d0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32);
+    };
+    // equal leading bases looking at most 32*nb bases ahead (and at most rem)
+    auto match_n = [&](int v, int h, int rem, int nb) -> int {
+      int m = 32 * nb;
+      for (int i = nb - 1; i >= 0; --i) {
+        const uint64_t x = (32 * i < rem) ? (ld32b(0, v + 32 * i) ^ ld32b(offT, h + 32 * i)) : ~0ull;
+        if (x) m = 32 * i + (int)(__builtin_ctzll(x) >> 1);
+      }
+      return m < rem ? m : rem;
+    };
+    // wave-cooperative extension of ONE diagonal (arguments wave-uniform), 2048 bases per iteration
+    auto wave_match = [&](int v, int h, int rem) -> int {
+      int total = 0;
+      while (total < rem) {
+        const int off = total + lane * 32;
+        uint64_t x = ~0ull;
+        if (off < rem) x = ld32b(0, v + off) ^ ld32b(offT, h + off);
+        const int m = x ? (int)(__builtin_ctzll(x) >> 1) : 32;
+        const unsigned long long stop = __ballot(m < 32);
+        if (stop) { const int f = (int)__builtin_ctzll(stop); total += f * 32 + __builtin_amdgcn_readlane(m, f); break; }
+        total += 2048;
+      }
+      return total < rem ? total : rem;
+    };
 
     for (int s = 0; !fail; ++s) {
       if (s >= ws.nrows) { fail = true; break; }
@@ -1035,7 +1097,7 @@ __global__ __launch_bounds__(NW * 64) void wfa_affine_kernel_v4(
               const int kk = lo + (int)queue[e];
               const int h = Mn[kk - kbase];
               const int v = h - kk;
-              const int m = otg_wave_match(P, T, v, h, imin(pl - v, tl - h), lane);
+              const int m = wave_match(v, h, imin(pl - v, tl - h));
               Mn[kk - kbase] = (int16_t)(h + m);
             }
             qn = 0;
@@ -1052,11 +1114,8 @@ __global__ __launch_bounds__(NW * 64) void wfa_affine_kernel_v4(
               v = h - kk;
               const int rem = imin(pl - v, tl - h);
               int m, full;
-              if (pass == 0) {
-                const uint64_t xl = otg_load8(P + v) ^ otg_load8(T + h), xh = otg_load8(P + v + 8) ^ otg_load8(T + h + 8);
-                m = xl ? (__builtin_ctzll(xl) >> 3) : (xh ? 8 + (__builtin_ctzll(xh) >> 3) : 16);
-                m = imin(m, rem); full = 16;
-              } else { m = otg_match64(P, T, v, h, rem); full = 64; }
+              if (pass == 0) { m = match_n(v, h, rem, 2); full = 64; }
+              else { m = match_n(v, h, rem, 8); full = 256; }
               v += m; h += m;
               more = (m == full) && v < pl && h < tl;
               Mn[kk - kbase] = (int16_t)h;
@@ -1083,11 +1142,11 @@ __global__ __launch_bounds__(NW * 64) void wfa_affine_kernel_v4(
         bool more = false;
         if (p_probe) {
           const uint64_t xx = p_a ^ p_b;
-          int m = xx ? (__builtin_ctzll(xx) >> 3) : 8;
+          int m = xx ? (__builtin_ctzll(xx) >> 1) : 32;
           const int rem = imin(pl - v, tl - h);
           m = imin(m, rem);
           v += m; h += m;
-          more = (m == 8) && v < pl && h < tl;
+          more = (m == 32) && v < pl && h < tl;
         }
         if (p_in) Mn[p_k - kbase] = (int16_t)(p_valid ? h : NUL16);
         const unsigned long long mq = __ballot(more);
@@ -1134,7 +1193,7 @@ __global__ __launch_bounds__(NW * 64) void wfa_affine_kernel_v4(
         if (p_pending) finish();                              // retire the previous chunk (its probe was issued one iteration ago)
         uint64_t a, b;
         { const int vc = imin(imax(v, 0), pl), hc = imin(imax(h, 0), tl);      // clamped: always inside arena + slack
-          a = otg_load8(P + vc); b = otg_load8(T + hc); }
+          a = ld32b(0, vc); b = ld32b(offT, hc); }
         if (in) {
           LI[jl] = (int16_t)(ins < 0 ? NUL16 : ins);
           LD[jl] = (int16_t)(del < 0 ? NUL16 : del);
@@ -1269,7 +1328,7 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
     w.slab_bytes = slab & ~(size_t)255; w.stride = w.off_slab + w.slab_bytes;
     return w;
   };
-  uint32_t blocksS = std::min<uint32_t>((uint32_t)ctx->n_cu * 12, n_tasks), blocksM = std::min<uint32_t>((uint32_t)ctx->n_cu * 6, n_tasks);
+  uint32_t blocksS = std::min<uint32_t>((uint32_t)ctx->n_cu * 10, n_tasks), blocksM = std::min<uint32_t>((uint32_t)ctx->n_cu * 5, n_tasks);   // resident blocks per CU (LDS / VGPR limits)
   AffWs wsS = lds_ws(1024, blocksS), wsM = lds_ws(2048, blocksM);
   const size_t need = std::max(std::max(std::max(wsA.stride * wavesA, wsB.stride * wavesB), wsC.stride * (size_t)gridC * WPB),
                                std::max(wsS.stride * blocksS, wsM.stride * blocksM));
@@ -1306,17 +1365,15 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
     static const bool no_v4 = getenv("OTG_NO_AFFINE_V4") != nullptr;
     if (d_bound && !no_v4) {
       static const int nws = getenv("OTG_V4_NWS") ? atoi(getenv("OTG_V4_NWS")) : 2;
-      static const int nwm = getenv("OTG_V4_NWM") ? atoi(getenv("OTG_V4_NWM")) : 2;
-#define OTG_V4_LAUNCH(CAPV, NWV, BLOCKS, TODO, NTODO, IMM, TICK, OVF, LIST, WS)                                              \
-      hipLaunchKernelGGL((wfa_affine_kernel_v4<CAPV, 256, NWV>), dim3(BLOCKS), dim3(NWV * 64), 0, ctx->stream, d_arena, d_tasks, \
+      static const int nwm = getenv("OTG_V4_NWM") ? atoi(getenv("OTG_V4_NWM")) : 4;
+#define OTG_V4_LAUNCH(CAPV, NWV, SEQV, BLOCKS, TODO, NTODO, IMM, TICK, OVF, LIST, WS)                                        \
+      hipLaunchKernelGGL((wfa_affine_kernel_v4<CAPV, 256, NWV, SEQV>), dim3(BLOCKS), dim3(NWV * 64), 0, ctx->stream, d_arena, d_tasks, \
                          TODO, NTODO, IMM, g, d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, TICK, OVF, LIST, WS,       \
                          (const int32_t*)d_bound)
-      if (nws == 1) OTG_V4_LAUNCH(1024, 1, blocksS, d_todo, d_n_todo, n_tasks, cnt + 24, cnt + 25, listS, wsS);
-      else if (nws == 4) OTG_V4_LAUNCH(1024, 4, blocksS, d_todo, d_n_todo, n_tasks, cnt + 24, cnt + 25, listS, wsS);
-      else OTG_V4_LAUNCH(1024, 2, blocksS, d_todo, d_n_todo, n_tasks, cnt + 24, cnt + 25, listS, wsS);
-      if (nwm == 1) OTG_V4_LAUNCH(2048, 1, blocksM, (const uint32_t*)listS, (const uint32_t*)(cnt + 25), 0u, cnt + 26, cnt + 27, listM, wsM);
-      else if (nwm == 4) OTG_V4_LAUNCH(2048, 4, blocksM, (const uint32_t*)listS, (const uint32_t*)(cnt + 25), 0u, cnt + 26, cnt + 27, listM, wsM);
-      else OTG_V4_LAUNCH(2048, 2, blocksM, (const uint32_t*)listS, (const uint32_t*)(cnt + 25), 0u, cnt + 26, cnt + 27, listM, wsM);
+      if (nws == 1) OTG_V4_LAUNCH(1024, 1, 2304, blocksS, d_todo, d_n_todo, n_tasks, cnt + 24, cnt + 25, listS, wsS);
+      else OTG_V4_LAUNCH(1024, 2, 2304, blocksS, d_todo, d_n_todo, n_tasks, cnt + 24, cnt + 25, listS, wsS);
+      if (nwm == 4) OTG_V4_LAUNCH(2048, 4, 3072, blocksM, (const uint32_t*)listS, (const uint32_t*)(cnt + 25), 0u, cnt + 26, cnt + 27, listM, wsM);
+      else OTG_V4_LAUNCH(2048, 2, 3072, blocksM, (const uint32_t*)listS, (const uint32_t*)(cnt + 25), 0u, cnt + 26, cnt + 27, listM, wsM);
 #undef OTG_V4_LAUNCH
       inA = listM; inA_n = cnt + 27; inA_imm = 0;
     }
