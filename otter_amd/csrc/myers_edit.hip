@@ -65,12 +65,34 @@ __global__ __launch_bounds__(WPB * 64) void myers_edit_kernel(
 {
   constexpr int G = 64 / GL;            // pairs per wave
   constexpr int SB = 64 * BPL;
+  constexpr int NT = WPB * 64;
+  // Match-mask table of the lane's CURRENT superblock: row (sym * BPL + q), column = thread; a lane only ever reads
+  // its own column (same-wave program order, no barrier) and the row stride is a multiple of the bank count, so the
+  // per-step fetch `row(symbol of this column)` is one conflict-free ds_read_b64 instead of a select tree.
+  // sym: 0..3 = A C T G (code (byte >> 1) & 3), 4 = the one extra byte value of the pattern, 5 = anything else (zero).
+  __shared__ u64 s_eq[6 * BPL][NT];
+  // byte -> row index (sym * BPL) per lane group; text bytes are translated when a lane loads its next 8 columns
+  __shared__ uint8_t s_lut[WPB * G][256];
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
   const int gl = lane & (GL - 1);       // lane within its group
   const int grp = lane / GL;
   u64* peq = peq_ws + ((size_t)(blockIdx.x * WPB + wib) * G + grp) * (size_t)maxblk * 5;
   const uint32_t n_todo = n_todo_ptr ? *n_todo_ptr : n_todo_imm;
+  using lds_u64 = __attribute__((address_space(3))) u64;
+  using lds_u8 = __attribute__((address_space(3))) uint8_t;
+  volatile lds_u64* EQ = (volatile lds_u64*)&s_eq[0][0] + threadIdx.x;          // this thread's column; row r at EQ[r * NT]
+  volatile lds_u8* LUT = (volatile lds_u8*)&s_lut[wib * G + grp][0];
+  {
+    // static part of the tables: zero rows, ACGT entries of the byte map (the extra symbol is patched per pair)
+#pragma unroll
+    for (int q = 0; q < BPL; ++q) EQ[(5 * BPL + q) * NT] = 0ull;
+    for (int c = gl; c < 256; c += GL) {
+      const uint32_t code = ((uint32_t)c >> 1) & 3u;
+      LUT[c] = (uint8_t)(((uint32_t)c == ((0x47544341u >> (8 * code)) & 0xffu) ? code : 5u) * BPL);
+    }
+  }
+  int lut_other = -1;                    // byte currently mapped to row 4 in this group's map
 
   for (;;) {
     const uint32_t tk0 = otg_wave_atomic_add(ticket, (uint32_t)G);
@@ -137,13 +159,20 @@ __global__ __launch_bounds__(WPB * 64) void myers_edit_kernel(
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    if (other != lut_other) {            // group-uniform
+      if (gl == 0) {
+        if (lut_other >= 0) LUT[lut_other] = (uint8_t)(5 * BPL);
+        if (other >= 0) LUT[other] = (uint8_t)(4 * BPL);
+      }
+      lut_other = other;
+    }
 
     // ---- skewed sweep
     int B = gl;                         // current superblock of this lane
     bool inited = false;
-    u64 Pv[BPL], Mv[BPL], EA[BPL], EC[BPL], EG[BPL], ET[BPL], EX[BPL];
+    u64 Pv[BPL], Mv[BPL];
 #pragma unroll
-    for (int q = 0; q < BPL; ++q) { Pv[q] = ~0ull; Mv[q] = 0; EA[q] = EC[q] = EG[q] = ET[q] = EX[q] = 0; }
+    for (int q = 0; q < BPL; ++q) { Pv[q] = ~0ull; Mv[q] = 0; }
     int score = 0, hout = 0;
     int best = 0x3fffffff;
     const int i_lo = m - pef;           // the answer is min over rows i in [i_lo, m] of D[i][n]
@@ -165,23 +194,28 @@ __global__ __launch_bounds__(WPB * 64) void myers_edit_kernel(
     setup();
     // text bytes: one unaligned 8-byte load per 8 steps and lane (prefetched 4 steps ahead); byte (t & 7) of c8
     // is column (t & ~7) - B + (t & 7) = t - B
-    auto load_group = [&](int tg) -> u64 {              // tg = first step of the group
+    auto load_group = [&](int tg) -> u64 {              // tg = first step of the group; returns 8 row indices
       int a = tg - B;
       if (a > n - 1) a = n - 1;
-      if (a >= 0) return load8(T + a);
-      const int sh = -a;
-      return sh < 8 ? (load8(T) << (8 * sh)) : 0ull;
+      u64 x;
+      if (a >= 0) x = load8(T + a);
+      else { const int sh = -a; x = sh < 8 ? (load8(T) << (8 * sh)) : 0ull; }
+      uint32_t r[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) r[i] = LUT[(uint32_t)(x >> (8 * i)) & 0xffu];
+      const uint32_t lo = r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24), hi = r[4] | (r[5] << 8) | (r[6] << 16) | (r[7] << 24);
+      return (u64)lo | ((u64)hi << 32);
     };
     u64 c8 = load_group(0), c8n = 0;
     // the wave runs until its longest pair is done
     int t_end_w = t_end;
     for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(t_end_w, off); t_end_w = o > t_end_w ? o : t_end_w; }
     t_end_w = __builtin_amdgcn_readfirstlane(t_end_w);
-    for (int t = 0; t <= t_end_w; ++t) {
+    // one column per step; unrolled by the 8 columns of a translated text group so that every byte position is static
+    auto step = [&](const int t, const int ph) {
       // values of lane-1 (within the group) after its previous step
       const int up_score = group_ror1<GL>(score, lane);
       const int up_hout = group_ror1<GL>(hout, lane);
-      const int ph = t & 7;
       if (t > t_stop) {                 // this superblock left the band: move to the next one owned by the lane
         B += GL; inited = false; setup();
         c8 = load_group(t - ph);
@@ -194,8 +228,9 @@ __global__ __launch_bounds__(WPB * 64) void myers_edit_kernel(
 #pragma unroll
           for (int q = 0; q < BPL; ++q) {
             const int b = B * BPL + q;
-            if (b < nblk) { EA[q] = peq[b * 5 + 0]; EC[q] = peq[b * 5 + 1]; EG[q] = peq[b * 5 + 2]; ET[q] = peq[b * 5 + 3]; EX[q] = peq[b * 5 + 4]; }
-            else { EA[q] = EC[q] = EG[q] = ET[q] = EX[q] = 0; }
+            const bool have = b < nblk;
+#pragma unroll
+            for (int y = 0; y < 5; ++y) EQ[(y * BPL + q) * NT] = have ? peq[b * 5 + (y == 2 ? 3 : y == 3 ? 2 : y)] : 0ull;   // rows A C T G X <- scratch A C G T X
             Mv[q] = 0;
             if (exact_init) {
               // true first column: D[i][0] = max(0, i - pbf)  ->  vertical delta +1 for rows i > pbf
@@ -208,17 +243,11 @@ __global__ __launch_bounds__(WPB * 64) void myers_edit_kernel(
           else score = (up_score - up_hout) + SB;
           inited = true;
         }
-        const uint32_t c = (uint32_t)(c8 >> (8 * ph)) & 0xffu;
-        const uint32_t code = (c >> 1) & 3u;                               // A C T G -> 0 1 2 3
-        const bool is_acgt = c == ((0x47544341u >> (8 * code)) & 0xffu);
-        const bool is_x = (int)c == other;
+        const uint32_t row = (uint32_t)(c8 >> (8 * ph)) & 0xffu;               // sym * BPL of this column's text byte
         int hin = t <= t_hin_stop ? up_hout : 1;
 #pragma unroll
         for (int q = 0; q < BPL; ++q) {
-          const u64 e01 = (code & 1u) ? EC[q] : EA[q];
-          const u64 e23 = (code & 1u) ? EG[q] : ET[q];
-          u64 Eq = (code & 2u) ? e23 : e01;
-          Eq = is_acgt ? Eq : (is_x ? EX[q] : 0ull);
+          u64 Eq = EQ[(row + q) * NT];
           const u64 pv = Pv[q], mv = Mv[q];
           const u64 hneg = hin < 0 ? 1ull : 0ull;
           const u64 Xv = Eq | mv;
@@ -253,6 +282,10 @@ __global__ __launch_bounds__(WPB * 64) void myers_edit_kernel(
           }
         }
       }
+    };
+    for (int t8 = 0; t8 <= t_end_w; t8 += 8) {
+      step(t8 + 0, 0); step(t8 + 1, 1); step(t8 + 2, 2); step(t8 + 3, 3);
+      step(t8 + 4, 4); step(t8 + 5, 5); step(t8 + 6, 6); step(t8 + 7, 7);
     }
     for (int off = GL / 2; off > 0; off >>= 1) { const int o = __shfl_xor(best, off, GL); best = o < best ? o : best; }
     const bool ok = !unsupported && best <= K;
@@ -275,8 +308,16 @@ int launch_one(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_task* d_tas
   int maxblk = (int)((ctx->max_seq_len + 63) / 64) + 1;
   if (maxblk > MAXBLK) maxblk = MAXBLK;
   uint32_t want = (n_tasks + WPB * G - 1) / (WPB * G);
-  const uint32_t grid_max = (uint32_t)ctx->n_cu * 8;      // 32 waves / CU when the VGPR budget allows
-  uint32_t grid = grid_max < want ? grid_max : want;
+  // persistent blocks: exactly as many as are resident at once (VGPR / LDS limits differ per instantiation)
+  static int per_cu = 0;
+  if (per_cu == 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, myers_edit_kernel<BPL, GL, WPB>, WPB * 64, 0) != hipSuccess || nb < 1) nb = 4;
+    per_cu = nb > 8 ? 8 : nb;
+  }
+  const uint32_t grid_max = (uint32_t)ctx->n_cu * 8;      // sizes the scratch (upper bound of per_cu)
+  const uint32_t grid_res = (uint32_t)ctx->n_cu * (uint32_t)per_cu;
+  uint32_t grid = grid_res < want ? grid_res : want;
   if (grid == 0) return OTG_OK;
   u64* ws = (u64*)otg_slot(ctx, SLOT_AUX8, (size_t)grid_max * WPB * 4 * (size_t)MAXBLK * 5 * sizeof(u64));
   if (!ws) return OTG_ERR_HIP;
