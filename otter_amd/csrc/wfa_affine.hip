@@ -602,7 +602,7 @@ __global__ __launch_bounds__(NW * 64) void wfa_affine_kernel_v3(
   __shared__ int s_mhi[64];
   __shared__ int s_misc[16];
   const int lane = threadIdx.x & 63;
-  const int wv = threadIdx.x >> 6;               // NW waves cooperate on ONE alignment: wave wv sweeps a contiguous 1/NW of each wavefront
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // NW waves cooperate on ONE alignment: wave wv sweeps a contiguous 1/NW of each wavefront
   volatile lds_i16* LI = (volatile lds_i16*)&s_I[0];
   volatile lds_i16* LD = (volatile lds_i16*)&s_D[0];
   volatile lds_u16* queue = (volatile lds_u16*)&s_q[wv][0];
@@ -912,8 +912,8 @@ __global__ __launch_bounds__(NW * 64) void wfa_affine_kernel_v3(
 // first grow and then shrink by one diagonal per side and score; whatever an array holds outside the current
 // range is either null (never written) or a value of an older, wider wavefront that no later score reads
 // (the readers' ranges have shrunk past it), see DESIGN.md §4.
-template <int CAP, int QCAP, int NW, int SEQB>
-__global__ __launch_bounds__(NW * 64) void wfa_affine_kernel_v4(
+template <int CAP, int QCAP, int NW, int SEQB, int WPEU>
+__global__ __launch_bounds__(NW * 64, WPEU) void wfa_affine_kernel_v4(
     const uint8_t* __restrict__ arena, const otg_align_task* __restrict__ tasks,
     const uint32_t* __restrict__ todo, const uint32_t* __restrict__ n_todo_ptr, uint32_t n_todo_imm, int g,
     int32_t* __restrict__ scores, const uint64_t* __restrict__ cig_off, uint32_t* __restrict__ cig_len,
@@ -934,7 +934,7 @@ __global__ __launch_bounds__(NW * 64) void wfa_affine_kernel_v4(
   __shared__ uint32_t s_seq[SEQB / 4];
   volatile lds_u32* SQ = (volatile lds_u32*)&s_seq[0];
   const int lane = threadIdx.x & 63;
-  const int wv = threadIdx.x >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // wave-uniform: keeps the share bounds and the sweep loop scalar
   volatile lds_i16* LI = (volatile lds_i16*)&s_I[0];
   volatile lds_i16* LD = (volatile lds_i16*)&s_D[0];
   volatile lds_u16* queue = (volatile lds_u16*)&s_q[wv][0];
@@ -1273,7 +1273,7 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
   const int xs = x / g, oes = (o + e) / g, es = e / g;
   if (std::max(xs, oes) + 1 > 64 || es + 1 > 64) return otg_fail(ctx, OTG_ERR_ARG, "affine penalties too large after gcd reduction");
   uint32_t* cnt = (uint32_t*)otg_slot(ctx, SLOT_COUNTERS, 64 * sizeof(uint32_t));
-  uint32_t* todo = (uint32_t*)otg_slot(ctx, SLOT_TODO, 4 * (size_t)n_tasks * sizeof(uint32_t));
+  uint32_t* todo = (uint32_t*)otg_slot(ctx, SLOT_TODO, 5 * (size_t)n_tasks * sizeof(uint32_t));
   if (!cnt || !todo) return OTG_ERR_HIP;
   HIP_TRY(ctx, hipMemsetAsync(cnt + 8, 0, 8 * sizeof(uint32_t), ctx->stream));   // tickets / overflow counters of the tiers
   HIP_TRY(ctx, hipMemsetAsync(cnt + 24, 0, 8 * sizeof(uint32_t), ctx->stream));
@@ -1329,16 +1329,18 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
     return w;
   };
   uint32_t blocksS = std::min<uint32_t>((uint32_t)ctx->n_cu * 10, n_tasks), blocksM = std::min<uint32_t>((uint32_t)ctx->n_cu * 5, n_tasks);   // resident blocks per CU (LDS / VGPR limits)
-  AffWs wsS = lds_ws(1024, blocksS), wsM = lds_ws(2048, blocksM);
+  uint32_t blocksX = std::min<uint32_t>((uint32_t)ctx->n_cu * 6, n_tasks);
+  AffWs wsS = lds_ws(1024, blocksS), wsM = lds_ws(2048, blocksM), wsX = lds_ws(1536, blocksX);
   const size_t need = std::max(std::max(std::max(wsA.stride * wavesA, wsB.stride * wavesB), wsC.stride * (size_t)gridC * WPB),
-                               std::max(wsS.stride * blocksS, wsM.stride * blocksM));
+                               std::max(std::max(wsS.stride * blocksS, wsM.stride * blocksM), wsX.stride * blocksX));
   uint8_t* wsp = (uint8_t*)otg_slot(ctx, SLOT_WF_WS, need);
   if (!wsp) return OTG_ERR_HIP;
-  wsA.base = wsB.base = wsC.base = wsS.base = wsM.base = wsp;
+  wsA.base = wsB.base = wsC.base = wsS.base = wsM.base = wsX.base = wsp;
   uint32_t* listA = todo;                  // overflow of tier A
   uint32_t* listB = todo + n_tasks;        // overflow of tier B
   uint32_t* listS = todo + 2 * (size_t)n_tasks;   // overflow of the LDS tier with 1024 diagonals
   uint32_t* listM = todo + 3 * (size_t)n_tasks;   // ... 2048 diagonals
+  uint32_t* listX = todo + 4 * (size_t)n_tasks;   // ... 1536 diagonals
   static const bool no_v3 = getenv("OTG_NO_AFFINE_V3") != nullptr;
   if (kernel_ms) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   const uint32_t* cur = d_todo; const uint32_t* cur_n = d_n_todo; uint32_t cur_imm = n_tasks;
@@ -1366,14 +1368,20 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
     if (d_bound && !no_v4) {
       static const int nws = getenv("OTG_V4_NWS") ? atoi(getenv("OTG_V4_NWS")) : 2;
       static const int nwm = getenv("OTG_V4_NWM") ? atoi(getenv("OTG_V4_NWM")) : 4;
-#define OTG_V4_LAUNCH(CAPV, NWV, SEQV, BLOCKS, TODO, NTODO, IMM, TICK, OVF, LIST, WS)                                        \
-      hipLaunchKernelGGL((wfa_affine_kernel_v4<CAPV, 256, NWV, SEQV>), dim3(BLOCKS), dim3(NWV * 64), 0, ctx->stream, d_arena, d_tasks, \
+#define OTG_V4_LAUNCH(CAPV, NWV, SEQV, WPEUV, BLOCKS, TODO, NTODO, IMM, TICK, OVF, LIST, WS)                                 \
+      hipLaunchKernelGGL((wfa_affine_kernel_v4<CAPV, 256, NWV, SEQV, WPEUV>), dim3(BLOCKS), dim3(NWV * 64), 0, ctx->stream, d_arena, d_tasks, \
                          TODO, NTODO, IMM, g, d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, TICK, OVF, LIST, WS,       \
                          (const int32_t*)d_bound)
-      if (nws == 1) OTG_V4_LAUNCH(1024, 1, 2304, blocksS, d_todo, d_n_todo, n_tasks, cnt + 24, cnt + 25, listS, wsS);
-      else OTG_V4_LAUNCH(1024, 2, 2304, blocksS, d_todo, d_n_todo, n_tasks, cnt + 24, cnt + 25, listS, wsS);
-      if (nwm == 4) OTG_V4_LAUNCH(2048, 4, 3072, blocksM, (const uint32_t*)listS, (const uint32_t*)(cnt + 25), 0u, cnt + 26, cnt + 27, listM, wsM);
-      else OTG_V4_LAUNCH(2048, 2, 3072, blocksM, (const uint32_t*)listS, (const uint32_t*)(cnt + 25), 0u, cnt + 26, cnt + 27, listM, wsM);
+      static const bool no_mid = getenv("OTG_V4_NO_MID") != nullptr;
+      if (nws == 1) OTG_V4_LAUNCH(1024, 1, 2304, 3, blocksS, d_todo, d_n_todo, n_tasks, cnt + 24, cnt + 25, listS, wsS);
+      else OTG_V4_LAUNCH(1024, 2, 2304, 5, blocksS, d_todo, d_n_todo, n_tasks, cnt + 24, cnt + 25, listS, wsS);
+      const uint32_t* inM = listS; const uint32_t* inM_n = cnt + 25;
+      if (!no_mid) {
+        OTG_V4_LAUNCH(1536, 4, 2688, 6, blocksX, (const uint32_t*)listS, (const uint32_t*)(cnt + 25), 0u, cnt + 28, cnt + 29, listX, wsX);
+        inM = listX; inM_n = cnt + 29;
+      }
+      if (nwm == 4) OTG_V4_LAUNCH(2048, 4, 3072, 5, blocksM, inM, inM_n, 0u, cnt + 26, cnt + 27, listM, wsM);
+      else OTG_V4_LAUNCH(2048, 2, 3072, 3, blocksM, inM, inM_n, 0u, cnt + 26, cnt + 27, listM, wsM);
 #undef OTG_V4_LAUNCH
       inA = listM; inA_n = cnt + 27; inA_imm = 0;
     }
