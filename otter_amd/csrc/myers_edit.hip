@@ -11,9 +11,9 @@
 // group owns "superblocks" l, l+GL, ... (BPL consecutive blocks each) and at time step t processes column
 // j = t - B of its superblock B: the anti-diagonal skew turns the block-to-block carry (hout -> hin) into a
 // one-lane rotate per step (DPP row_ror for 16-lane groups, ds_bpermute for 32, wave_ror for 64).  Only the
-// Ukkonen band -K <= i - j <= K + d (d = m - n >= 0) is evaluated; a superblock enters the band initialised as in
+// Ukkonen band -KL <= i - j <= KU (KL = (K - d)/2, KU = (K + d)/2 for a global alignment, d = m - n >= 0) is evaluated; a superblock enters the band initialised as in
 // Edlib (Pv = ~0, score = score_above + rows) and the block at the top of the band takes hin = +1.  With
-// 2K + d <= (GL-1)*64*BPL + 64 a lane has left its superblock before the next one (B + GL) enters the band, so
+// KL + KU <= (GL-1)*64*BPL + 64 (i.e. K up to that many rows) a lane has left its superblock before the next one (B + GL) enters the band, so
 // narrow bands (within-allele pairs) run four to a wave and only wide ones need the whole wave.
 // The computed score is exact iff it is <= K; otherwise the task is appended to the overflow list and handled
 // by the next tier (larger group / more blocks per lane, finally the wavefront kernel).
@@ -114,8 +114,14 @@ __global__ __launch_bounds__(WPB * 64) void myers_edit_kernel(
     const int d = m - n;
     const int nblk = (m + 63) >> 6;
     const int nsb = (m + SB - 1) / SB;
-    const int K = ((GL - 1) * SB + 64 - d) / 2;
-    if (nblk > maxblk || K < d || K < 1 || n < 1 || pbf > d || pef > d) unsupported = true;
+    // Ukkonen band for the threshold K: an alignment that starts on diagonal e0 in [0, pbf], ends on e1 in [d - pef, d]
+    // and visits diagonal e pays at least |e - e0| + |e - e1| indels, so cost <= K confines it to
+    // -KL <= i - j <= KU with KU = (K + d + pbf) / 2, KL = (K - d + pef) / 2 (rounded up): K + 1 + free ends
+    // diagonals, not 2K + d + 1.  The lane schedule holds KL + KU <= R rows apart (see header).
+    constexpr int R = (GL - 1) * SB + 64;
+    const int K = R - 2 - (pbf + pef + 1) / 2;
+    const int KU = (K + d + pbf + 1) / 2, KL = (K - d + pef + 1) / 2;
+    if (nblk > maxblk || K < d || K < 1 || KL < 0 || n < 1 || pbf > d || pef > d) unsupported = true;
     if (!has_task) unsupported = true;
 
     // ---- pattern match masks per 64-row block: A, C, G, T, X (one further byte value), built by the group
@@ -181,12 +187,12 @@ __global__ __launch_bounds__(WPB * 64) void myers_edit_kernel(
     // per-superblock time window (recomputed only when the lane moves to its next superblock)
     int t_start, t_stop, t_hin_stop, t_last; bool exact_init;
     auto setup = [&]() {
-      int jlo = SB * B - K - d; if (jlo < 0) jlo = 0;
-      int jhi = SB * B + SB - 1 + K; if (jhi > n - 1) jhi = n - 1;
+      int jlo = SB * B - KU; if (jlo < 0) jlo = 0;
+      int jhi = SB * B + SB - 1 + KL; if (jhi > n - 1) jhi = n - 1;
       exact_init = (jlo == 0);
       if (!unsupported && B < nsb && jlo <= jhi) {
         t_start = jlo + B; t_stop = jhi + B;
-        int jh = SB * B - 1 + K; if (jh > jhi) jh = jhi;
+        int jh = SB * B - 1 + KL; if (jh > jhi) jh = jhi;
         t_hin_stop = B > 0 ? jh + B : -1;              // block above still inside the band
         t_last = (jhi == n - 1) ? n - 1 + B : -1;
       } else { t_start = 0x7fffffff; t_stop = 0x7ffffffe; t_hin_stop = -1; t_last = -1; }

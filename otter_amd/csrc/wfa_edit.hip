@@ -340,12 +340,14 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_kernel_v2(
       // no safety margin: trying a tier that fails costs half of going one tier up straight away, so the median
       // estimate is the cheapest choice (OTG_EDIT_ROUTE_MARGIN overrides, in percent)
       const int need = (int)(route_margin * (est + (ef ? 0.0f : (float)dlen)));
+      // threshold of tier t: rows of its lane schedule minus the free ends (myers_edit.hip)
+      const int fe = ef ? (t.pattern_begin_free + t.pattern_end_free + 1) / 2 + 2 : 2;
       int tier = 5;
-      if (need <= (16192 - dlen) / 2) tier = 4;
-      if (need <= (8128 - dlen) / 2) tier = 3;
-      if (need <= (4096 - dlen) / 2) tier = 2;
-      if (need <= (2048 - dlen) / 2) tier = 1;
-      if (need <= (1024 - dlen) / 2) tier = 0;
+      if (need <= 16192 - fe) tier = 4;
+      if (need <= 8128 - fe) tier = 3;
+      if (need <= 4096 - fe) tier = 2;
+      if (need <= 2048 - fe) tier = 1;
+      if (need <= 1024 - fe) tier = 0;
       const uint32_t q = otg_wave_atomic_add(route_cnt + tier, 1u);
       route_lists[(size_t)tier * route_stride + q] = ti;
     } else if (overflow && overflow_list) {
