@@ -316,6 +316,17 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_kernel_v2(
       hi = hi + 1 > tl ? tl : hi + 1;
       ++s;
       if (lo - kbase < 0 || hi - kbase + 1 >= CAP || s > cap) overflow = true;
+      if (route_cnt && s == 16 && cap > 32) {
+        // early exit: if 16 edits covered so little that the projected distance is far beyond the cap, this pair is
+        // not a near-identical one; hand it to the bit-parallel tiers now (the projection also routes it)
+        int am = 0;
+        for (int c = lo_prev; c <= hi_prev; c += 64) {
+          const int k = c + lane;
+          if (k <= hi_prev) { const int x = wf[k - kbase]; if (x != NUL) { const int a = 2 * x - k; am = a > am ? a : am; } }
+        }
+        am = otg_wave_max_i32(am);
+        if ((long long)s * (pl + tl) > 3ll * cap * (am > 0 ? am : 1)) overflow = true;
+      }
       if (s > pl + tl + 2) break;
     }
     if (done) {
