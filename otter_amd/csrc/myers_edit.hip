@@ -325,7 +325,7 @@ int launch_one(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_task* d_tas
   const uint32_t grid_res = (uint32_t)ctx->n_cu * (uint32_t)per_cu;
   uint32_t grid = grid_res < want ? grid_res : want;
   if (grid == 0) return OTG_OK;
-  u64* ws = (u64*)otg_slot(ctx, SLOT_AUX8, (size_t)grid_max * WPB * 4 * (size_t)MAXBLK * 5 * sizeof(u64));
+  u64* ws = (u64*)otg_slot(ctx, SLOT_AUX8, (size_t)grid_max * WPB * 8 * (size_t)MAXBLK * 5 * sizeof(u64));   // up to 8 pairs per wave
   if (!ws) return OTG_ERR_HIP;
   hipLaunchKernelGGL((myers_edit_kernel<BPL, GL, WPB>), dim3(grid), dim3(WPB * 64), 0, ctx->stream, d_arena, d_tasks, d_todo, d_n_todo, n_tasks,
                      d_scores, d_cells, ticket, n_overflow, overflow_list, ws, maxblk);
@@ -336,18 +336,19 @@ int launch_one(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_task* d_tas
 
 // One tier of the bit-parallel engine: tasks from (d_todo, d_n_todo) (or all n_tasks when d_todo is null);
 // tasks it cannot finish exactly are appended to overflow_list / n_overflow.
-// tier: 0 = 16-lane groups (4 pairs / wave), 1 = 32-lane groups, 2 = whole wave, 3 = whole wave x 2 blocks per lane,
-//       4 = whole wave x 4 blocks per lane.
+// tier: 0 = 8-lane groups (8 pairs / wave), 1 = 16-lane groups, 2 = 32-lane groups, 3 = whole wave,
+//       4 = whole wave x 2 blocks per lane, 5 = whole wave x 4 blocks per lane.
 int otg_launch_myers(otg_ctx* ctx, int tier, const uint8_t* d_arena, const otg_align_task* d_tasks, const uint32_t* d_todo,
                      const uint32_t* d_n_todo, uint32_t n_tasks, int32_t* d_scores, uint64_t* d_cells,
                      uint32_t* ticket, uint32_t* n_overflow, uint32_t* overflow_list)
 {
   int rc;
   switch (tier) {
-    case 0: rc = launch_one<1, 16>(ctx, d_arena, d_tasks, d_todo, d_n_todo, n_tasks, d_scores, d_cells, ticket, n_overflow, overflow_list); break;
-    case 1: rc = launch_one<1, 32>(ctx, d_arena, d_tasks, d_todo, d_n_todo, n_tasks, d_scores, d_cells, ticket, n_overflow, overflow_list); break;
-    case 2: rc = launch_one<1, 64>(ctx, d_arena, d_tasks, d_todo, d_n_todo, n_tasks, d_scores, d_cells, ticket, n_overflow, overflow_list); break;
-    case 3: rc = launch_one<2, 64>(ctx, d_arena, d_tasks, d_todo, d_n_todo, n_tasks, d_scores, d_cells, ticket, n_overflow, overflow_list); break;
+    case 0: rc = launch_one<1, 8>(ctx, d_arena, d_tasks, d_todo, d_n_todo, n_tasks, d_scores, d_cells, ticket, n_overflow, overflow_list); break;
+    case 1: rc = launch_one<1, 16>(ctx, d_arena, d_tasks, d_todo, d_n_todo, n_tasks, d_scores, d_cells, ticket, n_overflow, overflow_list); break;
+    case 2: rc = launch_one<1, 32>(ctx, d_arena, d_tasks, d_todo, d_n_todo, n_tasks, d_scores, d_cells, ticket, n_overflow, overflow_list); break;
+    case 3: rc = launch_one<1, 64>(ctx, d_arena, d_tasks, d_todo, d_n_todo, n_tasks, d_scores, d_cells, ticket, n_overflow, overflow_list); break;
+    case 4: rc = launch_one<2, 64>(ctx, d_arena, d_tasks, d_todo, d_n_todo, n_tasks, d_scores, d_cells, ticket, n_overflow, overflow_list); break;
     default: rc = launch_one<4, 64>(ctx, d_arena, d_tasks, d_todo, d_n_todo, n_tasks, d_scores, d_cells, ticket, n_overflow, overflow_list); break;
   }
   if (rc) return rc;

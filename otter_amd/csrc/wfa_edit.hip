@@ -353,12 +353,13 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_kernel_v2(
       const int need = (int)(route_margin * (est + (ef ? 0.0f : (float)dlen)));
       // threshold of tier t: rows of its lane schedule minus the free ends (myers_edit.hip)
       const int fe = ef ? (t.pattern_begin_free + t.pattern_end_free + 1) / 2 + 2 : 2;
-      int tier = 5;
-      if (need <= 16192 - fe) tier = 4;
-      if (need <= 8128 - fe) tier = 3;
-      if (need <= 4096 - fe) tier = 2;
-      if (need <= 2048 - fe) tier = 1;
-      if (need <= 1024 - fe) tier = 0;
+      int tier = 6;
+      if (need <= 16192 - fe) tier = 5;
+      if (need <= 8128 - fe) tier = 4;
+      if (need <= 4096 - fe) tier = 3;
+      if (need <= 2048 - fe) tier = 2;
+      if (need <= 1024 - fe) tier = 1;
+      if (need <= 512 - fe) tier = 0;
       const uint32_t q = otg_wave_atomic_add(route_cnt + tier, 1u);
       route_lists[(size_t)tier * route_stride + q] = ti;
     } else if (overflow && overflow_list) {
@@ -393,11 +394,11 @@ int otg_launch_edit_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_t
   if (!cnt || !todo) return OTG_ERR_HIP;
   HIP_TRY(ctx, hipMemsetAsync(cnt, 0, 8 * sizeof(uint32_t), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(cnt + 16, 0, 16 * sizeof(uint32_t), ctx->stream));
-  // lists[t] (t = 0..4) feed the bit-parallel tiers, lists[5] the wide wavefront tier, listG its overflow.  The
+  // lists[t] (t = 0..5) feed the bit-parallel tiers, lists[6] the wide wavefront tier, listG its overflow.  The
   // first kernel routes every pair it cannot finish to the tier matching its estimated distance; a tier that is too
   // narrow appends the pair to the next list.  cnt[32 + t] = length of lists[t].
   uint32_t* const lists = todo;
-  uint32_t* listG = todo + 6 * (size_t)n_tasks;
+  uint32_t* listG = todo + 7 * (size_t)n_tasks;
   uint32_t* const rc = cnt + 32;
   HIP_TRY(ctx, hipMemsetAsync(rc, 0, 8 * sizeof(uint32_t), ctx->stream));
   static const bool no_myers = getenv("OTG_NO_MYERS") != nullptr;
@@ -412,19 +413,19 @@ int otg_launch_edit_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_t
     if (grid > want) grid = want;
     // without routing everything unfinished goes to lists[0] (or straight to the wide wavefront tier)
     hipLaunchKernelGGL((wfa_edit_kernel_v2<CAP, WPB>), dim3(grid), dim3(WPB * 64), lds, ctx->stream, d_arena, d_tasks,
-                       d_todo, d_n_todo, n_tasks, d_scores, d_cells, cnt + 0, no_myers ? rc + 5 : rc + 0,
-                       no_myers ? lists + 5 * (size_t)n_tasks : lists, no_myers ? 0.0f : 1.0f,
+                       d_todo, d_n_todo, n_tasks, d_scores, d_cells, cnt + 0, no_myers ? rc + 6 : rc + 0,
+                       no_myers ? lists + 6 * (size_t)n_tasks : lists, no_myers ? 0.0f : 1.0f,
                        (no_myers || no_route) ? (uint32_t*)nullptr : rc, lists, n_tasks, route_margin);
   }
   if (!no_myers) {
-    uint32_t* const tick[5] = {cnt + 2, cnt + 4, cnt + 6, cnt + 20, cnt + 22};
-    for (int tier = 0; tier < 5; ++tier) {
+    uint32_t* const tick[6] = {cnt + 2, cnt + 4, cnt + 6, cnt + 20, cnt + 22, cnt + 24};
+    for (int tier = 0; tier < 6; ++tier) {
       const int rc_ = otg_launch_myers(ctx, tier, d_arena, d_tasks, lists + (size_t)tier * n_tasks, rc + tier, n_tasks, d_scores, d_cells,
                                        tick[tier], rc + tier + 1, lists + (size_t)(tier + 1) * n_tasks);
       if (rc_) return rc_;
     }
   }
-  const uint32_t* cur = lists + 5 * (size_t)n_tasks; const uint32_t* cur_n = rc + 5;
+  const uint32_t* cur = lists + 6 * (size_t)n_tasks; const uint32_t* cur_n = rc + 6;
   if (kernel_ms) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   {
     constexpr int CAP = 8192, WPB = 1;                         // 32 KB per wave -> 5 waves / CU, scores up to ~4000
@@ -449,8 +450,8 @@ int otg_launch_edit_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_t
     hipError_t er = hipStreamSynchronize(ctx->stream);
     uint32_t h[40];
     (void)hipMemcpy(h, cnt, sizeof(h), hipMemcpyDeviceToHost);
-    fprintf(stderr, "[otg] edit: %s; inputs of the bit-parallel tiers 0..4: %u %u %u %u %u, wide wavefront tier %u, its overflow %u\n",
-            hipGetErrorString(er), h[32], h[33], h[34], h[35], h[36], h[37], h[17]);
+    fprintf(stderr, "[otg] edit: %s; inputs of the bit-parallel tiers 0..5: %u %u %u %u %u %u, wide wavefront tier %u, its overflow %u\n",
+            hipGetErrorString(er), h[32], h[33], h[34], h[35], h[36], h[37], h[38], h[17]);
   }
   if (kernel_ms) {
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
