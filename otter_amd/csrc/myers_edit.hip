@@ -13,7 +13,7 @@
 // one-lane rotate per step (DPP row_ror for 16-lane groups, ds_bpermute for 32, wave_ror for 64).  Only the
 // Ukkonen band -KL <= i - j <= KU (KL = (K - d)/2, KU = (K + d)/2 for a global alignment, d = m - n >= 0) is evaluated; a superblock enters the band initialised as in
 // Edlib (Pv = ~0, score = score_above + rows) and the block at the top of the band takes hin = +1.  With
-// KL + KU <= (GL-1)*64*BPL + 64 (i.e. K up to that many rows) a lane has left its superblock before the next one (B + GL) enters the band, so
+// KL + KU <= (GL-1)*64*BPL + GL (i.e. K up to about that many rows) a lane has left its superblock before the next one (B + GL) enters the band, so
 // narrow bands (within-allele pairs) run four to a wave and only wide ones need the whole wave.
 // The computed score is exact iff it is <= K; otherwise the task is appended to the overflow list and handled
 // by the next tier (larger group / more blocks per lane, finally the wavefront kernel).
@@ -114,14 +114,14 @@ __global__ __launch_bounds__(WPB * 64) void myers_edit_kernel(
     const int d = m - n;
     const int nblk = (m + 63) >> 6;
     const int nsb = (m + SB - 1) / SB;
-    // Ukkonen band for the threshold K: an alignment that starts on diagonal e0 in [0, pbf], ends on e1 in [d - pef, d]
-    // and visits diagonal e pays at least |e - e0| + |e - e1| indels, so cost <= K confines it to
-    // -KL <= i - j <= KU with KU = (K + d + pbf) / 2, KL = (K - d + pef) / 2 (rounded up): K + 1 + free ends
-    // diagonals, not 2K + d + 1.  The lane schedule holds KL + KU <= R rows apart (see header).
-    constexpr int R = (GL - 1) * SB + 64;
-    const int K = R - 2 - (pbf + pef + 1) / 2;
-    const int KU = (K + d + pbf + 1) / 2, KL = (K - d + pef + 1) / 2;
-    if (nblk > maxblk || K < d || K < 1 || KL < 0 || n < 1 || pbf > d || pef > d) unsupported = true;
+    // Ukkonen band for the largest threshold K this lane schedule (R rows) can certify, see otg_myers_band
+    // R: a lane must have left superblock B (last step SB*B + SB-1 + KL + B) before B + GL enters the band
+    // (first step SB*(B+GL) - KU + B + GL)  <=>  KL + KU <= SB*(GL-1) + GL
+    constexpr int R = (GL - 1) * SB + GL;
+    const int K = otg_myers_threshold(R, d, pbf, pef);
+    int KL, KU;
+    otg_myers_band(K, d, pbf, pef, &KL, &KU);
+    if (nblk > maxblk || K < d - pbf - pef || K < 1 || KL + KU > R || n < 1 || pbf > d || pef > d) unsupported = true;
     if (!has_task) unsupported = true;
 
     // ---- pattern match masks per 64-row block: A, C, G, T, X (one further byte value), built by the group

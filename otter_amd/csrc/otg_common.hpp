@@ -92,6 +92,32 @@ __device__ __forceinline__ int otg_wave_max_i32(int v)
   return __builtin_amdgcn_readlane(v, 63);
 }
 
+// Band of the bit-parallel edit tiers (myers_edit.hip) for a cost threshold K.  Rows i (pattern), columns j (text),
+// d = m - n >= 0; the alignment starts on a diagonal e0 in [0, pbf] and ends on e1 in [d - pef, d].  A path of cost
+// <= K that visits diagonal e pays at least |e - e0| + |e - e1| indels and needs |e0 - e1| <= K, hence
+//   e <= KU = min((K + d + pbf) / 2, K + pbf)      and      e >= -KL, KL = max(0, min((K - d + pef) / 2, K)).
+__device__ __forceinline__ void otg_myers_band(int K, int d, int pbf, int pef, int* KL, int* KU)
+{
+  const int u1 = (K + d + pbf + 1) / 2, u2 = K + pbf;
+  *KU = u1 < u2 ? u1 : u2;
+  int l = (K - d + pef + 1) / 2;
+  if (l > K) l = K;
+  if (K - d + pef < 0) l = 0;
+  *KL = l < 0 ? 0 : l;
+}
+// Largest threshold K whose band fits R rows of lane schedule (KL + KU <= R, monotone in K).
+__device__ __forceinline__ int otg_myers_threshold(int R, int d, int pbf, int pef)
+{
+  int lo = 0, hi = R;            // invariant: band(lo) fits (K = 0: KL + KU <= pbf + small), band(hi + 1) unknown
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    int kl, ku;
+    otg_myers_band(mid, d, pbf, pef, &kl, &ku);
+    if (kl + ku <= R) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
 // ---- match-run extension helpers shared by the wavefront kernels -------------------------------------
 __device__ __forceinline__ uint64_t otg_load8(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
 

@@ -351,15 +351,18 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_kernel_v2(
       // no safety margin: trying a tier that fails costs half of going one tier up straight away, so the median
       // estimate is the cheapest choice (OTG_EDIT_ROUTE_MARGIN overrides, in percent)
       const int need = (int)(route_margin * (est + (ef ? 0.0f : (float)dlen)));
-      // threshold of tier t: rows of its lane schedule minus the free ends (myers_edit.hip)
-      const int fe = ef ? (t.pattern_begin_free + t.pattern_end_free + 1) / 2 + 2 : 2;
+      // threshold of tier t for this pair's length difference and free ends (same function the tier itself uses)
       int tier = 6;
-      if (need <= 16192 - fe) tier = 5;
-      if (need <= 8128 - fe) tier = 4;
-      if (need <= 4096 - fe) tier = 3;
-      if (need <= 2048 - fe) tier = 2;
-      if (need <= 1024 - fe) tier = 1;
-      if (need <= 512 - fe) tier = 0;
+      {
+        const bool swap = !ef && pl < tl;                       // the bit-parallel kernel puts the longer sequence in the rows
+        const int dd = swap ? tl - pl : pl - tl;
+        const int fb = ef ? (int)t.pattern_begin_free : 0, fe2 = ef ? (int)t.pattern_end_free : 0;
+        if (dd >= 0) {
+          const int rows[6] = {456, 976, 2016, 4096, 8128, 16192};    // (GL-1)*64*BPL + GL of the six tiers
+#pragma unroll
+          for (int q = 5; q >= 0; --q) if (need <= otg_myers_threshold(rows[q], dd, fb < dd ? fb : dd, fe2 < dd ? fe2 : dd)) tier = q;
+        }
+      }
       const uint32_t q = otg_wave_atomic_add(route_cnt + tier, 1u);
       route_lists[(size_t)tier * route_stride + q] = ti;
     } else if (overflow && overflow_list) {
