@@ -133,3 +133,39 @@ def test_edit_text_longer_than_pattern(gpu, oracle):
         pairs.append((a, b) if len(a) <= len(b) else (b, a))
     arena, tasks = pair_tasks(pairs)
     assert np.array_equal(gpu.edit_distance_batch(arena, tasks), oracle.edit_distance_batch(arena, tasks))
+
+
+def test_edit_band_edges(gpu, oracle):
+    """Distances placed right at the thresholds the bit-parallel tiers can certify (K + 1 diagonals per tier: about
+    456, 976, 2016 rows for 8/16/32-lane groups): two far-apart block indels drive the optimal path to one edge of the
+    band and back, with and without free pattern ends.  Pairs just under a threshold must be exact in that tier,
+    pairs just over it must move up a tier — either way the score equals the oracle's."""
+    rng = np.random.default_rng(17)
+    pairs, forms = [], []
+    for T in (456, 976, 2016):
+        for trial in range(14):
+            L = int(rng.integers(1400, 2600))
+            core = rand_seq(rng, L)
+            tot = T + int(rng.integers(-8, 9))
+            d1 = int(rng.integers(0, tot + 1)) if trial % 3 else tot
+            d2 = tot - d1
+            p_, q_ = sorted(rng.integers(100, L - 100, 2).tolist())
+            if trial % 2:
+                a = core[:p_] + rand_seq(rng, d1) + core[p_:]
+                b = core[:q_] + rand_seq(rng, d2) + core[q_:]
+            else:           # both blocks in the same sequence: the path leaves the main diagonal by d1 + d2
+                a = core[:p_] + rand_seq(rng, d1) + core[p_:q_] + rand_seq(rng, d2) + core[q_:]
+                b = core
+            if trial % 5 == 4:
+                a = mutate(rng, a, 0.01)
+            if len(b) > len(a):
+                a, b = b, a
+            d = len(a) - len(b)
+            f = [None, (0, d, 0, 0), (d, 0, 0, 0), (d // 2, d - d // 2, 0, 0), None][trial % 5]
+            pairs.append((a, b))
+            forms.append(f)
+    arena, tasks = pair_tasks(pairs, forms)
+    got = gpu.edit_distance_batch(arena, tasks)
+    exp = oracle.edit_distance_batch(arena, tasks)
+    bad = [(i, int(got[i]), int(exp[i])) for i in range(len(pairs)) if got[i] != exp[i]]
+    assert not bad, bad[:10]
