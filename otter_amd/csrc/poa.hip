@@ -43,6 +43,7 @@ struct PoaDev {
   // outputs
   const uint64_t* out_off; uint32_t* out_len; uint8_t* out_arena; uint32_t* out_start; int32_t* status;
   int dbg_skip;
+  const uint32_t* order;      // graphs in decreasing order of work (longest first: shortest tail)
 };
 
 __global__ void poa_count_kernel(const uint8_t* __restrict__ cig_arena, const otg_poa_member* __restrict__ members,
@@ -235,10 +236,10 @@ __global__ __launch_bounds__(64) void poa_graph_kernel(PoaDev P)
 // prefix counts, and an 'M' that follows an 'M' only bumps the implicit backbone edge ref-1 -> ref (distinct
 // addresses per lane), so only the ops around mismatches and gaps (15-35 % for ONT reads) take the serial path.
 // One wave owns a graph, so plain read-modify-writes replace the atomics of v1.
-__global__ __launch_bounds__(256) void poa_graph_wave_kernel(PoaDev P)
+__global__ __launch_bounds__(64, 8) void poa_graph_wave_kernel(PoaDev P)
 {
   const int lane = threadIdx.x & 63;
-  const uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t g = P.order[blockIdx.x];      // one single-wave block per graph: the dispatcher refills a wave slot as soon as its graph is done
   if (g >= P.n_graphs) return;
   const otg_poa_graph G = P.graphs[g];
   const uint64_t no = P.node_off[g], eo = P.edge_off[g], so = P.start_off[g];
@@ -492,6 +493,20 @@ int otg_launch_poa(otg_ctx* ctx, const uint8_t* d_seq_arena, const uint8_t* d_ci
   P.out_off = d_node_off;     // consensus g is written into [node_off[g], node_off[g+1]) of out_arena
   P.out_len = d_out_len;
   P.dbg_skip = getenv("OTG_POA_DBG_SKIP") ? 1 : 0;
+  {
+    // longest graphs first (work ~ op-string bytes = nodes + edges capacity computed above)
+    std::vector<uint32_t> order(n_graphs);
+    for (uint32_t g = 0; g < n_graphs; ++g) order[g] = g;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+      const uint64_t wa = (edge_off[a + 1] - edge_off[a]) + (node_off[a + 1] - node_off[a]), wb = (edge_off[b + 1] - edge_off[b]) + (node_off[b + 1] - node_off[b]);
+      return wa != wb ? wa > wb : a < b;
+    });
+    uint32_t* d_order = (uint32_t*)otg_slot(ctx, SLOT_P18, (size_t)n_graphs * sizeof(uint32_t));
+    if (!d_order) return OTG_ERR_HIP;
+    HIP_TRY(ctx, hipMemcpyAsync(d_order, order.data(), (size_t)n_graphs * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    P.order = d_order;
+  }
   HIP_TRY(ctx, hipMemcpyAsync(d_node_off, node_off.data(), (size_t)(n_graphs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(d_edge_off, edge_off.data(), (size_t)(n_graphs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(d_start_off, start_off.data(), (size_t)(n_graphs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
@@ -500,7 +515,7 @@ int otg_launch_poa(otg_ctx* ctx, const uint8_t* d_seq_arena, const uint8_t* d_ci
   hipLaunchKernelGGL(poa_init_kernel, dim3(gi), dim3(256), 0, ctx->stream, P);
   static const bool thread_per_graph = getenv("OTG_POA_THREAD") != nullptr;
   if (thread_per_graph) hipLaunchKernelGGL(poa_graph_kernel, dim3((n_graphs + 63) / 64), dim3(64), 0, ctx->stream, P);
-  else hipLaunchKernelGGL(poa_graph_wave_kernel, dim3((n_graphs + 3) / 4), dim3(256), 0, ctx->stream, P);
+  else hipLaunchKernelGGL(poa_graph_wave_kernel, dim3(n_graphs), dim3(64), 0, ctx->stream, P);
   HIP_TRY(ctx, hipGetLastError());
   return OTG_OK;
 }
