@@ -501,8 +501,20 @@ __global__ __launch_bounds__(256) void wfa_affine_bound1_kernel(
     const uint8_t* T = arena + t.text_off;
     const int pl = (int)t.pattern_len, tl = (int)t.text_len;
     const bool ef = t.endsfree != 0;
-    const int pef = ef ? t.pattern_end_free : 0, tef = ef ? t.text_end_free : 0;
-    const int lo0 = ef ? imax(-t.pattern_begin_free, -pl) : 0, hi0 = ef ? imin(t.text_begin_free, tl) : 0;
+    int pbf = ef ? imin(t.pattern_begin_free, pl) : 0, tbf = ef ? imin(t.text_begin_free, tl) : 0;
+    int pef = ef ? t.pattern_end_free : 0, tef = ef ? t.text_end_free : 0;
+    // A start range too wide for the band (free leading gaps) is handled on the REVERSED sequences: gap-affine
+    // scores are symmetric under reversing both strings, free begins become free ends, which the band follows.
+    const bool rev = pbf + tbf + 1 > 40 && imin(pef, pl) + imin(tef, tl) + 1 <= 40;
+    if (rev) { int x = pbf; pbf = imin(pef, pl); pef = x; x = tbf; tbf = imin(tef, tl); tef = x; }
+    const int lo0 = -pbf, hi0 = tbf;
+    // 8 bytes of the (possibly reversed) pattern / text starting at position pos in [0, len]
+    auto ld8s = [&](const uint8_t* S, int len, int pos) -> uint64_t {
+      if (!rev) return otg_load8(S + pos);
+      const int a = len - 8 - pos;                        // reversed byte i = S[len-1-pos-i]
+      const uint64_t x = otg_load8(S + (a > 0 ? a : 0)) << (8 * imin(a < 0 ? -a : 0, 7));
+      return __builtin_bswap64(x);
+    };
     int result = 0x7fffffff;
     if (hi0 - lo0 + 1 <= 40 && pl > 0 && tl > 0 && pl < 32766 && tl < 32766) {
       int bk0 = ((lo0 + hi0) >> 1) - 32;                 // diagonal of lane 0
@@ -515,7 +527,7 @@ __global__ __launch_bounds__(256) void wfa_affine_bound1_kernel(
         do {
           const int h = cur, v = h - k;
           const int vc = imin(imax(v, 0), pl), hc = imin(imax(h, 0), tl);
-          const uint64_t xx = otg_load8(P + vc) ^ otg_load8(T + hc);
+          const uint64_t xx = ld8s(P, pl, vc) ^ ld8s(T, tl, hc);
           int m = xx ? (int)(__builtin_ctzll(xx) >> 3) : 8;
           m = imin(m, imin(pl - v, tl - h));
           if (more) cur = h + m;
