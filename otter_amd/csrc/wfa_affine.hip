@@ -1142,80 +1142,91 @@ __global__ __launch_bounds__(NW * 64, WPEU) void wfa_affine_kernel_v4(
           qn = wq; ++pass;
         }
       };
-      // LDS operands one chunk ahead (clamped index: lanes past the window never store)
-      int jn = imin(c0 + lane - kbase, CAP - 2);
-      int n_iold = LI[jn], n_dx = LD[jn + 1], n_mo = Mn[jn], n_mor = Mn[jn + 1], n_mm = Mm[jn];
-      int carryI = bI, carryMo = bMl;
-      bool p_pending = false, p_in = false, p_valid = false, p_probe = false;
-      int p_k = 0, p_h = 0, p_v = 0;
-      uint64_t p_a = 0, p_b = 0;
-      auto finish = [&]() {
-        int h = p_h, v = p_v;
-        bool more = false;
-        if (p_probe) {
-          const uint64_t xx = p_a ^ p_b;
-          int m = xx ? (__builtin_ctzll(xx) >> 1) : 32;
-          const int rem = imin(pl - v, tl - h);
-          m = imin(m, rem);
-          v += m; h += m;
-          more = (m == 32) && v < pl && h < tl;
-        }
-        if (p_in) Mn[p_k - kbase] = (int16_t)(p_valid ? h : NUL16);
-        const unsigned long long mq = __ballot(more);
-        if (more) {
+      if (s == 0) {
+        // score 0: offset max(k, 0) on every start diagonal, no I/D wavefronts; the drain extends them from scratch
+        for (int c = c0; c < c1; c += 64) {
+          const int k = c + lane;
+          const int jl = k - kbase;
+          const bool in = k <= hi;
+          const int h = k > 0 ? k : 0, v = h - k;
+          const bool valid = in && h <= tl && v <= pl;
+          const bool more = valid && v < pl && h < tl;
+          if (in) { LI[jl] = (int16_t)NUL16; LD[jl] = (int16_t)NUL16; Mn[jl] = (int16_t)(valid ? h : NUL16); btrow[k] = 0; }
+          const unsigned long long mq = __ballot(more);
           const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mq, 0u));
-          queue[qn + rank] = (uint16_t)(p_k - lo);
+          queue[more ? qn + rank : QCAP - 1] = (uint16_t)(k - lo);
+          qn += __builtin_popcountll(mq);
+          if (qn + 128 > QCAP) drain();
         }
-        qn += __builtin_popcountll(mq);
-      };
-      for (int c = c0; c < c1; c += 64) {
-        const int k = c + lane;
-        const int jl = k - kbase;
-        const bool in = k <= hi;
-        const int iold = n_iold;                              // I[s-1][k]
-        int dx = n_dx;                                        // D[s-1][k+1]
-        const int mo = n_mo;                                  // M[s-o-e][k]
-        int dop = n_mor;                                      // M[s-o-e][k+1]
-        const int mm = n_mm;                                  // M[s-x][k]
-        if (lane == 63 && c + 64 >= c1) { dx = bD; dop = bMr; }   // first diagonal of the next wave's share
-        jn = imin(jl + 64, CAP - 2);
-        n_iold = LI[jn]; n_dx = LD[jn + 1]; n_mo = Mn[jn]; n_mor = Mn[jn + 1]; n_mm = Mm[jn];
-        int ix = dpp_shr1(iold);                              // I[s-1][k-1]
-        if (lane == 0) ix = carryI;
-        carryI = __builtin_amdgcn_readlane(iold, 63);
-        int io = dpp_shr1(mo);                                // M[s-o-e][k-1]
-        if (lane == 0) io = carryMo;
-        carryMo = __builtin_amdgcn_readlane(mo, 63);
-        uint32_t bits = 0;
-        int ins, del;
-        if (ix >= io) { ins = ix; bits |= 4u; } else ins = io;
-        ins += 1;
-        if (dx >= dop) { del = dx; bits |= 8u; } else del = dop;
-        const int mis = mm + 1;
-        int mx = imax(del, imax(mis, ins));
-        uint32_t org = 0;
-        if (mx == ins) org = 2;
-        if (mx == del) org = 1;
-        if (mx == mis) org = 0;
-        bits |= org;
-        if (s == 0) { mx = k > 0 ? k : 0; ins = NUL16; del = NUL16; bits = 0; }   // selects, not a branch
-        const int h = mx, v = mx - k;
-        const bool valid = in && mx >= 0 && h <= tl && v <= pl;
-        const bool probe = valid && v < pl && h < tl;
-        if (p_pending) finish();                              // retire the previous chunk (its probe was issued one iteration ago)
-        uint64_t a, b;
-        { const int vc = imin(imax(v, 0), pl), hc = imin(imax(h, 0), tl);      // clamped: always inside arena + slack
-          a = ld32b(0, vc); b = ld32b(offT, hc); }
-        if (in) {
-          LI[jl] = (int16_t)(ins < 0 ? NUL16 : ins);
-          LD[jl] = (int16_t)(del < 0 ? NUL16 : del);
-          btrow[k] = (uint8_t)bits;
+        drain();
+      } else {
+        // LDS operands one chunk ahead (clamped index: lanes past the window never store)
+        int jn = imin(c0 + lane - kbase, CAP - 2);
+        int n_iold = LI[jn], n_dx = LD[jn + 1], n_mo = Mn[jn], n_mor = Mn[jn + 1], n_mm = Mm[jn];
+        int carryI = bI, carryMo = bMl;
+        bool p_pending = false, p_in = false, p_valid = false, p_probe = false;
+        int p_k = 0, p_h = 0, p_v = 0;
+        uint64_t p_a = 0, p_b = 0;
+        // retire a chunk: branch-free, lanes that must not store aim at the unused last slot of the row / queue
+        auto finish = [&]() {
+          const uint64_t xx = p_a ^ p_b;
+          int m = xx ? (int)(__builtin_ctzll(xx) >> 1) : 32;
+          m = imin(m, imin(pl - p_v, tl - p_h));
+          m = p_probe ? m : 0;
+          const int h = p_h + m, v = p_v + m;
+          const bool more = p_probe && m == 32 && v < pl && h < tl;
+          Mn[p_in ? p_k - kbase : CAP - 1] = (int16_t)(p_valid ? h : NUL16);
+          const unsigned long long mq = __ballot(more);
+          const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mq, 0u));
+          queue[more ? qn + rank : QCAP - 1] = (uint16_t)(p_k - lo);
+          qn += __builtin_popcountll(mq);
+        };
+        for (int c = c0; c < c1; c += 64) {
+          const int k = c + lane;
+          const int jl = k - kbase;
+          const bool in = k <= hi;
+          const int iold = n_iold;                              // I[s-1][k]
+          int dx = n_dx;                                        // D[s-1][k+1]
+          const int mo = n_mo;                                  // M[s-o-e][k]
+          int dop = n_mor;                                      // M[s-o-e][k+1]
+          const int mm = n_mm;                                  // M[s-x][k]
+          if (lane == 63 && c + 64 >= c1) { dx = bD; dop = bMr; }   // first diagonal of the next wave's share
+          jn = imin(jl + 64, CAP - 2);
+          n_iold = LI[jn]; n_dx = LD[jn + 1]; n_mo = Mn[jn]; n_mor = Mn[jn + 1]; n_mm = Mm[jn];
+          int ix = dpp_shr1(iold);                              // I[s-1][k-1]
+          if (lane == 0) ix = carryI;
+          carryI = __builtin_amdgcn_readlane(iold, 63);
+          int io = dpp_shr1(mo);                                // M[s-o-e][k-1]
+          if (lane == 0) io = carryMo;
+          carryMo = __builtin_amdgcn_readlane(mo, 63);
+          uint32_t bits = 0;
+          int ins, del;
+          if (ix >= io) { ins = ix; bits |= 4u; } else ins = io;
+          ins += 1;                                             // a null (-32768) creeps up by one per score: stays negative for < 32768 scores
+          if (dx >= dop) { del = dx; bits |= 8u; } else del = dop;
+          const int mis = mm + 1;
+          const int mx = imax(del, imax(mis, ins));
+          uint32_t org = 0;
+          if (mx == ins) org = 2;
+          if (mx == del) org = 1;
+          if (mx == mis) org = 0;
+          bits |= org;
+          const int h = mx, v = mx - k;
+          const bool valid = in && (uint32_t)h <= (uint32_t)tl && (uint32_t)v <= (uint32_t)pl;
+          const bool probe = valid && v < pl && h < tl;
+          if (p_pending) finish();                              // retire the previous chunk (its probe was issued one iteration ago)
+          const uint64_t a = ld32b(0, valid ? v : 0), b = ld32b(offT, valid ? h : 0);
+          if (in) {
+            LI[jl] = (int16_t)ins;
+            LD[jl] = (int16_t)del;
+            btrow[k] = (uint8_t)bits;
+          }
+          p_pending = true; p_in = in; p_valid = valid; p_probe = probe; p_k = k; p_h = h; p_v = v; p_a = a; p_b = b;
+          if (qn + 128 > QCAP) { finish(); p_pending = false; drain(); }
         }
-        p_pending = true; p_in = in; p_valid = valid; p_probe = probe; p_k = k; p_h = h; p_v = v; p_a = a; p_b = b;
-        if (qn + 128 > QCAP) { finish(); p_pending = false; drain(); }
+        if (p_pending) finish();
+        drain();
       }
-      if (p_pending) finish();
-      drain();
       idlo = s == 0 ? 1 : lo; idhi = s == 0 ? 0 : hi;
       // termination: the first diagonal (ascending) whose fully extended offset satisfies the end condition
       int cand = 0x7fffffff;
