@@ -110,3 +110,25 @@ def test_affine_bounded_tandem_repeats(gpu, oracle):
     bad = [i for i in range(len(pairs)) if gc[i] != ec[i]]
     assert not bad, bad[:10]
     assert np.array_equal(gcells, ecells)
+
+
+def test_affine_non_acgt_bytes(gpu, oracle):
+    """Bytes outside ACGT (N, lower case, IUPAC) cannot be packed to 2 bits: those alignments must take the
+    byte-compare tiers and still match the oracle op for op."""
+    rng = np.random.default_rng(26)
+    pairs, forms = [], []
+    for i in range(60):
+        L = int(rng.integers(200, 1200))
+        a = bytearray(mutate(rng, tr_seq(rng, L) if i % 2 else rand_seq(rng, L), 0.03))
+        b = bytearray(mutate(rng, bytes(a), 0.08))
+        for s_ in (a, b) if i % 3 else (a,):
+            for _ in range(int(rng.integers(1, 6))):
+                s_[int(rng.integers(0, len(s_)))] = b"NnacgtRY"[int(rng.integers(0, 8))]
+        pairs.append((bytes(a), bytes(b)))
+        forms.append(None if i % 4 else (0, 0, 0, 0))
+    arena, tasks = pair_tasks(pairs, forms)
+    gs, gc, gcells = gpu.affine_align_batch(arena, tasks, want_cells=True)
+    es, ec, ecells = oracle.affine_align_batch(arena, tasks, want_cells=True)
+    assert np.array_equal(gs, es)
+    assert gc == ec
+    assert np.array_equal(gcells, ecells)
