@@ -99,8 +99,9 @@ def main():
     def step():
         ctx.assemble_run()
         if dist is not None:
-            # end-of-run gather of the per-region allele records to rank 0 (RCCL over xGMI)
-            res = ctx.assemble_collect()
+            # end-of-run gather of the per-region allele records to rank 0 (RCCL over xGMI), straight from the
+            # library's device-resident result buffers: GPU -> GPU, one device-to-host copy on rank 0
+            res = ctx.assemble_device_results()
             g = parallel.gather_records(res, dist, rank, world, torch.device("cuda", local_rank))
             if rank == 0:
                 gathered["records"] = len(g["alleles"])

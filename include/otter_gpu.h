@@ -238,6 +238,13 @@ int otg_assemble_submit(otg_ctx* ctx, const otg_params* params,
 int otg_assemble_run(otg_ctx* ctx);
 /* Sizes needed by otg_assemble_collect for the last run.                                        */
 int otg_assemble_result_sizes(otg_ctx* ctx, uint32_t* n_alleles, uint64_t* seq_bytes);
+/* Device-resident results of the last run, for callers that forward them without a host round trip
+ * (one process per GPU: the end-of-run gather of allele records to rank 0, north_star / src/assemble.cpp:143-149
+ * in the single-process reference).  Pointers are HBM addresses on the context's device, valid until the next
+ * otg_assemble_submit / otg_assemble_run / otg_destroy; sizes: n_regions records, and the two figures of
+ * otg_assemble_result_sizes.  The library's stream is synchronised before returning.             */
+int otg_assemble_device_results(otg_ctx* ctx, const otg_region_result** d_regions, const otg_allele** d_alleles,
+                                const uint8_t** d_seqs);
 /* D2H of the results.  labels_out (nullable) gets the final per-read label (-1 unassigned).     */
 int otg_assemble_collect(otg_ctx* ctx,
                          otg_region_result* region_out,

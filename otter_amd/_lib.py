@@ -2,6 +2,7 @@
 if the HIP library is missing or no device is usable, every entry point raises."""
 import ctypes as C
 import os
+import sys
 import numpy as np
 from . import abi
 
@@ -12,7 +13,7 @@ EXPORTS = [
     "otg_params_default", "otg_create", "otg_destroy", "otg_last_error", "otg_device_count", "otg_exp_variant",
     "otg_edit_distance_batch", "otg_affine_align_batch", "otg_cluster_batch", "otg_poa_consensus_batch",
     "otg_genotype_cluster_batch", "otg_assemble_submit", "otg_assemble_run", "otg_assemble_result_sizes",
-    "otg_assemble_collect", "otg_assemble_stats",
+    "otg_assemble_collect", "otg_assemble_device_results", "otg_assemble_stats",
 ]
 
 _lib = None
@@ -28,6 +29,14 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise OtterGpuError("%s is missing: build it with `python -m otter_amd.build` (hipcc, gfx950). "
                                 "otter_amd has no CPU fallback." % LIB_PATH)
+        # A process that also uses PyTorch must load PyTorch's HIP runtime FIRST: torch wheels bundle their own
+        # libamdhip64 under the same soname, and whichever copy is mapped first serves both; with the system copy first
+        # torch.cuda finds no device (and RCCL cannot start).  The library itself does not depend on torch.
+        if "torch" not in sys.modules and os.environ.get("OTG_NO_TORCH_PRELOAD") is None:
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         _lib = C.CDLL(LIB_PATH)
         _lib.otg_last_error.restype = C.c_char_p
         _lib.otg_last_error.argtypes = [C.c_void_p]
@@ -48,6 +57,7 @@ class Context:
             raise OtterGpuError("otg_create(device=%d) failed (%d): %s" % (device, rc, (L.otg_last_error(None) or b"").decode()))
         self._h = h
         self._L = L
+        self.device = int(device)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -169,6 +179,31 @@ class Context:
                                           abi.ptr(res["seqs"]), C.c_uint64(res["seqs"].size), abi.ptr(res["labels"]))
         self._check(rc, "otg_assemble_collect")
         return res
+
+    def assemble_device_results(self):
+        """Device-resident results of the last run as zero-copy torch uint8 tensors on this context's GPU
+        (valid until the next submit / run): {"regions", "alleles", "seqs"} + counts.  Used by the multi-GPU
+        gather so that allele records travel GPU -> GPU (RCCL) without a host round trip."""
+        import torch
+        na = C.c_uint32(0)
+        sb = C.c_uint64(0)
+        self._check(self._L.otg_assemble_result_sizes(self._h, C.byref(na), C.byref(sb)), "otg_assemble_result_sizes")
+        pr, pa, ps = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._check(self._L.otg_assemble_device_results(self._h, C.byref(pr), C.byref(pa), C.byref(ps)), "otg_assemble_device_results")
+        dev = torch.device("cuda", self.device)
+
+        class _Span:          # minimal __cuda_array_interface__ carrier: torch.as_tensor wraps it without copying
+            def __init__(self, ptr, nbytes):
+                self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2, "strides": None}
+
+        def wrap(ptr, nbytes):
+            if not ptr or nbytes == 0:
+                return torch.zeros(0, dtype=torch.uint8, device=dev)
+            return torch.as_tensor(_Span(ptr, int(nbytes)), device=dev)
+
+        return {"regions": wrap(pr.value, self._n_regions * abi.region_result_dt.itemsize),
+                "alleles": wrap(pa.value, na.value * abi.allele_dt.itemsize),
+                "seqs": wrap(ps.value, sb.value), "n_alleles": int(na.value), "n_regions": int(self._n_regions)}
 
     def assemble_stats(self):
         st = np.zeros(1, dtype=abi.run_stats_dt)

@@ -893,6 +893,19 @@ int otg_assemble_collect(otg_ctx* ctx, otg_region_result* region_out, otg_allele
   return OTG_OK;
 }
 
+int otg_assemble_device_results(otg_ctx* ctx, const otg_region_result** d_regions, const otg_allele** d_alleles, const uint8_t** d_seqs)
+{
+  if (!ctx || !ctx->pipe || !ctx->pipe->ran) return otg_fail(ctx, OTG_ERR_ARG, "otg_assemble_device_results: no completed run");
+  Pipeline* pl = ctx->pipe;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  const bool empty = pl->n_regions == 0 || pl->n_reads == 0;
+  if (d_regions) *d_regions = empty ? nullptr : (const otg_region_result*)pl->buf[B_REGRES].p;
+  if (d_alleles) *d_alleles = (empty || !pl->out_alleles) ? nullptr : (const otg_allele*)pl->buf[B_OUTAL].p;
+  if (d_seqs) *d_seqs = (empty || !pl->out_seq_bytes) ? nullptr : (const uint8_t*)pl->buf[B_OUTSEQ].p;
+  return OTG_OK;
+}
+
 int otg_assemble_stats(otg_ctx* ctx, otg_run_stats* out)
 {
   if (!ctx || !ctx->pipe || !out) return otg_fail(ctx, OTG_ERR_ARG, "otg_assemble_stats: no run");

@@ -9,7 +9,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, as_tensors=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
@@ -26,6 +26,13 @@ def _worker(rank, world, port, q):
     # what Context.assemble_collect returns for a shard: only the shard's regions
     res = {"regions": full["regions"][a:b].copy(), "alleles": full["alleles"].copy(), "seqs": full["seqs"]}
     res["alleles"]["region"] -= a
+    if as_tensors:
+        # the form Context.assemble_device_results hands over on a GPU: flat uint8 tensors, sequence arena = exactly
+        # the bytes the records point at
+        nseq = int(res["alleles"]["seq_len"].astype(np.int64).sum())
+        res = {"alleles": torch.from_numpy(res["alleles"].view(np.uint8).reshape(-1).copy()),
+               "seqs": torch.from_numpy(np.ascontiguousarray(res["seqs"][:nseq]).copy()),
+               "regions": torch.from_numpy(res["regions"].view(np.uint8).reshape(-1).copy())}
     g = parallel.gather_records(res, dist, rank, world, torch.device("cpu"))
     if rank == 0:
         whole = oracle_lib.assemble_batch(P, batch)
@@ -40,14 +47,22 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_shard_and_gather():
+def _run(as_tensors, port_off):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + port_off
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, as_tensors)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(180)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def test_two_rank_shard_and_gather():
+    _run(False, 0)
+
+
+def test_two_rank_gather_from_device_style_tensors():
+    _run(True, 2000)

@@ -100,3 +100,30 @@ def test_batch_composition_independence(gpu, oracle):
         seqs_parts += [p["seqs"][int(a["seq_off"]):int(a["seq_off"]) + int(a["seq_len"])].tobytes() for a in p["alleles"]]
     assert seqs_whole == seqs_parts
     assert np.array_equal(np.concatenate([p["regions"]["fc"] for p in parts]), whole["regions"]["fc"])
+
+
+def test_device_results_gather_matches_collect(gpu):
+    """The multi-GPU path forwards the library's device-resident result buffers (otg_assemble_device_results) through
+    parallel.gather_records; with one rank over RCCL it must reproduce what otg_assemble_collect copies to the host."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from otter_amd import parallel
+    batch = synth.make_batch(12, len_range=(200, 600), n_reads=10, err="ont", seed=33)
+    P = abi.default_params()
+    gpu.assemble_submit(P, batch)
+    gpu.assemble_run()
+    host = gpu.assemble_collect()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29650 + os.getpid() % 300))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        dev = gpu.assemble_device_results()
+        g = parallel.gather_records(dev, dist, 0, 1, torch.device("cuda", 0))
+    finally:
+        dist.destroy_process_group()
+    assert len(g["alleles"]) == len(host["alleles"])
+    assert g["alleles"].tobytes() == host["alleles"].tobytes()
+    assert g["regions"].tobytes() == host["regions"].tobytes()
+    n = len(g["seqs"])
+    assert g["seqs"].tobytes() == host["seqs"][:n].tobytes()
