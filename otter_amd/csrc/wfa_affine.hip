@@ -1352,8 +1352,8 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
     return w;
   };
   uint32_t blocksS = std::min<uint32_t>((uint32_t)ctx->n_cu * 10, n_tasks), blocksM = std::min<uint32_t>((uint32_t)ctx->n_cu * 5, n_tasks);   // resident blocks per CU (LDS / VGPR limits)
-  uint32_t blocksX = std::min<uint32_t>((uint32_t)ctx->n_cu * 6, n_tasks);
-  AffWs wsS = lds_ws(1024, blocksS), wsM = lds_ws(2048, blocksM), wsX = lds_ws(1536, blocksX);
+  uint32_t blocksX = std::min<uint32_t>((uint32_t)ctx->n_cu * 7, n_tasks);
+  AffWs wsS = lds_ws(1024, blocksS), wsM = lds_ws(2048, blocksM), wsX = lds_ws(1472, blocksX);
   const size_t need = std::max(std::max(std::max(wsA.stride * wavesA, wsB.stride * wavesB), wsC.stride * (size_t)gridC * WPB),
                                std::max(std::max(wsS.stride * blocksS, wsM.stride * blocksM), wsX.stride * blocksX));
   uint8_t* wsp = (uint8_t*)otg_slot(ctx, SLOT_WF_WS, need);
@@ -1400,7 +1400,7 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
       else OTG_V4_LAUNCH(1024, 2, 2304, 5, blocksS, d_todo, d_n_todo, n_tasks, cnt + 24, cnt + 25, listS, wsS);
       const uint32_t* inM = listS; const uint32_t* inM_n = cnt + 25;
       if (!no_mid) {
-        OTG_V4_LAUNCH(1536, 4, 2688, 6, blocksX, (const uint32_t*)listS, (const uint32_t*)(cnt + 25), 0u, cnt + 28, cnt + 29, listX, wsX);
+        OTG_V4_LAUNCH(1472, 4, 2688, 7, blocksX, (const uint32_t*)listS, (const uint32_t*)(cnt + 25), 0u, cnt + 28, cnt + 29, listX, wsX);
         inM = listX; inM_n = cnt + 29;
       }
       if (nwm == 4) OTG_V4_LAUNCH(2048, 4, 3072, 5, blocksM, inM, inM_n, 0u, cnt + 26, cnt + 27, listM, wsM);
