@@ -17,6 +17,7 @@
 // when h>tlen or v>plen; k = h - v, offset = h.  End2end stops when M[s][tlen-plen] == tlen; ends-free
 // when any diagonal reaches a permitted boundary (score only: which diagonal does not matter).
 #include "otg_common.hpp"
+#include <algorithm>
 #include <cstdlib>
 
 namespace {
@@ -374,6 +375,46 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_kernel_v2(
   }
 }
 
+// ---- counting sort of a todo list by the number of columns of each pair (longest first, 32-column buckets).  The
+// bit-parallel tiers put 2-8 pairs into one wave, and a wave runs as long as its longest pair: neighbours in a sorted
+// list have nearly equal lengths, and starting with the long pairs shortens the tail of the persistent grid.
+constexpr int SORT_BUCKETS = 512;
+__device__ __forceinline__ int sort_bucket(const otg_align_task& t)
+{
+  const uint32_t n = t.pattern_len < t.text_len ? t.pattern_len : t.text_len;
+  const int b = (int)(n >> 5);
+  return SORT_BUCKETS - 1 - (b < SORT_BUCKETS ? b : SORT_BUCKETS - 1);          // descending length
+}
+__global__ void K_sort_hist(const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_ptr, const otg_align_task* __restrict__ tasks,
+                            uint32_t* __restrict__ hist)
+{
+  const uint32_t n = *n_ptr;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) atomicAdd(&hist[sort_bucket(tasks[list[i]])], 1u);
+}
+__global__ __launch_bounds__(SORT_BUCKETS) void K_sort_scan(uint32_t* __restrict__ hist)
+{
+  __shared__ uint32_t s[SORT_BUCKETS];
+  const int i = (int)threadIdx.x;
+  s[i] = hist[i];
+  __syncthreads();
+  for (int off = 1; off < SORT_BUCKETS; off <<= 1) {
+    const uint32_t v = i >= off ? s[i - off] : 0u;
+    __syncthreads();
+    s[i] += v;
+    __syncthreads();
+  }
+  hist[i] = s[i] - hist[i];                   // exclusive prefix = first output position of the bucket
+}
+__global__ void K_sort_scatter(const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_ptr, const otg_align_task* __restrict__ tasks,
+                               uint32_t* __restrict__ pos, uint32_t* __restrict__ out)
+{
+  const uint32_t n = *n_ptr;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t ti = list[i];
+    out[atomicAdd(&pos[sort_bucket(tasks[ti])], 1u)] = ti;
+  }
+}
+
 } // namespace
 
 // Enqueue the tier chain: wavefront tier 1 (LDS, score-capped) -> bit-parallel tiers 0..4 -> wavefront tier 2 -> global.  Requires: d_arena padded with >= 8 readable bytes after the last
@@ -393,7 +434,7 @@ int otg_launch_edit_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_t
 {
   if (n_tasks == 0) return OTG_OK;
   uint32_t* cnt = (uint32_t*)otg_slot(ctx, SLOT_COUNTERS, 64 * sizeof(uint32_t));
-  uint32_t* todo = (uint32_t*)otg_slot(ctx, SLOT_TODO, 8 * (size_t)n_tasks * sizeof(uint32_t));
+  uint32_t* todo = (uint32_t*)otg_slot(ctx, SLOT_TODO, 9 * (size_t)n_tasks * sizeof(uint32_t));
   if (!cnt || !todo) return OTG_ERR_HIP;
   HIP_TRY(ctx, hipMemsetAsync(cnt, 0, 8 * sizeof(uint32_t), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(cnt + 16, 0, 16 * sizeof(uint32_t), ctx->stream));
@@ -422,8 +463,22 @@ int otg_launch_edit_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_t
   }
   if (!no_myers) {
     uint32_t* const tick[6] = {cnt + 2, cnt + 4, cnt + 6, cnt + 20, cnt + 22, cnt + 24};
+    static const bool no_sort = getenv("OTG_NO_EDIT_SORT") != nullptr;
+    uint32_t* sorted = todo + 8 * (size_t)n_tasks;
+    uint32_t* hist = (uint32_t*)otg_slot(ctx, SLOT_ROWTAB, 6 * SORT_BUCKETS * sizeof(uint32_t));
+    if (!hist) return OTG_ERR_HIP;
+    if (!no_sort) HIP_TRY(ctx, hipMemsetAsync(hist, 0, 6 * SORT_BUCKETS * sizeof(uint32_t), ctx->stream));
     for (int tier = 0; tier < 6; ++tier) {
-      const int rc_ = otg_launch_myers(ctx, tier, d_arena, d_tasks, lists + (size_t)tier * n_tasks, rc + tier, n_tasks, d_scores, d_cells,
+      const uint32_t* in = lists + (size_t)tier * n_tasks;
+      if (!no_sort && tier < 4) {               // tiers that share a wave between pairs, and the whole-wave tier for its tail
+        uint32_t* h = hist + tier * SORT_BUCKETS;
+        const uint32_t sg = std::min<uint32_t>((n_tasks + 255) / 256, (uint32_t)ctx->n_cu * 8);
+        hipLaunchKernelGGL(K_sort_hist, dim3(sg), dim3(256), 0, ctx->stream, in, (const uint32_t*)(rc + tier), d_tasks, h);
+        hipLaunchKernelGGL(K_sort_scan, dim3(1), dim3(SORT_BUCKETS), 0, ctx->stream, h);
+        hipLaunchKernelGGL(K_sort_scatter, dim3(sg), dim3(256), 0, ctx->stream, in, (const uint32_t*)(rc + tier), d_tasks, h, sorted);
+        in = sorted;
+      }
+      const int rc_ = otg_launch_myers(ctx, tier, d_arena, d_tasks, in, rc + tier, n_tasks, d_scores, d_cells,
                                        tick[tier], rc + tier + 1, lists + (size_t)(tier + 1) * n_tasks);
       if (rc_) return rc_;
     }
