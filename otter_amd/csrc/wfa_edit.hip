@@ -385,11 +385,16 @@ __device__ __forceinline__ int sort_bucket(const otg_align_task& t)
   const int b = (int)(n >> 5);
   return SORT_BUCKETS - 1 - (b < SORT_BUCKETS ? b : SORT_BUCKETS - 1);          // descending length
 }
-__global__ void K_sort_hist(const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_ptr, const otg_align_task* __restrict__ tasks,
-                            uint32_t* __restrict__ hist)
+__global__ __launch_bounds__(256) void K_sort_hist(const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_ptr, const otg_align_task* __restrict__ tasks,
+                                                   uint32_t* __restrict__ hist)
 {
+  __shared__ uint32_t h[SORT_BUCKETS];
+  for (int b = (int)threadIdx.x; b < SORT_BUCKETS; b += 256) h[b] = 0;
+  __syncthreads();
   const uint32_t n = *n_ptr;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) atomicAdd(&hist[sort_bucket(tasks[list[i]])], 1u);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) atomicAdd(&h[sort_bucket(tasks[list[i]])], 1u);
+  __syncthreads();
+  for (int b = (int)threadIdx.x; b < SORT_BUCKETS; b += 256) if (h[b]) atomicAdd(&hist[b], h[b]);
 }
 __global__ __launch_bounds__(SORT_BUCKETS) void K_sort_scan(uint32_t* __restrict__ hist)
 {
@@ -405,13 +410,24 @@ __global__ __launch_bounds__(SORT_BUCKETS) void K_sort_scan(uint32_t* __restrict
   }
   hist[i] = s[i] - hist[i];                   // exclusive prefix = first output position of the bucket
 }
-__global__ void K_sort_scatter(const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_ptr, const otg_align_task* __restrict__ tasks,
-                               uint32_t* __restrict__ pos, uint32_t* __restrict__ out)
+// every block owns a contiguous slice: local histogram in LDS, one global reservation per non-empty bucket, local scatter
+__global__ __launch_bounds__(256) void K_sort_scatter(const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_ptr, const otg_align_task* __restrict__ tasks,
+                                                      uint32_t* __restrict__ pos, uint32_t* __restrict__ out)
 {
+  __shared__ uint32_t cnt[SORT_BUCKETS], basep[SORT_BUCKETS];
   const uint32_t n = *n_ptr;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+  const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
+  const uint32_t lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+  for (int b = (int)threadIdx.x; b < SORT_BUCKETS; b += 256) cnt[b] = 0;
+  __syncthreads();
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) atomicAdd(&cnt[sort_bucket(tasks[list[i]])], 1u);
+  __syncthreads();
+  for (int b = (int)threadIdx.x; b < SORT_BUCKETS; b += 256) { basep[b] = cnt[b] ? atomicAdd(&pos[b], cnt[b]) : 0u; cnt[b] = 0; }
+  __syncthreads();
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
     const uint32_t ti = list[i];
-    out[atomicAdd(&pos[sort_bucket(tasks[ti])], 1u)] = ti;
+    const int b = sort_bucket(tasks[ti]);
+    out[basep[b] + atomicAdd(&cnt[b], 1u)] = ti;
   }
 }
 
@@ -472,7 +488,7 @@ int otg_launch_edit_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_t
       const uint32_t* in = lists + (size_t)tier * n_tasks;
       if (!no_sort && tier < 4) {               // tiers that share a wave between pairs, and the whole-wave tier for its tail
         uint32_t* h = hist + tier * SORT_BUCKETS;
-        const uint32_t sg = std::min<uint32_t>((n_tasks + 255) / 256, (uint32_t)ctx->n_cu * 8);
+        const uint32_t sg = std::min<uint32_t>((n_tasks + 2047) / 2048, (uint32_t)ctx->n_cu * 2);
         hipLaunchKernelGGL(K_sort_hist, dim3(sg), dim3(256), 0, ctx->stream, in, (const uint32_t*)(rc + tier), d_tasks, h);
         hipLaunchKernelGGL(K_sort_scan, dim3(1), dim3(SORT_BUCKETS), 0, ctx->stream, h);
         hipLaunchKernelGGL(K_sort_scatter, dim3(sg), dim3(256), 0, ctx->stream, in, (const uint32_t*)(rc + tier), d_tasks, h, sorted);
