@@ -1296,7 +1296,7 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
   const int xs = x / g, oes = (o + e) / g, es = e / g;
   if (std::max(xs, oes) + 1 > 64 || es + 1 > 64) return otg_fail(ctx, OTG_ERR_ARG, "affine penalties too large after gcd reduction");
   uint32_t* cnt = (uint32_t*)otg_slot(ctx, SLOT_COUNTERS, 64 * sizeof(uint32_t));
-  uint32_t* todo = (uint32_t*)otg_slot(ctx, SLOT_TODO, 5 * (size_t)n_tasks * sizeof(uint32_t));
+  uint32_t* todo = (uint32_t*)otg_slot(ctx, SLOT_TODO, 6 * (size_t)n_tasks * sizeof(uint32_t));
   if (!cnt || !todo) return OTG_ERR_HIP;
   HIP_TRY(ctx, hipMemsetAsync(cnt + 8, 0, 8 * sizeof(uint32_t), ctx->stream));   // tickets / overflow counters of the tiers
   HIP_TRY(ctx, hipMemsetAsync(cnt + 24, 0, 8 * sizeof(uint32_t), ctx->stream));
@@ -1353,17 +1353,19 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
   };
   uint32_t blocksS = std::min<uint32_t>((uint32_t)ctx->n_cu * 10, n_tasks), blocksM = std::min<uint32_t>((uint32_t)ctx->n_cu * 5, n_tasks);   // resident blocks per CU (LDS / VGPR limits)
   uint32_t blocksX = std::min<uint32_t>((uint32_t)ctx->n_cu * 7, n_tasks);
-  AffWs wsS = lds_ws(1024, blocksS), wsM = lds_ws(2048, blocksM), wsX = lds_ws(1472, blocksX);
+  uint32_t blocksL = std::min<uint32_t>((uint32_t)ctx->n_cu * 2, n_tasks);
+  AffWs wsS = lds_ws(1024, blocksS), wsM = lds_ws(2048, blocksM), wsX = lds_ws(1472, blocksX), wsL = lds_ws(4096, blocksL);
   const size_t need = std::max(std::max(std::max(wsA.stride * wavesA, wsB.stride * wavesB), wsC.stride * (size_t)gridC * WPB),
-                               std::max(std::max(wsS.stride * blocksS, wsM.stride * blocksM), wsX.stride * blocksX));
+                               std::max(std::max(wsS.stride * blocksS, wsM.stride * blocksM), std::max(wsX.stride * blocksX, wsL.stride * blocksL)));
   uint8_t* wsp = (uint8_t*)otg_slot(ctx, SLOT_WF_WS, need);
   if (!wsp) return OTG_ERR_HIP;
-  wsA.base = wsB.base = wsC.base = wsS.base = wsM.base = wsX.base = wsp;
+  wsA.base = wsB.base = wsC.base = wsS.base = wsM.base = wsX.base = wsL.base = wsp;
   uint32_t* listA = todo;                  // overflow of tier A
   uint32_t* listB = todo + n_tasks;        // overflow of tier B
   uint32_t* listS = todo + 2 * (size_t)n_tasks;   // overflow of the LDS tier with 1024 diagonals
   uint32_t* listM = todo + 3 * (size_t)n_tasks;   // ... 2048 diagonals
-  uint32_t* listX = todo + 4 * (size_t)n_tasks;   // ... 1536 diagonals
+  uint32_t* listX = todo + 4 * (size_t)n_tasks;   // ... 1472 diagonals
+  uint32_t* listL = todo + 5 * (size_t)n_tasks;   // ... 4096 diagonals
   static const bool no_v3 = getenv("OTG_NO_AFFINE_V3") != nullptr;
   if (kernel_ms) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   const uint32_t* cur = d_todo; const uint32_t* cur_n = d_n_todo; uint32_t cur_imm = n_tasks;
@@ -1405,8 +1407,15 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
       }
       if (nwm == 4) OTG_V4_LAUNCH(2048, 4, 3072, 5, blocksM, inM, inM_n, 0u, cnt + 26, cnt + 27, listM, wsM);
       else OTG_V4_LAUNCH(2048, 2, 3072, 3, blocksM, inM, inM_n, 0u, cnt + 26, cnt + 27, listM, wsM);
+      // diamonds of up to 4096 diagonals (reads beyond ~6 kb at ONT divergence): eight waves per alignment, two alignments per CU
+      static const bool no_l = getenv("OTG_V4_NO_L") != nullptr;
+      const uint32_t* outM = listM; const uint32_t* outM_n = cnt + 27;
+      if (!no_l) {
+        OTG_V4_LAUNCH(4096, 8, 6144, 2, blocksL, (const uint32_t*)listM, (const uint32_t*)(cnt + 27), 0u, cnt + 30, cnt + 31, listL, wsL);
+        outM = listL; outM_n = cnt + 31;
+      }
 #undef OTG_V4_LAUNCH
-      inA = listM; inA_n = cnt + 27; inA_imm = 0;
+      inA = outM; inA_n = outM_n; inA_imm = 0;
     }
     hipLaunchKernelGGL((wfa_affine_kernel_v3<4096, 512, NWA>), dim3(wavesA), dim3(NWA * 64), 0, ctx->stream, d_arena, d_tasks,
                        inA, inA_n, inA_imm, xs, oes, es, g, d_scores, d_cig_off, d_cig_len,
