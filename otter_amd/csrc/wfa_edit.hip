@@ -466,16 +466,23 @@ int otg_launch_edit_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_t
   static const float route_margin = getenv("OTG_EDIT_ROUTE_MARGIN") ? (float)atoi(getenv("OTG_EDIT_ROUTE_MARGIN")) / 100.0f : 1.0f;
   if (kernel_ms) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   {
-    constexpr int CAP = 2048, WPB = 4;                         // 2 x 2048 x u16 = 8 KB per wave -> 20 waves / CU
-    const size_t lds = (size_t)CAP * 2 * WPB * sizeof(uint16_t);
+    // with the bit-parallel tiers behind it this pass only has to hold wavefronts of ~2 x cap diagonals: 1024 diagonals
+    // (4 KB per wave) leave room for 32 waves per CU, which is what hides the probe latency of this short pass
+    constexpr int WPB = 4;
     uint32_t want = (n_tasks + WPB - 1) / WPB;
-    uint32_t grid = (uint32_t)ctx->n_cu * 5;
-    if (grid > want) grid = want;
-    // without routing everything unfinished goes to lists[0] (or straight to the wide wavefront tier)
-    hipLaunchKernelGGL((wfa_edit_kernel_v2<CAP, WPB>), dim3(grid), dim3(WPB * 64), lds, ctx->stream, d_arena, d_tasks,
-                       d_todo, d_n_todo, n_tasks, d_scores, d_cells, cnt + 0, no_myers ? rc + 6 : rc + 0,
-                       no_myers ? lists + 6 * (size_t)n_tasks : lists, no_myers ? 0.0f : 1.0f,
-                       (no_myers || no_route) ? (uint32_t*)nullptr : rc, lists, n_tasks, route_margin);
+    if (no_myers) {
+      constexpr int CAP = 2048;                                // 2 x 2048 x u16 = 8 KB per wave -> 20 waves / CU
+      uint32_t grid = std::min<uint32_t>((uint32_t)ctx->n_cu * 5, want);
+      hipLaunchKernelGGL((wfa_edit_kernel_v2<CAP, WPB>), dim3(grid), dim3(WPB * 64), (size_t)CAP * 2 * WPB * sizeof(uint16_t), ctx->stream, d_arena, d_tasks,
+                         d_todo, d_n_todo, n_tasks, d_scores, d_cells, cnt + 0, rc + 6, lists + 6 * (size_t)n_tasks, 0.0f,
+                         (uint32_t*)nullptr, lists, n_tasks, route_margin);
+    } else {
+      constexpr int CAP = 1024;
+      uint32_t grid = std::min<uint32_t>((uint32_t)ctx->n_cu * 8, want);
+      hipLaunchKernelGGL((wfa_edit_kernel_v2<CAP, WPB>), dim3(grid), dim3(WPB * 64), (size_t)CAP * 2 * WPB * sizeof(uint16_t), ctx->stream, d_arena, d_tasks,
+                         d_todo, d_n_todo, n_tasks, d_scores, d_cells, cnt + 0, rc + 0, lists, 1.0f,
+                         no_route ? (uint32_t*)nullptr : rc, lists, n_tasks, route_margin);
+    }
   }
   if (!no_myers) {
     uint32_t* const tick[6] = {cnt + 2, cnt + 4, cnt + 6, cnt + 20, cnt + 22, cnt + 24};
