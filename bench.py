@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--reads", type=int, default=30)
     ap.add_argument("--err", default="ont")
     ap.add_argument("--realign", action="store_true", help="config 2: -r given, soft-clipped flanks")
-    ap.add_argument("--cpu-sample", type=int, default=64)
+    ap.add_argument("--cpu-sample", type=int, default=192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
