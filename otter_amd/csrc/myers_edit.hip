@@ -222,13 +222,15 @@ __global__ __launch_bounds__(WPB * 64) void myers_edit_kernel(
       // values of lane-1 (within the group) after its previous step
       const int up_score = group_ror1<GL>(score, lane);
       const int up_hout = group_ror1<GL>(hout, lane);
+      bool switched = false;
       if (t > t_stop) {                 // this superblock left the band: move to the next one owned by the lane
         B += GL; inited = false; setup();
         c8 = load_group(t - ph);
         if (ph >= 4) c8n = load_group(t - ph + 8);
+        switched = true;
       }
       if (ph == 4) c8n = load_group(t + 4);
-      else if (ph == 0 && t > 0) c8 = c8n;
+      else if (ph == 0 && t > 0 && !switched) c8 = c8n;     // (after a switch c8 is already this group's text; c8n still belongs to the old superblock)
       if (t >= t_start && t <= t_stop) {
         if (!inited) {
 #pragma unroll

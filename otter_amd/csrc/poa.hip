@@ -42,7 +42,6 @@ struct PoaDev {
   uint32_t* start_list;
   // outputs
   const uint64_t* out_off; uint32_t* out_len; uint8_t* out_arena; uint32_t* out_start; int32_t* status;
-  int dbg_skip;
   const uint32_t* order;      // graphs in decreasing order of work (longest first: shortest tail)
 };
 
@@ -362,7 +361,6 @@ __global__ __launch_bounds__(64, 8) void poa_graph_wave_kernel(PoaDev P)
     }
   }
   __threadfence();
-  if (P.dbg_skip) { P.out_len[g] = 0; P.out_start[g] = 0; P.status[g] = 0; return; }
 
   // ---- heaviest path: Kahn sweep pushing (weight, source) along out-edges (wave-uniform)
   const float c_ = G.c, t_ = G.t;
@@ -492,7 +490,6 @@ int otg_launch_poa(otg_ctx* ctx, const uint8_t* d_seq_arena, const uint8_t* d_ci
   P.node_off = d_node_off; P.edge_off = d_edge_off; P.start_off = d_start_off;
   P.out_off = d_node_off;     // consensus g is written into [node_off[g], node_off[g+1]) of out_arena
   P.out_len = d_out_len;
-  P.dbg_skip = getenv("OTG_POA_DBG_SKIP") ? 1 : 0;
   {
     // longest graphs first (work ~ op-string bytes = nodes + edges capacity computed above)
     std::vector<uint32_t> order(n_graphs);

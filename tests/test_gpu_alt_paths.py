@@ -1,0 +1,30 @@
+"""GPU parity of the alternative kernel paths.  The library picks its tier chains by itself; environment switches
+(read once per process) force the fallback chains — un-bounded affine pass, HBM-ring affine tiers, wavefront-only edit
+distance, un-routed / un-sorted bit-parallel tiers, thread-per-graph POA.  Every chain must be bit-exact, so the
+aligner / POA parity tests are re-run in a child process per switch."""
+import os
+import subprocess
+import sys
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CASES = [
+    ("OTG_NO_AFFINE_BOUND", ["tests/test_gpu_affine.py"]),
+    ("OTG_NO_AFFINE_V4", ["tests/test_gpu_affine.py"]),
+    ("OTG_AFFINE_BOUND_STATIC", ["tests/test_gpu_affine.py"]),
+    ("OTG_NO_MYERS", ["tests/test_gpu_edit.py::test_edit_small_mixed", "tests/test_gpu_edit.py::test_edit_long_ont"]),
+    ("OTG_NO_EDIT_ROUTE", ["tests/test_gpu_edit.py"]),
+    ("OTG_NO_EDIT_SORT", ["tests/test_gpu_edit.py"]),
+    ("OTG_POA_THREAD", ["tests/test_gpu_poa.py"]),
+]
+
+
+@pytest.mark.parametrize("switch,targets", CASES, ids=[c[0] for c in CASES])
+def test_alternative_path(gpu, switch, targets):
+    env = dict(os.environ)
+    env[switch] = "1"
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"] + targets,
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (switch, r.stdout[-2000:], r.stderr[-1000:])

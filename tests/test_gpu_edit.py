@@ -169,3 +169,29 @@ def test_edit_band_edges(gpu, oracle):
     exp = oracle.edit_distance_batch(arena, tasks)
     bad = [(i, int(got[i]), int(exp[i])) for i in range(len(pairs)) if got[i] != exp[i]]
     assert not bad, bad[:10]
+
+
+def test_edit_threshold_sweep(gpu, oracle):
+    """Systematic sweep across the certification thresholds: one block deletion of D bases early / late / split in two,
+    for every even D from 36 below to 12 above each threshold.  With the band at its full width a lane switches from
+    one superblock to its next without a spare step, which is where a stale text group once slipped in."""
+    rng = np.random.default_rng(18)
+    pairs, meta = [], []
+    for T, L in ((456, 1100), (976, 1500), (976, 2100), (2016, 2600)):
+        core = rand_seq(rng, L)
+        p_, q_ = 300, L - 300
+        for D in range(T - 36, T + 13, 2):
+            for split in (0.0, 0.3, 1.0):
+                d1 = int(D * split)
+                d2 = D - d1
+                pairs.append((core[:p_] + rand_seq(rng, d1) + core[p_:q_] + rand_seq(rng, d2) + core[q_:], core))
+                a2, b2 = core[:p_] + rand_seq(rng, d1) + core[p_:], core[:q_] + rand_seq(rng, d2) + core[q_:]
+                if len(b2) > len(a2):
+                    a2, b2 = b2, a2
+                pairs.append((a2, b2))
+                meta += [(T, L, D, split, "one"), (T, L, D, split, "two")]
+    arena, tasks = pair_tasks(pairs)
+    got = gpu.edit_distance_batch(arena, tasks)
+    exp = oracle.edit_distance_batch(arena, tasks)
+    bad = [(meta[i], int(got[i]), int(exp[i])) for i in range(len(pairs)) if got[i] != exp[i]]
+    assert not bad, bad[:10]
