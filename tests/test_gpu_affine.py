@@ -132,3 +132,29 @@ def test_affine_non_acgt_bytes(gpu, oracle):
     assert np.array_equal(gs, es)
     assert gc == ec
     assert np.array_equal(gcells, ecells)
+
+
+def test_affine_lds_tier_admission_sweep(gpu, oracle):
+    """Alignments whose score bound sits right at the admission limit of each LDS tier (windows of 1024 / 1472 / 2048 /
+    4096 diagonals): one long gap (reduced score = gap length + 3) or two gaps in opposite directions, early and late
+    in the sequence.  Whether such an alignment is admitted to a tier or passed on, op string and score must match."""
+    rng = np.random.default_rng(27)
+    pairs = []
+    L = 900
+    core = rand_seq(rng, L)
+    for cap in (1024, 1472, 2048, 4096):
+        for G in list(range(cap - 26, cap + 5, 3)):
+            for pos in (120, L - 120):
+                a = core[:pos] + rand_seq(rng, G) + core[pos:]
+                pairs.append((a, core) if (G // 3) % 2 else (core, a))
+        # out and back: an insertion of g1 and, far away, a deletion of g2 (the path visits diagonal +g1, ends on g1 - g2)
+        for g1, g2 in ((cap // 2 - 8, cap // 2 - 9), (cap // 2 + 2, cap // 2 - 20)):
+            a = core[:200] + rand_seq(rng, g1) + core[200:]
+            b = core[:700] + rand_seq(rng, g2) + core[700:]
+            pairs.append((a, b))
+    arena, tasks = pair_tasks(pairs)
+    gs, gc = gpu.affine_align_batch(arena, tasks)
+    es, ec = oracle.affine_align_batch(arena, tasks)
+    assert np.array_equal(gs, es)
+    bad = [i for i in range(len(pairs)) if gc[i] != ec[i]]
+    assert not bad, bad[:10]
