@@ -45,3 +45,35 @@ def test_poa_random_ont_kb(gpu, oracle):
 def test_poa_hifi(gpu, oracle):
     rng = np.random.default_rng(43)
     _check(gpu, oracle, random_poa_specs(rng, oracle, 60, 300, 700, err=0.002))
+
+
+def test_poa_op_string_fuzz(gpu, oracle):
+    """Op strings that are NOT alignment output: random valid op sequences (M/X/D count = backbone length, M/X/I count =
+    read length) built from runs whose lengths straddle the 64-op chunks the wave kernel reads, starting with any op,
+    with long gap runs, consecutive insertions and deletions, for spanning and non-spanning members."""
+    from helpers import rand_seq
+    rng = np.random.default_rng(44)
+    specs = []
+    for g in range(120):
+        B = int(rng.integers(2, 400)) if g % 4 else int(rng.choice([2, 3, 11, 63, 64, 65, 127, 128, 129, 192]))
+        bb = rand_seq(rng, B)
+        mem = []
+        for _ in range(int(rng.integers(1, 12))):
+            ops = []
+            ref = 0
+            while ref < B:
+                kind = rng.choice(["M", "M", "M", "X", "D", "I"], p=[0.3, 0.3, 0.15, 0.1, 0.08, 0.07])
+                run = int(rng.choice([1, 1, 2, 3, 7, 31, 32, 33, 63, 64, 65, 100]))
+                if kind in "MXD":
+                    run = min(run, B - ref)
+                    ref += run
+                ops.append(kind * run)
+            if rng.random() < 0.3:
+                ops.append("I" * int(rng.integers(1, 70)))
+            cig = "".join(ops).encode()
+            tlen = cig.count(b"M") + cig.count(b"X") + cig.count(b"I")
+            mem.append((rand_seq(rng, max(tlen, 1))[:tlen] if tlen else b"", cig, bool(rng.random() < 0.8), bool(rng.random() < 0.8)))
+        n = len(mem)
+        c = np.float32(n * 0.4) if n >= 4 else np.float32(1.0)
+        specs.append((bb, mem, c, np.float32(0.3)))
+    _check(gpu, oracle, specs)
