@@ -158,3 +158,25 @@ def test_affine_lds_tier_admission_sweep(gpu, oracle):
     assert np.array_equal(gs, es)
     bad = [i for i in range(len(pairs)) if gc[i] != ec[i]]
     assert not bad, bad[:10]
+
+
+def test_affine_packed_sequence_capacity_sweep(gpu, oracle):
+    """The LDS tiers hold both sequences packed to 2 bits per base in a fixed slice (2304 / 2688 / 3072 bytes): near-identical
+    pairs whose combined length crosses each capacity (about 9.1, 10.6 and 12.1 kb) must be admitted or passed on cleanly."""
+    rng = np.random.default_rng(28)
+    base = rand_seq(rng, 6400)
+    pairs = []
+    for tot in list(range(9000, 9260, 20)) + list(range(10520, 10780, 20)) + list(range(12060, 12330, 20)):
+        la = tot // 2 + int(rng.integers(-40, 41))
+        lb = tot - la
+        a = bytearray(base[:la]); b = bytearray(base[:lb])
+        for s_ in (a, b):
+            for _ in range(3):
+                i = int(rng.integers(0, len(s_)))
+                s_[i] = b"ACGT"[(b"ACGT".index(s_[i]) + 1) % 4]
+        pairs.append((bytes(a), bytes(b)))
+    arena, tasks = pair_tasks(pairs)
+    gs, gc = gpu.affine_align_batch(arena, tasks)
+    es, ec = oracle.affine_align_batch(arena, tasks)
+    assert np.array_equal(gs, es)
+    assert gc == ec
