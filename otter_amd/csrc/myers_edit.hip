@@ -338,8 +338,9 @@ int launch_one(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_task* d_tas
 
 // One tier of the bit-parallel engine: tasks from (d_todo, d_n_todo) (or all n_tasks when d_todo is null);
 // tasks it cannot finish exactly are appended to overflow_list / n_overflow.
-// tier: 0 = 8-lane groups (8 pairs / wave), 1 = 16-lane groups, 2 = 32-lane groups, 3 = whole wave,
-//       4 = whole wave x 2 blocks per lane, 5 = whole wave x 4 blocks per lane.
+// tier: 0 = 8-lane groups x 1 block per lane (8 pairs / wave); 1..4 = 8 / 16 / 32 / 64-lane groups x 2 blocks per lane
+//       (two blocks share the per-column overhead of a lane: ~19 % fewer instructions per row than one block per lane);
+//       5 = whole wave x 4 blocks per lane.
 int otg_launch_myers(otg_ctx* ctx, int tier, const uint8_t* d_arena, const otg_align_task* d_tasks, const uint32_t* d_todo,
                      const uint32_t* d_n_todo, uint32_t n_tasks, int32_t* d_scores, uint64_t* d_cells,
                      uint32_t* ticket, uint32_t* n_overflow, uint32_t* overflow_list)
@@ -347,9 +348,9 @@ int otg_launch_myers(otg_ctx* ctx, int tier, const uint8_t* d_arena, const otg_a
   int rc;
   switch (tier) {
     case 0: rc = launch_one<1, 8>(ctx, d_arena, d_tasks, d_todo, d_n_todo, n_tasks, d_scores, d_cells, ticket, n_overflow, overflow_list); break;
-    case 1: rc = launch_one<1, 16>(ctx, d_arena, d_tasks, d_todo, d_n_todo, n_tasks, d_scores, d_cells, ticket, n_overflow, overflow_list); break;
-    case 2: rc = launch_one<1, 32>(ctx, d_arena, d_tasks, d_todo, d_n_todo, n_tasks, d_scores, d_cells, ticket, n_overflow, overflow_list); break;
-    case 3: rc = launch_one<1, 64>(ctx, d_arena, d_tasks, d_todo, d_n_todo, n_tasks, d_scores, d_cells, ticket, n_overflow, overflow_list); break;
+    case 1: rc = launch_one<2, 8>(ctx, d_arena, d_tasks, d_todo, d_n_todo, n_tasks, d_scores, d_cells, ticket, n_overflow, overflow_list); break;
+    case 2: rc = launch_one<2, 16>(ctx, d_arena, d_tasks, d_todo, d_n_todo, n_tasks, d_scores, d_cells, ticket, n_overflow, overflow_list); break;
+    case 3: rc = launch_one<2, 32>(ctx, d_arena, d_tasks, d_todo, d_n_todo, n_tasks, d_scores, d_cells, ticket, n_overflow, overflow_list); break;
     case 4: rc = launch_one<2, 64>(ctx, d_arena, d_tasks, d_todo, d_n_todo, n_tasks, d_scores, d_cells, ticket, n_overflow, overflow_list); break;
     default: rc = launch_one<4, 64>(ctx, d_arena, d_tasks, d_todo, d_n_todo, n_tasks, d_scores, d_cells, ticket, n_overflow, overflow_list); break;
   }

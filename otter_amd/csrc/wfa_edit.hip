@@ -359,7 +359,7 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_kernel_v2(
         const int dd = swap ? tl - pl : pl - tl;
         const int fb = ef ? (int)t.pattern_begin_free : 0, fe2 = ef ? (int)t.pattern_end_free : 0;
         if (dd >= 0) {
-          const int rows[6] = {456, 976, 2016, 4096, 8128, 16192};    // (GL-1)*64*BPL + GL of the six tiers
+          const int rows[6] = {456, 904, 1936, 4000, 8128, 16192};    // (GL-1)*64*BPL + GL of the six tiers (myers_edit.hip)
 #pragma unroll
           for (int q = 5; q >= 0; --q) if (need <= otg_myers_threshold(rows[q], dd, fb < dd ? fb : dd, fe2 < dd ? fe2 : dd)) tier = q;
         }

@@ -142,8 +142,8 @@ def test_edit_band_edges(gpu, oracle):
     pairs just over it must move up a tier — either way the score equals the oracle's."""
     rng = np.random.default_rng(17)
     pairs, forms = [], []
-    for T in (456, 976, 2016):
-        for trial in range(14):
+    for T in (456, 904, 976, 1936, 2016):
+        for trial in range(14 if T < 1000 else 8):
             L = int(rng.integers(1400, 2600))
             core = rand_seq(rng, L)
             tot = T + int(rng.integers(-8, 9))
@@ -177,7 +177,7 @@ def test_edit_threshold_sweep(gpu, oracle):
     one superblock to its next without a spare step, which is where a stale text group once slipped in."""
     rng = np.random.default_rng(18)
     pairs, meta = [], []
-    for T, L in ((456, 1100), (976, 1500), (976, 2100), (2016, 2600)):
+    for T, L in ((456, 1100), (904, 1400), (904, 2100), (976, 1500), (1936, 2500), (2016, 2600)):
         core = rand_seq(rng, L)
         p_, q_ = 300, L - 300
         for D in range(T - 36, T + 13, 2):
