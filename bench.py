@@ -101,7 +101,10 @@ def main():
         if dist is not None:
             # end-of-run gather of the per-region allele records to rank 0 (RCCL over xGMI), straight from the
             # library's device-resident result buffers: GPU -> GPU, one device-to-host copy on rank 0
-            res = ctx.assemble_device_results()
+            try:
+                res = ctx.assemble_device_results()
+            except Exception:                      # same records through the host (otg_assemble_collect) if wrapping fails
+                res = ctx.assemble_collect()
             g = parallel.gather_records(res, dist, rank, world, torch.device("cuda", local_rank))
             if rank == 0:
                 gathered["records"] = len(g["alleles"])
