@@ -8,6 +8,19 @@ from . import abi
 from .synth import shard_bounds  # noqa: F401  (re-exported)
 
 
+_PINNED = {}
+
+
+def _pinned(slot, nbytes, torch):
+    """Grow-only page-locked staging buffers of rank 0 (allocating hundreds of MB of pinned memory per step would cost
+    more than the copy)."""
+    buf = _PINNED.get(slot)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes + nbytes // 8, 1 << 20), dtype=torch.uint8, pin_memory=True)
+        _PINNED[slot] = buf
+    return buf[:nbytes]
+
+
 def gather_records(res, dist, rank, world, device):
     """All ranks call this with their own `res`: either the dict of Context.assemble_collect (host numpy arrays) or
     the dict of Context.assemble_device_results (uint8 tensors already on `device`; the records then travel
@@ -43,12 +56,12 @@ def gather_records(res, dist, rank, world, device):
     for j in range(3):
         cat = torch.cat([out[j][r][:int(all_sizes[r][j])] for r in range(world)])
         if cat.is_cuda:
-            host = torch.empty(cat.numel(), dtype=torch.uint8, pin_memory=True)
+            host = _pinned(j, cat.numel(), torch)
             host.copy_(cat, non_blocking=False)
             cat = host
         parts.append(cat.numpy())
     alleles = parts[0].view(abi.allele_dt).copy()
-    seqs = parts[1]
+    seqs = parts[1].copy()
     regions = parts[2].view(abi.region_result_dt).copy()
     seq_base = allele_base = region_base = 0
     ai = gi = 0
