@@ -214,6 +214,32 @@ typedef struct otg_region_result {
   int32_t  n_valid;
 } otg_region_result;
 
+/* ---------------------------------------------------------------------------------------------
+ * Record emit (the first "next" row after the hot path): the text `otter assemble`
+ * prints for the allele records of a batch — reference: the emit loop src/assemble.cpp:143-149 ->
+ * ANALLELE::stdout_sam / stdout_fa (src/anseqs.cpp:42-63), BED::toScString (src/anbed.cpp:17-20),
+ * header lines src/assemble.cpp:167-177.  Host-side formatting (no device work), byte-identical to the
+ * reference: regions in batch order (= BED order; the reference's own order with -t 1), alleles in label
+ * order; `se` printed the way `std::cout << float` prints it.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct otg_bed {
+  uint64_t chr_off;          /* chromosome name: chr_arena + chr_off, chr_len bytes (no terminator needed) */
+  uint32_t chr_len;
+  int32_t  start, end;       /* the UN-modified BED coordinates (local_bed, src/assemble.cpp:53)           */
+  uint32_t reserved;
+} otg_bed;
+
+/* Writes the record lines into `out` (capacity out_capacity) and their total length into *out_len; returns
+ * OTG_ERR_CAPACITY (with *out_len = bytes needed) when the buffer is too small.  is_fasta: 0 = SAM lines
+ * (name `chr:start-end_l`, read group tag when read_group is non-empty), 1 = FASTA (`>rg#chr:start-end#l#...`). */
+int otg_emit_alleles(const otg_bed* beds, const char* chr_arena, uint32_t n_regions,
+                     const otg_region_result* regions, const otg_allele* alleles, const uint8_t* seqs,
+                     const char* read_group, int is_fasta, char* out, uint64_t out_capacity, uint64_t* out_len);
+/* The three kinds of SAM header lines of src/assemble.cpp:167-177: @SQ per target, @RG, @PG with the offsets. */
+int otg_emit_sam_header(const char* name_arena, const uint64_t* name_off, const uint32_t* name_len,
+                        const uint64_t* target_len, uint32_t n_targets, const char* read_group,
+                        int32_t offset_l, int32_t offset_r, char* out, uint64_t out_capacity, uint64_t* out_len);
+
 /* Workload statistics of the last otg_assemble_run (for the roofline figure). */
 typedef struct otg_run_stats {
   uint64_t n_regions, n_regions_ok;

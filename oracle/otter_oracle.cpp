@@ -35,6 +35,7 @@
 #include <string>
 #include <utility>
 #include <vector>
+#include <sstream>
 
 namespace oto {
 
@@ -1445,6 +1446,56 @@ void oto_params_default(otg_params* p)
   p->min_cov_fraction2_l = 500; p->mismatch = 4; p->gap_open = 6; p->gap_ext = 2; p->realign = 0;
   p->bandwidth_short = 0.01; p->bandwidth_long = 0.015; p->max_error = 0.01; p->min_cov_fraction = 0.2;
   p->min_cov_fraction2_f = 0.1; p->min_sim = 0.9; p->gt_max_error = 0.025; p->gt_max_cosdis = 0.025;
+}
+
+
+/* ---- record emit, restated from ANALLELE::stdout_sam / stdout_fa (src/anseqs.cpp:42-63) as driven by
+ *      the emit loop src/assemble.cpp:143-149, BED::toScString (src/anbed.cpp:17-20) and the header lines
+ *      src/assemble.cpp:167-177.  Returns the number of bytes; copies at most cap bytes into out. ---- */
+uint64_t oto_emit_alleles(const otg_bed* beds, const char* chr_arena, uint32_t n_regions, const otg_region_result* regions,
+                          const otg_allele* alleles, const uint8_t* seqs, const char* read_group, int is_fasta, char* out, uint64_t cap)
+{
+  std::ostringstream os;
+  const std::string rg = read_group ? read_group : "";
+  for (uint32_t r = 0; r < n_regions; ++r) {
+    const std::string chr(chr_arena + beds[r].chr_off, beds[r].chr_len);
+    const std::string sc = chr + ":" + std::to_string(beds[r].start) + "-" + std::to_string(beds[r].end);      /* toScString */
+    for (uint32_t l = 0; l < regions[r].n_alleles; ++l) {
+      const otg_allele& A = alleles[regions[r].first_allele + l];
+      const std::string seq((const char*)seqs + A.seq_off, A.seq_len);
+      if (is_fasta) {   /* stdout_fa(name = read_group, region = sc + '#' + l), is_read = false (:56-63) */
+        os << '>' << rg << '#' << (sc + '#' + std::to_string(l)) << '#' << "tc" << ":i:" << A.tcov << '#' << "ac" << ":i:" << A.acov << '#' << "sc" << ":i:" << A.scov;
+        if (A.ps >= 0) os << '#' << "PS" << ":i:" << A.ps;
+        if (A.hp >= 0) os << '#' << "HP" << ":i:" << A.hp;
+        os << '\n' << seq << '\n';
+      } else {          /* stdout_sam(name = sc + "_" + l, chr, start, end, rg), is_read = false (:42-54) */
+        const std::string pseudo_qual(seq.size(), '!');
+        os << (sc + "_" + std::to_string(l)) << "\t0\t" << chr << '\t' << beds[r].start << "\t0\t" << seq.size() << "M\t*\t0\t0\t" << seq << '\t' << pseudo_qual;
+        if (!rg.empty()) os << '\t' << "RG" << ":Z:" << rg;
+        os << '\t' << "ta" << ":Z:" << chr << ':' << beds[r].start << '-' << beds[r].end << '\t' << "tc" << ":i:" << A.tcov << '\t' << "ac" << ":i:" << A.acov << '\t' << "sc" << ":i:" << A.scov;
+        os << '\t' << "ic" << ":i:" << A.ic;
+        os << '\t' << "se" << ":f:" << A.se;
+        if (A.ps >= 0) os << '\t' << "PS" << ":i:" << A.ps;
+        if (A.hp >= 0) os << '\t' << "HP" << ":i:" << A.hp;
+        os << '\n';
+      }
+    }
+  }
+  const std::string t = os.str();
+  if (out && cap) memcpy(out, t.data(), std::min<uint64_t>(cap, t.size()));
+  return t.size();
+}
+
+uint64_t oto_emit_sam_header(const char* name_arena, const uint64_t* name_off, const uint32_t* name_len, const uint64_t* target_len,
+                             uint32_t n_targets, const char* read_group, int32_t offset_l, int32_t offset_r, char* out, uint64_t cap)
+{
+  std::ostringstream os;
+  for (uint32_t i = 0; i < n_targets; ++i) os << "@SQ\tSN:" << std::string(name_arena + name_off[i], name_len[i]) << "\tLN:" << target_len[i] << '\n';
+  os << "@RG\tID:" << (read_group ? read_group : "") << '\n';
+  os << "@PG\tID:otter\tOF:" << offset_l << ',' << offset_r << '\n';
+  const std::string t = os.str();
+  if (out && cap) memcpy(out, t.data(), std::min<uint64_t>(cap, t.size()));
+  return t.size();
 }
 
 } /* extern "C" */

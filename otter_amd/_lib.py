@@ -14,6 +14,7 @@ EXPORTS = [
     "otg_edit_distance_batch", "otg_affine_align_batch", "otg_cluster_batch", "otg_poa_consensus_batch",
     "otg_genotype_cluster_batch", "otg_assemble_submit", "otg_assemble_run", "otg_assemble_result_sizes",
     "otg_assemble_collect", "otg_assemble_device_results", "otg_assemble_stats",
+    "otg_emit_alleles", "otg_emit_sam_header",
 ]
 
 _lib = None
@@ -218,3 +219,36 @@ class Context:
 
 def device_count():
     return load().otg_device_count()
+
+
+def emit_alleles(beds, chr_arena, res, read_group="", fasta=False):
+    """Text of the allele records of a collected batch exactly as `otter assemble` prints them (otg_emit_alleles;
+    src/assemble.cpp:143-149).  res: dict with "regions", "alleles", "seqs" (Context.assemble_collect)."""
+    L = load()
+    n = C.c_uint64(0)
+    args = [abi.ptr(beds), abi.ptr(chr_arena, C.c_char_p), C.c_uint32(len(beds)), abi.ptr(res["regions"]), abi.ptr(res["alleles"]),
+            abi.ptr(res["seqs"]), C.c_char_p(read_group.encode()), C.c_int(1 if fasta else 0)]
+    rc = L.otg_emit_alleles(*args, None, C.c_uint64(0), C.byref(n))
+    if rc not in (0, abi.OTG_ERR_CAPACITY):
+        raise OtterGpuError("otg_emit_alleles failed (%d): %s" % (rc, (L.otg_last_error(None) or b"").decode()))
+    out = np.zeros(max(1, n.value), dtype=np.uint8)
+    rc = L.otg_emit_alleles(*args, abi.ptr(out, C.c_char_p), C.c_uint64(out.size), C.byref(n))
+    if rc != 0:
+        raise OtterGpuError("otg_emit_alleles failed (%d)" % rc)
+    return out[:n.value].tobytes()
+
+
+def emit_sam_header(targets, read_group="", offset_l=0, offset_r=0):
+    """targets: list of (name, length) -> the @SQ/@RG/@PG header lines of src/assemble.cpp:167-177."""
+    L = load()
+    names = b"".join(t[0].encode() for t in targets) + b"\0"
+    off = np.cumsum([0] + [len(t[0].encode()) for t in targets[:-1]]).astype(np.uint64) if targets else np.zeros(0, np.uint64)
+    ln = np.array([len(t[0].encode()) for t in targets], dtype=np.uint32)
+    tl = np.array([t[1] for t in targets], dtype=np.uint64)
+    out = np.zeros(64 + sum(40 + len(t[0]) for t in targets) + len(read_group), dtype=np.uint8)
+    n = C.c_uint64(0)
+    rc = L.otg_emit_sam_header(C.c_char_p(names), abi.ptr(off), abi.ptr(ln), abi.ptr(tl), C.c_uint32(len(targets)), C.c_char_p(read_group.encode()),
+                               C.c_int32(offset_l), C.c_int32(offset_r), abi.ptr(out, C.c_char_p), C.c_uint64(out.size), C.byref(n))
+    if rc != 0:
+        raise OtterGpuError("otg_emit_sam_header failed (%d)" % rc)
+    return out[:n.value].tobytes()

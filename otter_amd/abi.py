@@ -83,6 +83,20 @@ assert align_task_dt.itemsize == 48
 assert read_dt.itemsize == 32
 assert region_dt.itemsize == 32
 assert allele_dt.itemsize == 48
+
+bed_dt = np.dtype([("chr_off", "<u8"), ("chr_len", "<u4"), ("start", "<i4"), ("end", "<i4"), ("reserved", "<u4")], align=True)
+assert bed_dt.itemsize == 24
+
+
+def make_beds(regions):
+    """regions: list of (chr_str, start, end) -> (otg_bed array, chr byte arena)."""
+    beds = np.zeros(len(regions), dtype=bed_dt)
+    arena = bytearray()
+    for i, (c, st, en) in enumerate(regions):
+        cb = c.encode() if isinstance(c, str) else bytes(c)
+        beds[i]["chr_off"] = len(arena); beds[i]["chr_len"] = len(cb); beds[i]["start"] = st; beds[i]["end"] = en
+        arena += cb
+    return beds, np.frombuffer(bytes(arena) + b"\0", dtype=np.uint8).copy()
 assert region_result_dt.itemsize == 24
 assert poa_member_dt.itemsize == 32
 assert poa_graph_dt.itemsize == 32

@@ -1,0 +1,80 @@
+// emit.hip — record emit of `otter assemble`: SAM / FASTA lines of the allele records and the SAM
+// header, byte-identical to the reference (src/assemble.cpp:143-149,167-177; ANALLELE::stdout_sam / stdout_fa
+// src/anseqs.cpp:42-63; BED::toScString src/anbed.cpp:17-20).  Host-side formatting only; lives in the library so
+// that a caller of the C-ABI gets the wire format the parity diff is taken on without re-implementing it.
+#include "otg_common.hpp"
+#include <cstdio>
+
+namespace {
+
+struct Sink {
+  char* out; uint64_t cap; uint64_t len;
+  void put(const char* p, size_t n) { if (len + n <= cap && out) memcpy(out + len, p, n); len += n; }
+  void put(const char* z) { put(z, strlen(z)); }
+  void ch(char c) { put(&c, 1); }
+  void i64(long long v) { char b[32]; const int n = snprintf(b, sizeof b, "%lld", v); put(b, (size_t)n); }
+  void u64(unsigned long long v) { char b[32]; const int n = snprintf(b, sizeof b, "%llu", v); put(b, (size_t)n); }
+  // `std::cout << float`: default float field, precision 6 == printf %g of the value widened to double
+  void flt(float v) { char b[48]; const int n = snprintf(b, sizeof b, "%g", (double)v); put(b, (size_t)n); }
+  void fill(char c, size_t n) { if (len + n <= cap && out) memset(out + len, c, n); len += n; }
+};
+
+} // namespace
+
+extern "C" {
+
+int otg_emit_alleles(const otg_bed* beds, const char* chr_arena, uint32_t n_regions, const otg_region_result* regions,
+                     const otg_allele* alleles, const uint8_t* seqs, const char* read_group, int is_fasta,
+                     char* out, uint64_t out_capacity, uint64_t* out_len)
+{
+  if ((n_regions && (!beds || !regions)) || !out_len) return otg_fail(nullptr, OTG_ERR_ARG, "otg_emit_alleles: null argument");
+  const char* rg = read_group ? read_group : "";
+  Sink s{out, out_capacity, 0};
+  for (uint32_t r = 0; r < n_regions; ++r) {
+    const otg_bed& b = beds[r];
+    const char* chr = chr_arena + b.chr_off;
+    for (uint32_t a = 0; a < regions[r].n_alleles; ++a) {
+      const otg_allele& A = alleles[regions[r].first_allele + a];
+      const char* seq = (const char*)seqs + A.seq_off;
+      if (is_fasta) {
+        // stdout_fa(name = read group, region = toScString() + '#' + l)  (src/assemble.cpp:146, src/anseqs.cpp:56-63)
+        s.ch('>'); s.put(rg); s.ch('#'); s.put(chr, b.chr_len); s.ch(':'); s.i64(b.start); s.ch('-'); s.i64(b.end); s.ch('#'); s.i64(a);
+        s.put("#tc:i:"); s.i64(A.tcov); s.put("#ac:i:"); s.i64(A.acov); s.put("#sc:i:"); s.i64(A.scov);
+        if (A.ps >= 0) { s.put("#PS:i:"); s.i64(A.ps); }
+        if (A.hp >= 0) { s.put("#HP:i:"); s.i64(A.hp); }
+        s.ch('\n'); s.put(seq, A.seq_len); s.ch('\n');
+      } else {
+        // stdout_sam(name = toScString() + "_" + l, chr, start, end, rg)  (src/assemble.cpp:147, src/anseqs.cpp:42-54)
+        s.put(chr, b.chr_len); s.ch(':'); s.i64(b.start); s.ch('-'); s.i64(b.end); s.ch('_'); s.i64(a);
+        s.put("\t0\t"); s.put(chr, b.chr_len); s.ch('\t'); s.i64(b.start); s.put("\t0\t"); s.u64(A.seq_len); s.put("M\t*\t0\t0\t");
+        s.put(seq, A.seq_len); s.ch('\t'); s.fill('!', A.seq_len);
+        if (rg[0]) { s.put("\tRG:Z:"); s.put(rg); }
+        s.put("\tta:Z:"); s.put(chr, b.chr_len); s.ch(':'); s.i64(b.start); s.ch('-'); s.i64(b.end);
+        s.put("\ttc:i:"); s.i64(A.tcov); s.put("\tac:i:"); s.i64(A.acov); s.put("\tsc:i:"); s.i64(A.scov);
+        s.put("\tic:i:"); s.i64(A.ic); s.put("\tse:f:"); s.flt(A.se);
+        if (A.ps >= 0) { s.put("\tPS:i:"); s.i64(A.ps); }
+        if (A.hp >= 0) { s.put("\tHP:i:"); s.i64(A.hp); }
+        s.ch('\n');
+      }
+    }
+  }
+  *out_len = s.len;
+  if (s.len > out_capacity || (!out && s.len)) return OTG_ERR_CAPACITY;
+  return OTG_OK;
+}
+
+int otg_emit_sam_header(const char* name_arena, const uint64_t* name_off, const uint32_t* name_len, const uint64_t* target_len,
+                        uint32_t n_targets, const char* read_group, int32_t offset_l, int32_t offset_r,
+                        char* out, uint64_t out_capacity, uint64_t* out_len)
+{
+  if ((n_targets && (!name_arena || !name_off || !name_len || !target_len)) || !out_len) return otg_fail(nullptr, OTG_ERR_ARG, "otg_emit_sam_header: null argument");
+  Sink s{out, out_capacity, 0};
+  for (uint32_t i = 0; i < n_targets; ++i) { s.put("@SQ\tSN:"); s.put(name_arena + name_off[i], name_len[i]); s.put("\tLN:"); s.u64(target_len[i]); s.ch('\n'); }
+  s.put("@RG\tID:"); s.put(read_group ? read_group : ""); s.ch('\n');
+  s.put("@PG\tID:otter\tOF:"); s.i64(offset_l); s.ch(','); s.i64(offset_r); s.ch('\n');
+  *out_len = s.len;
+  if (s.len > out_capacity || (!out && s.len)) return OTG_ERR_CAPACITY;
+  return OTG_OK;
+}
+
+} // extern "C"

@@ -62,3 +62,16 @@ cons = O.poa_consensus_batch(sarena, carena, members, graphs, which="ref")
 np.savez_compressed(os.path.join(out, "poa_ref.npz"), sarena=sarena, carena=carena, members=members, graphs=graphs,
                     cons=np.frombuffer(b"\n".join(cons), dtype=np.uint8))
 print("golden fixtures written to", out)
+
+
+# G5: record emit — the reference's own ANALLELE::stdout_sam / stdout_fa (oracle/_ref/libotter_ref_io.so) on synthetic records;
+# the header lines are three literal stream inserts (src/assemble.cpp:171-174), written here from the oracle's restatement
+import json  # noqa: E402
+from test_emit import synthetic_records, TARGETS  # noqa: E402
+assert O.ref_io() is not None, "oracle/_ref/libotter_ref_io.so not built"
+beds, carena, res = synthetic_records()
+gold = {k: O.emit_alleles(beds, carena, res, rg, fa, which="ref").decode() for k, rg, fa in
+        (("sam", "", False), ("sam_rg", "sampleA", False), ("fa", "", True), ("fa_rg", "sampleA", True))}
+gold["header"] = O.emit_sam_header(TARGETS, "sampleA", 30, 31).decode()
+json.dump(gold, open(os.path.join(out, "emit_ref.json"), "w"))
+print("emit_ref.json", {k: len(v) for k, v in gold.items()})

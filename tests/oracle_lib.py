@@ -9,6 +9,7 @@ from otter_amd import abi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_SO = os.path.join(ROOT, "oracle", "libotter_oracle.so")
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libotter_ref.so")
+REF_IO_SO = os.path.join(ROOT, "oracle", "_ref", "libotter_ref_io.so")
 
 u8p, i32p, u32p, u64p, f64p = (C.POINTER(t) for t in (C.c_uint8, C.c_int32, C.c_uint32, C.c_uint64, C.c_double))
 
@@ -223,3 +224,43 @@ def assemble_batch(params, batch, region_range=None):
 def allele_seq(res, i):
     a = res["alleles"][i]
     return res["seqs"][int(a["seq_off"]):int(a["seq_off"]) + int(a["seq_len"])].tobytes()
+
+
+_ref_io = None
+
+
+def ref_io():
+    """The reference's own record types + emit code (oracle/_ref/libotter_ref_io.so); None when not built."""
+    global _ref_io
+    if _ref_io is None and os.path.exists(REF_IO_SO):
+        _ref_io = C.CDLL(REF_IO_SO)
+        _ref_io.ref_emit_alleles.restype = C.c_uint64
+    return _ref_io
+
+
+def emit_alleles(beds, chr_arena, res, read_group="", fasta=False, which="oracle"):
+    """Record text of a collected batch: the oracle's restatement, or the reference's own stdout_sam / stdout_fa."""
+    if which == "ref":
+        f = ref_io().ref_emit_alleles
+    else:
+        f = lib().oto_emit_alleles
+        f.restype = C.c_uint64
+    args = [abi.ptr(beds), abi.ptr(chr_arena, C.c_char_p), C.c_uint32(len(beds)), abi.ptr(res["regions"]), abi.ptr(res["alleles"]),
+            abi.ptr(res["seqs"]), C.c_char_p(read_group.encode()), C.c_int(1 if fasta else 0)]
+    n = f(*args, None, C.c_uint64(0))
+    out = np.zeros(max(1, n), dtype=np.uint8)
+    f(*args, abi.ptr(out, C.c_char_p), C.c_uint64(out.size))
+    return out[:n].tobytes()
+
+
+def emit_sam_header(targets, read_group="", offset_l=0, offset_r=0):
+    f = lib().oto_emit_sam_header
+    f.restype = C.c_uint64
+    names = b"".join(t[0].encode() for t in targets) + b"\0"
+    off = np.cumsum([0] + [len(t[0].encode()) for t in targets[:-1]]).astype(np.uint64) if targets else np.zeros(0, np.uint64)
+    ln = np.array([len(t[0].encode()) for t in targets], dtype=np.uint32)
+    tl = np.array([t[1] for t in targets], dtype=np.uint64)
+    out = np.zeros(64 + sum(40 + len(t[0]) for t in targets) + len(read_group), dtype=np.uint8)
+    n = f(C.c_char_p(names), abi.ptr(off), abi.ptr(ln), abi.ptr(tl), C.c_uint32(len(targets)), C.c_char_p(read_group.encode()),
+          C.c_int32(offset_l), C.c_int32(offset_r), abi.ptr(out, C.c_char_p), C.c_uint64(out.size))
+    return out[:n].tobytes()

@@ -127,3 +127,16 @@ def test_device_results_gather_matches_collect(gpu):
     assert g["regions"].tobytes() == host["regions"].tobytes()
     n = len(g["seqs"])
     assert g["seqs"].tobytes() == host["seqs"][:n].tobytes()
+
+
+def test_emitted_text_matches_oracle(gpu, oracle):
+    """End of the path: the SAM / FASTA text of the GPU pipeline's allele records (otg_emit_alleles) against the oracle's
+    emit of the oracle's records — the wire format the reference's parity diff is taken on."""
+    import otter_amd
+    batch = synth.make_batch(24, len_range=(300, 900), n_reads=14, err="ont", seed=35)
+    P = abi.default_params()
+    ora = oracle.assemble_batch(P, batch)
+    res = gpu.assemble(P, batch)
+    beds, carena = abi.make_beds([("chr%d" % (1 + i % 5), 10_000 * i + 7, 10_000 * i + 507) for i in range(len(batch["regions"]))])
+    for rg, fa in (("", False), ("s1", False), ("s1", True)):
+        assert otter_amd.emit_alleles(beds, carena, res, rg, fa) == oracle.emit_alleles(beds, carena, ora, rg, fa)
