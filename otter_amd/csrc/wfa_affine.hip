@@ -490,7 +490,13 @@ __global__ __launch_bounds__(256) void wfa_affine_bound1_kernel(
 {
   static_assert(XS == 2 && OES == 4, "ring roles below are written out for (2,4,1)");
   constexpr int NULLV = -(1 << 29);
+  // per wave: both sequences packed to 2 bits per base (as in the LDS tiers of the exact pass): a probe covers 32 bases
+  // and comes from LDS; pairs that do not fit or contain a byte outside ACGT use the byte probes from HBM
+  constexpr int SEQW = 800;                               // words per wave: pl + tl up to ~12.6 kb
+  __shared__ uint32_t s_pk[4][SEQW];
+  using lds_u32b = __attribute__((address_space(3))) uint32_t;
   const int lane = threadIdx.x & 63;
+  volatile lds_u32b* SQ = (volatile lds_u32b*)&s_pk[threadIdx.x >> 6][0];
   const uint32_t n_todo = n_todo_ptr ? *n_todo_ptr : n_todo_imm;
   for (;;) {
     const uint32_t tk = otg_wave_atomic_add(ticket, 1u);
@@ -517,6 +523,39 @@ __global__ __launch_bounds__(256) void wfa_affine_bound1_kernel(
     };
     int result = 0x7fffffff;
     if (hi0 - lo0 + 1 <= 40 && pl > 0 && tl > 0 && pl < 32766 && tl < 32766) {
+      // pack (in the orientation the pass runs in): word q = bases 16q .. 16q+15, code (byte >> 1) & 3
+      const int offT = (pl + 15) / 16 + 3;
+      bool packed = offT + (tl + 15) / 16 + 3 <= SEQW;
+      if (packed) {
+        bool bad = false;
+        auto pack = [&](const uint8_t* S, int len, int woff) {
+          for (int q = lane; q < (len + 15) / 16; q += 64) {
+            uint32_t w = 0;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const int b0 = 16 * q + 8 * j;
+              const uint64_t x = ld8s(S, len, b0 < len ? b0 : len);
+#pragma unroll
+              for (int t2 = 0; t2 < 8; ++t2) {
+                const uint32_t c = (uint32_t)(x >> (8 * t2)) & 0xffu;
+                const uint32_t code = (c >> 1) & 3u;
+                if (b0 + t2 < len && c != ((0x47544341u >> (8 * code)) & 0xffu)) bad = true;
+                w |= code << (2 * (8 * j + t2));
+              }
+            }
+            SQ[woff + q] = w;
+          }
+        };
+        pack(P, pl, 0);
+        pack(T, tl, offT);
+        packed = __ballot(bad) == 0ull;
+      }
+      auto ld32b = [&](int woff, int pos) -> uint64_t {
+        const int w = woff + (pos >> 4);
+        const uint32_t sh = (uint32_t)(pos & 15) * 2u;
+        const uint32_t d0 = SQ[w], d1 = SQ[w + 1], d2 = SQ[w + 2];
+        return (uint64_t)__builtin_amdgcn_alignbit(d1, d0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32);
+      };
       int bk0 = ((lo0 + hi0) >> 1) - 32;                 // diagonal of lane 0
       int M1 = NULLV, M2 = NULLV, M3 = NULLV, M4 = NULLV, I = NULLV, D = NULLV, cur;
       { const int k = bk0 + lane, h = k > 0 ? k : 0, v = h - k;
@@ -524,15 +563,27 @@ __global__ __launch_bounds__(256) void wfa_affine_bound1_kernel(
       auto extend_and_test = [&]() -> bool {
         const int k = bk0 + lane;
         bool more = cur >= 0;
-        do {
-          const int h = cur, v = h - k;
-          const int vc = imin(imax(v, 0), pl), hc = imin(imax(h, 0), tl);
-          const uint64_t xx = ld8s(P, pl, vc) ^ ld8s(T, tl, hc);
-          int m = xx ? (int)(__builtin_ctzll(xx) >> 3) : 8;
-          m = imin(m, imin(pl - v, tl - h));
-          if (more) cur = h + m;
-          more = more && m == 8 && v + 8 < pl && h + 8 < tl;
-        } while (__ballot(more));
+        if (packed) {
+          do {
+            const int h = cur, v = h - k;
+            const int vc = imin(imax(v, 0), pl), hc = imin(imax(h, 0), tl);
+            const uint64_t xx = ld32b(0, vc) ^ ld32b(offT, hc);
+            int m = xx ? (int)(__builtin_ctzll(xx) >> 1) : 32;
+            m = imin(m, imin(pl - v, tl - h));
+            if (more) cur = h + m;
+            more = more && m == 32 && v + 32 < pl && h + 32 < tl;
+          } while (__ballot(more));
+        } else {
+          do {
+            const int h = cur, v = h - k;
+            const int vc = imin(imax(v, 0), pl), hc = imin(imax(h, 0), tl);
+            const uint64_t xx = ld8s(P, pl, vc) ^ ld8s(T, tl, hc);
+            int m = xx ? (int)(__builtin_ctzll(xx) >> 3) : 8;
+            m = imin(m, imin(pl - v, tl - h));
+            if (more) cur = h + m;
+            more = more && m == 8 && v + 8 < pl && h + 8 < tl;
+          } while (__ballot(more));
+        }
         const int h = cur, v = h - k;
         const bool fin = h >= 0 && ((h >= tl && pl - v <= pef) || (v >= pl && tl - h <= tef));
         return __ballot(fin) != 0;
