@@ -9,6 +9,12 @@
 #include <string>
 #include "anseqs.hpp"
 #include "anbed.hpp"
+#include "anbamfilehelper.hpp"
+#include "anfahelper.hpp"
+#include "otter_opts.hpp"
+#include "sam.h"
+#include "faidx.h"
+#include <vector>
 #include "../include/otter_gpu.h"
 
 extern "C" {
@@ -37,6 +43,86 @@ uint64_t ref_emit_alleles(const otg_bed* beds, const char* chr_arena, uint32_t n
   const std::string t = os.str();
   if (out && cap) memcpy(out, t.data(), t.size() < cap ? t.size() : cap);
   return t.size();
+}
+
+
+// ---- the reference's own ingest as a fixture generator and end-to-end driver ------------
+
+// SAM text -> BAM + BAI with the htslib-lite the reference vendors (sam_parse1 / bam_write1 / bam_index_build).
+int ref_sam_to_bam(const char* sam_path, const char* bam_path)
+{
+  samFile* in = sam_open(sam_path, "r", nullptr);
+  if (!in) return -1;
+  bam_hdr_t* h = sam_hdr_read(in);
+  if (!h) return -2;
+  BGZF* out = bgzf_open(bam_path, "w");
+  if (!out) return -3;
+  if (bam_hdr_write(out, h) < 0) return -4;
+  bam1_t* b = bam_init1();
+  int n = 0;
+  while (sam_read1(in, h, b) >= 0) { if (bam_write1(out, b) < 0) return -5; ++n; }
+  bam_destroy1(b);
+  bgzf_close(out);
+  bam_hdr_destroy(h);
+  sam_close(in);
+  if (bam_index_build(bam_path, 0) < 0) return -6;
+  return n;
+}
+
+struct RefIngest { BamInstance bam; FaidxInstance fa; bool has_fa; };
+
+void* ref_ingest_open(const char* bam_path, const char* fasta_path)
+{
+  RefIngest* r = new RefIngest();
+  r->bam.init(bam_path, true);
+  r->has_fa = fasta_path && fasta_path[0];
+  if (r->has_fa) r->fa.init(fasta_path);
+  return r;
+}
+void ref_ingest_close(void* hnd) { RefIngest* r = (RefIngest*)hnd; r->bam.destroy(); if (r->has_fa) r->fa.destroy(); delete r; }
+
+// parse_anreads (src/anseqs.cpp:439-460) for one BED region, exactly as assemble_process calls it (src/assemble.cpp:55-65):
+// the query region is the BED region widened by the offsets.  Appends the reads to caller buffers in the layout of
+// include/otter_gpu.h (otg_read + byte arena); returns the number of reads, or -(needed) style negatives on overflow.
+int64_t ref_ingest_region(void* hnd, const char* chr, int start, int end, int offset_l, int offset_r, int mapq, int nonprimary,
+                          double read_quality, int omitnonspanning, otg_read* reads, uint64_t reads_cap, uint8_t* arena,
+                          uint64_t arena_cap, uint64_t* arena_used)
+{
+  RefIngest* r = (RefIngest*)hnd;
+  OtterOpts params{};
+  params.mapq = mapq; params.nonprimary = nonprimary != 0; params.read_quality = read_quality; params.omitnonspanning = omitnonspanning != 0;
+  BED mod_bed;
+  mod_bed.chr = chr; mod_bed.start = start - offset_l; mod_bed.end = end + offset_r;
+  std::vector<ANREAD> block;
+  parse_anreads(params, mod_bed, r->bam, block);
+  if (block.size() > reads_cap) return -1;
+  uint64_t used = *arena_used;
+  for (size_t i = 0; i < block.size(); ++i) {
+    const ANREAD& a = block[i];
+    if (used + a.seq.size() + 64 > arena_cap) return -2;
+    memset(&reads[i], 0, sizeof(otg_read));
+    reads[i].seq_off = used; reads[i].seq_len = (uint32_t)a.seq.size();
+    reads[i].spanning_l = a.is_spanning_l; reads[i].spanning_r = a.is_spanning_r;
+    reads[i].ps = a.hpt.ps; reads[i].hp = a.hpt.hp;
+    reads[i].ccoord_first = a.ccoords.first; reads[i].ccoord_second = a.ccoords.second;
+    memcpy(arena + used, a.seq.data(), a.seq.size());
+    used += a.seq.size();
+  }
+  *arena_used = used;
+  return (int64_t)block.size();
+}
+
+// the two reference flanks local_realignment fetches (src/analignments.cpp:22,28 via FaidxInstance::fetch): 0-based inclusive on both
+// ends, i.e. flank + 1 bases, upper-cased by the helper.  Returns the length written (0 when no FASTA was opened).
+int ref_fetch(void* hnd, const char* chr, int beg, int end_incl, char* out, int cap)
+{
+  RefIngest* r = (RefIngest*)hnd;
+  if (!r->has_fa) return 0;
+  std::string s;
+  r->fa.fetch(chr, beg, end_incl, s);
+  const int n = (int)s.size() < cap ? (int)s.size() : cap;
+  memcpy(out, s.data(), n);
+  return (int)s.size();
 }
 
 } // extern "C"
