@@ -240,6 +240,31 @@ int otg_emit_sam_header(const char* name_arena, const uint64_t* name_off, const 
                         const uint64_t* target_len, uint32_t n_targets, const char* read_group,
                         int32_t offset_l, int32_t offset_r, char* out, uint64_t out_capacity, uint64_t* out_len);
 
+/* ---------------------------------------------------------------------------------------------
+ * BAM/BAI region ingest: the reads of each BED region as `parse_anreads` delivers them to the hot
+ * path (src/anseqs.cpp:244-460, called at src/assemble.cpp:55-65), straight into the region batch of
+ * otg_assemble_submit.  Host code (zlib + stdio); the index is `<bam>.bai` (src/anbamfilehelper.cpp:20).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct otg_bam otg_bam;
+typedef struct otg_ingest_opts {
+  int32_t offset_l, offset_r;   /* --offset: the query region is [start - offset_l, end + offset_r] (src/assemble.cpp:55-57) */
+  int32_t mapq;                 /* --mapq                                                     */
+  int32_t nonprimary;           /* --non-primary: keep secondary / supplementary alignments   */
+  int32_t omit_nonspanning;     /* --omit-nonspanning                                         */
+  int32_t threads;              /* host threads for the ingest (regions are split into contiguous slices); <= 1: one */
+  double  read_quality;         /* --read-quality (tag rq)                                    */
+} otg_ingest_opts;
+int  otg_bam_open(const char* bam_path, otg_bam** out);
+void otg_bam_close(otg_bam* bam);
+uint32_t otg_bam_n_targets(const otg_bam* bam);
+const char* otg_bam_target(const otg_bam* bam, uint32_t i, uint64_t* length);   /* name (owned by the handle) + length: @SQ lines */
+/* Appends the reads of n_regions BED regions to arena / reads (in-out counters *arena_used, *n_reads) and fills
+ * regions[i].first_read / n_reads (flank fields zeroed).  OTG_ERR_CAPACITY: buffers too small, the counters hold the
+ * needed totals.  Reads come in file order; filters, sub-sequence, spanning flags and clip coordinates as the reference. */
+int  otg_ingest_regions(otg_bam* bam, const otg_bed* beds, const char* chr_arena, uint32_t n_regions,
+                        const otg_ingest_opts* opts, uint8_t* arena, uint64_t arena_capacity, uint64_t* arena_used,
+                        otg_read* reads, uint32_t reads_capacity, uint32_t* n_reads, otg_region* regions);
+
 /* Workload statistics of the last otg_assemble_run (for the roofline figure). */
 typedef struct otg_run_stats {
   uint64_t n_regions, n_regions_ok;

@@ -15,6 +15,7 @@ EXPORTS = [
     "otg_genotype_cluster_batch", "otg_assemble_submit", "otg_assemble_run", "otg_assemble_result_sizes",
     "otg_assemble_collect", "otg_assemble_device_results", "otg_assemble_stats",
     "otg_emit_alleles", "otg_emit_sam_header",
+    "otg_bam_open", "otg_bam_close", "otg_bam_n_targets", "otg_bam_target", "otg_ingest_regions",
 ]
 
 _lib = None
@@ -252,3 +253,62 @@ def emit_sam_header(targets, read_group="", offset_l=0, offset_r=0):
     if rc != 0:
         raise OtterGpuError("otg_emit_sam_header failed (%d)" % rc)
     return out[:n.value].tobytes()
+
+
+class Bam:
+    """An indexed BAM (otg_bam_open: <path> + <path>.bai) as the source of region batches (otg_ingest_regions)."""
+
+    def __init__(self, path):
+        L = load()
+        h = C.c_void_p()
+        rc = L.otg_bam_open(C.c_char_p(path.encode()), C.byref(h))
+        if rc != 0:
+            raise OtterGpuError("otg_bam_open failed (%d): %s" % (rc, (L.otg_last_error(None) or b"").decode()))
+        self._h, self._L, self._path = h, L, path
+        L.otg_bam_target.restype = C.c_char_p
+        L.otg_bam_n_targets.restype = C.c_uint32
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.otg_bam_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def targets(self):
+        out = []
+        for i in range(self._L.otg_bam_n_targets(self._h)):
+            ln = C.c_uint64(0)
+            nm = self._L.otg_bam_target(self._h, C.c_uint32(i), C.byref(ln))
+            out.append((nm.decode(), int(ln.value)))
+        return out
+
+    def ingest(self, regions, offset_l=0, offset_r=0, mapq=0, nonprimary=False, omit_nonspanning=False, read_quality=0.0, threads=1):
+        """regions: list of (chr, start, end) -> batch dict {"arena", "reads", "regions"} for Context.assemble_submit
+        (reference flanks, needed only with -r, are the caller's to append)."""
+        beds, carena = abi.make_beds(regions)
+        opts = np.zeros(1, dtype=abi.ingest_opts_dt)
+        opts[0]["offset_l"] = offset_l; opts[0]["offset_r"] = offset_r; opts[0]["mapq"] = mapq
+        opts[0]["nonprimary"] = int(nonprimary); opts[0]["omit_nonspanning"] = int(omit_nonspanning); opts[0]["read_quality"] = read_quality; opts[0]["threads"] = threads
+        regs = np.zeros(len(beds), dtype=abi.region_dt)
+        # generous first guess from the file size (untouched pages cost nothing), exact retry if it was too small
+        fsz = os.path.getsize(self._path)
+        cap_r, cap_a = max(1024, fsz // 64), max(1 << 20, 8 * fsz)
+        while True:
+            reads = np.empty(cap_r, dtype=abi.read_dt)
+            arena = np.empty(cap_a, dtype=np.uint8)
+            used, nr = C.c_uint64(0), C.c_uint32(0)
+            rc = self._L.otg_ingest_regions(self._h, abi.ptr(beds), abi.ptr(carena, C.c_char_p), C.c_uint32(len(beds)), abi.ptr(opts),
+                                            abi.ptr(arena), C.c_uint64(cap_a), C.byref(used), abi.ptr(reads), C.c_uint32(cap_r), C.byref(nr),
+                                            abi.ptr(regs))
+            if rc == abi.OTG_ERR_CAPACITY:
+                cap_r, cap_a = max(cap_r, nr.value + 16), max(cap_a, used.value + 64 * (nr.value + 2) + 4096)
+                continue
+            if rc != 0:
+                raise OtterGpuError("otg_ingest_regions failed (%d): %s" % (rc, (self._L.otg_last_error(None) or b"").decode()))
+            arena[used.value:used.value + 64] = 0
+            return {"arena": np.ascontiguousarray(arena[:used.value + 64]), "reads": np.ascontiguousarray(reads[:nr.value]), "regions": regs}

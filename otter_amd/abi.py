@@ -88,6 +88,11 @@ bed_dt = np.dtype([("chr_off", "<u8"), ("chr_len", "<u4"), ("start", "<i4"), ("e
 assert bed_dt.itemsize == 24
 
 
+ingest_opts_dt = np.dtype([("offset_l", "<i4"), ("offset_r", "<i4"), ("mapq", "<i4"), ("nonprimary", "<i4"), ("omit_nonspanning", "<i4"),
+                           ("threads", "<i4"), ("read_quality", "<f8")], align=True)
+assert ingest_opts_dt.itemsize == 32
+
+
 def make_beds(regions):
     """regions: list of (chr_str, start, end) -> (otg_bed array, chr byte arena)."""
     beds = np.zeros(len(regions), dtype=bed_dt)

@@ -1,0 +1,494 @@
+// ingest.hip — BAM/BAI region ingest (the "next" row in front of the hot path): for every BED region the
+// reads overlapping it, cut to the region and flagged, as `parse_anreads` hands them to the five hot-path calls
+// (reference: src/anseqs.cpp:244-460 — parse_standard_auxs, get_breakpoints, parse_alignment, parse_anreads — called at
+// src/assemble.cpp:55-65 on the offset-widened region; file formats: BGZF / BAM / BAI as read by the htslib-lite the
+// reference vendors, src/bgzf.c, src/sam.c, src/hts.c:690-870).  Host code (north_star keeps ingest on the host); written
+// from the format definitions, not from those sources: a BGZF block reader on zlib, a BAI loader, the standard
+// bin + linear-index region query, and a restatement of the reference's CIGAR walk with all of its quirks.
+// Output goes straight into the region batch of the L3 pipeline (otg_read / otg_region + byte arena).
+#include "otg_common.hpp"
+#include <zlib.h>
+#include <algorithm>
+#include <cstdio>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+struct Bgzf {
+  FILE* fp = nullptr;
+  uint64_t block_address = 0;      // file offset of the current (or next, when nothing is loaded) block
+  uint32_t block_csize = 0;        // compressed size of the loaded block (0 = nothing loaded)
+  uint32_t block_length = 0;       // its uncompressed size
+  uint32_t block_offset = 0;
+  std::vector<uint8_t> cbuf, ubuf;
+  bool eof = false;
+
+  bool open(const char* path) { fp = fopen(path, "rb"); return fp != nullptr; }
+  void close() { if (fp) fclose(fp); fp = nullptr; }
+  // loads the block at block_address; false on EOF / malformed data
+  bool load() {
+    block_csize = block_length = block_offset = 0;
+    if (fseeko(fp, (off_t)block_address, SEEK_SET) != 0) return false;
+    uint8_t h[12];
+    if (fread(h, 1, 12, fp) != 12) { eof = true; return false; }
+    if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) return false;
+    const uint32_t xlen = h[10] | (h[11] << 8);
+    uint8_t extra[256];
+    if (xlen > sizeof extra) return false;
+    if (xlen && fread(extra, 1, xlen, fp) != xlen) return false;
+    int bsize = -1;
+    for (uint32_t i = 0; i + 4 <= xlen;) {
+      const uint32_t slen = extra[i + 2] | (extra[i + 3] << 8);
+      if (extra[i] == 'B' && extra[i + 1] == 'C' && slen == 2 && i + 6 <= xlen) bsize = extra[i + 4] | (extra[i + 5] << 8);
+      i += 4 + slen;
+    }
+    if (bsize < 0) return false;
+    const uint32_t total = (uint32_t)bsize + 1;
+    if (total < 12 + xlen + 8) return false;
+    const uint32_t clen = total - 12 - xlen - 8;
+    cbuf.resize(clen + 8);
+    if (fread(cbuf.data(), 1, clen + 8, fp) != clen + 8) return false;
+    const uint8_t* t = cbuf.data() + clen;
+    const uint32_t isize = t[4] | (t[5] << 8) | (t[6] << 16) | ((uint32_t)t[7] << 24);
+    ubuf.resize(isize ? isize : 1);
+    if (isize) {
+      z_stream zs{};
+      zs.next_in = cbuf.data(); zs.avail_in = clen; zs.next_out = ubuf.data(); zs.avail_out = isize;
+      if (inflateInit2(&zs, -15) != Z_OK) return false;
+      const int rc = inflate(&zs, Z_FINISH);
+      inflateEnd(&zs);
+      if (rc != Z_STREAM_END || zs.total_out != isize) return false;
+    }
+    block_csize = total; block_length = isize;
+    return true;
+  }
+  // like bgzf_read: returns bytes read (< n at end of file)
+  size_t read(void* dst, size_t n) {
+    size_t got = 0;
+    uint8_t* out = (uint8_t*)dst;
+    while (got < n) {
+      if (block_offset >= block_length) {
+        if (block_csize) block_address += block_csize;          // move past the consumed block
+        if (!load()) break;
+        if (block_length == 0) { if (eof) break; continue; }     // empty block (e.g. the EOF marker): try the next one
+      }
+      const size_t k = std::min<size_t>(n - got, block_length - block_offset);
+      memcpy(out + got, ubuf.data() + block_offset, k);
+      got += k; block_offset += (uint32_t)k;
+    }
+    if (block_csize && block_offset == block_length) {           // bgzf_tell semantics: a fully consumed block points at the next one
+      block_address += block_csize; block_csize = block_length = block_offset = 0;
+    }
+    return got;
+  }
+  bool seek(uint64_t voff) {
+    eof = false;
+    if (block_csize && block_address == (voff >> 16)) { block_offset = (uint32_t)(voff & 0xffff); return block_offset <= block_length; }   // already inflated
+    block_address = voff >> 16;
+    if (!load()) return false;
+    block_offset = (uint32_t)(voff & 0xffff);
+    return block_offset <= block_length;
+  }
+  uint64_t tell() const { return (block_address << 16) | (block_offset & 0xffffu); }
+};
+
+struct RefIndex {
+  std::unordered_map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>> bins;
+  std::vector<uint64_t> linear;
+};
+
+} // namespace
+
+struct otg_bam {
+  Bgzf fp;
+  std::vector<std::string> names;
+  std::vector<uint32_t> lengths;
+  std::unordered_map<std::string, int> name2id;
+  std::vector<RefIndex> idx;
+  std::vector<uint8_t> rec;        // one decoded record
+  std::string err;
+  std::string path;
+};
+
+namespace {
+
+inline uint32_t rd32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+
+bool load_bai(otg_bam* b, const std::string& path)
+{
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) { b->err = "cannot open index " + path; return false; }
+  auto rd = [&](void* p, size_t n) { return fread(p, 1, n, f) == n; };
+  char magic[4]; int32_t n_ref = 0;
+  bool ok = rd(magic, 4) && memcmp(magic, "BAI\1", 4) == 0 && rd(&n_ref, 4) && n_ref >= 0;
+  if (ok) b->idx.resize((size_t)n_ref);
+  for (int32_t r = 0; ok && r < n_ref; ++r) {
+    int32_t n_bin = 0;
+    ok = rd(&n_bin, 4);
+    for (int32_t i = 0; ok && i < n_bin; ++i) {
+      uint32_t bin; int32_t n_chunk;
+      ok = rd(&bin, 4) && rd(&n_chunk, 4) && n_chunk >= 0;
+      if (!ok) break;
+      std::vector<std::pair<uint64_t, uint64_t>> ch((size_t)n_chunk);
+      for (int32_t c = 0; ok && c < n_chunk; ++c) ok = rd(&ch[c].first, 8) && rd(&ch[c].second, 8);
+      b->idx[r].bins[bin] = std::move(ch);
+    }
+    int32_t n_intv = 0;
+    ok = ok && rd(&n_intv, 4) && n_intv >= 0;
+    if (ok) {
+      b->idx[r].linear.resize((size_t)n_intv);
+      if (n_intv) ok = rd(b->idx[r].linear.data(), (size_t)n_intv * 8);
+      for (int32_t j = 1; j < n_intv; ++j) if (b->idx[r].linear[j] == 0) b->idx[r].linear[j] = b->idx[r].linear[j - 1];
+    }
+  }
+  fclose(f);
+  if (!ok) b->err = "malformed BAI " + path;
+  return ok;
+}
+
+// candidate bins of [beg, end) in the 6-level UCSC binning scheme (min_shift 14, 5 levels below the root)
+void reg2bins(int64_t beg, int64_t end, std::vector<uint32_t>& out)
+{
+  if (beg >= end) return;
+  if (end > (1LL << 29)) end = 1LL << 29;
+  --end;
+  int s = 29, t = 0;
+  for (int l = 0; l <= 5; ++l) {
+    const int64_t b = t + (beg >> s), e = t + (end >> s);
+    for (int64_t i = b; i <= e; ++i) out.push_back((uint32_t)i);
+    t += 1 << (3 * l);
+    s -= 3;
+  }
+}
+
+struct Rec {
+  int32_t tid, pos, l_seq;
+  uint32_t mapq, flag, n_cigar;
+  const uint32_t* cigar;       // may be unaligned: read with rd32
+  const uint8_t* seq;
+  const uint8_t* aux;
+  const uint8_t* aux_end;
+};
+
+inline int cig_op(const uint8_t* c, uint32_t i) { return (int)(rd32(c + 4 * i) & 0xf); }
+inline int cig_len(const uint8_t* c, uint32_t i) { return (int)(rd32(c + 4 * i) >> 4); }
+
+// returns 1 record decoded, 0 end of file, -1 error
+int read_record(otg_bam* b, Rec* r)
+{
+  int32_t block_len = 0;
+  const size_t g = b->fp.read(&block_len, 4);
+  if (g == 0) return 0;
+  if (g != 4 || block_len < 32) return -1;
+  b->rec.resize((size_t)block_len);
+  if (b->fp.read(b->rec.data(), (size_t)block_len) != (size_t)block_len) return -1;
+  const uint8_t* p = b->rec.data();
+  r->tid = (int32_t)rd32(p); r->pos = (int32_t)rd32(p + 4);
+  const uint32_t bmn = rd32(p + 8), fnc = rd32(p + 12);
+  const uint32_t l_name = bmn & 0xff;
+  r->mapq = (bmn >> 8) & 0xff; r->flag = fnc >> 16; r->n_cigar = fnc & 0xffff;
+  r->l_seq = (int32_t)rd32(p + 16);
+  const size_t need = 32 + (size_t)l_name + 4 * (size_t)r->n_cigar + ((size_t)r->l_seq + 1) / 2 + (size_t)r->l_seq;
+  if (r->l_seq < 0 || need > (size_t)block_len) return -1;
+  const uint8_t* q = p + 32 + l_name;
+  r->cigar = (const uint32_t*)q;
+  r->seq = q + 4 * (size_t)r->n_cigar;
+  r->aux = r->seq + ((size_t)r->l_seq + 1) / 2 + (size_t)r->l_seq;
+  r->aux_end = p + block_len;
+  return 1;
+}
+
+// reference length of the CIGAR (ops that consume the reference: M D N = X)
+int cigar_rlen(const Rec& r)
+{
+  int l = 0;
+  const uint8_t* c = (const uint8_t*)r.cigar;
+  for (uint32_t k = 0; k < r.n_cigar; ++k) { const int op = cig_op(c, k); if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) l += cig_len(c, k); }
+  return l;
+}
+
+// pointer to the value (type byte first) of an aux tag, or null (bam_aux_get)
+const uint8_t* aux_get(const Rec& r, char t0, char t1)
+{
+  const uint8_t* s = r.aux;
+  while (s + 3 <= r.aux_end) {
+    const bool hit = s[0] == (uint8_t)t0 && s[1] == (uint8_t)t1;
+    s += 2;
+    if (hit) return s;
+    const int type = *s++;
+    size_t sz = 0;
+    switch (type) {
+      case 'A': case 'c': case 'C': sz = 1; break;
+      case 's': case 'S': sz = 2; break;
+      case 'i': case 'I': case 'f': sz = 4; break;
+      case 'd': sz = 8; break;
+      case 'Z': case 'H': while (s < r.aux_end && *s) ++s; sz = 1; break;
+      case 'B': {
+        if (s + 5 > r.aux_end) return nullptr;
+        const int sub = *s; const uint32_t n = rd32(s + 1);
+        const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+        s += 5; sz = es * (size_t)n; break;
+      }
+      default: return nullptr;
+    }
+    s += sz;
+  }
+  return nullptr;
+}
+int32_t aux2i(const uint8_t* s)
+{
+  const int type = *s++;
+  if (type == 'c') return (int32_t)(int8_t)s[0];
+  if (type == 'C') return (int32_t)s[0];
+  if (type == 's') { int16_t v; memcpy(&v, s, 2); return v; }
+  if (type == 'S') { uint16_t v; memcpy(&v, s, 2); return v; }
+  if (type == 'i' || type == 'I') { int32_t v; memcpy(&v, s, 4); return v; }
+  return 0;
+}
+double aux2f(const uint8_t* s)
+{
+  const int type = *s++;
+  if (type == 'd') { double v; memcpy(&v, s, 8); return v; }
+  if (type == 'f') { float v; memcpy(&v, s, 4); return (double)v; }
+  return 0.0;
+}
+
+struct ParseMsg { bool successful = true, spanning_l = true, spanning_r = true; int c_first = -1, c_second = -1; };
+
+// get_breakpoints (src/anseqs.cpp:286-408), restated with its quirks; q_first / q_second = the extracted query interval
+void get_breakpoints(int start, int end, const Rec& r, ParseMsg& msg, bool& have, int& q_first, int& q_second)
+{
+  bool clipped_l = false, clipped_r = false;
+  int qstart_dist = -1, qend_dist = -1;
+  int leftmost_q = -1, rightmost_q = -1, leftmost_r = -1, rightmost_r = -1;
+  int qstart_q = -1, qend_q = -1;
+  uint32_t qstart_cigar_i = 0, qend_cigar_i = 0;
+  const uint8_t* cg = (const uint8_t*)r.cigar;
+  int rpos = r.pos, qpos = 0;
+  for (uint32_t i = 0; i < r.n_cigar; ++i) {
+    const int op = cig_op(cg, i), ol = cig_len(cg, i);
+    if (op == 5 || op == 4) {                      // H, S
+      if (i == 0) clipped_l = true;
+      if (i == r.n_cigar - 1) clipped_r = true;
+      if (op == 4) qpos += ol;
+    } else if (op == 0 || op == 7 || op == 8) {    // M, =, X
+      for (int j = 0; j < ol; ++j) {
+        if (leftmost_q == -1) { leftmost_q = qpos; leftmost_r = rpos; }
+        if (rightmost_q == -1 || rpos > rightmost_r) { rightmost_q = qpos; rightmost_r = rpos; }
+        const int cstart_dist = rpos - start, cend_dist = end - rpos;
+        if (cstart_dist >= 0 && (qstart_dist < 0 || cstart_dist < qstart_dist)) { qstart_dist = cstart_dist; qstart_q = qpos; qstart_cigar_i = i; }
+        if (cend_dist >= 0 && (qend_dist < 0 || cend_dist < qend_dist)) { qend_dist = cend_dist; qend_q = qpos; qend_cigar_i = i; }
+        ++rpos; ++qpos;
+      }
+    } else if (op == 1) qpos += ol;                // I
+    else if (op == 2) rpos += ol;                  // D   (N, P: ignored, as in the reference)
+  }
+  if (rightmost_r < start || leftmost_r > end) {
+    qstart_q = qend_q = -1;
+    msg.successful = false; msg.spanning_l = false; msg.spanning_r = false;
+  } else if (qstart_q > -1 && qend_q > -1 && qstart_q > qend_q) {     // region deleted in the read
+    qstart_q = qend_q = -1;
+    msg.successful = true; msg.spanning_l = true; msg.spanning_r = true;
+  } else {
+    msg.c_first = qstart_q; msg.c_second = qend_q;
+    if (leftmost_r > start && clipped_l && qstart_cigar_i == 1) {
+      while (qstart_q > 0 && qstart_cigar_i > 0) {
+        const int op = cig_op(cg, qstart_cigar_i - 1), ol = cig_len(cg, qstart_cigar_i - 1);
+        if (op == 2) --qstart_cigar_i;
+        else if (op == 5 || op == 4 || op == 1) { qstart_q -= ol; --qstart_cigar_i; }
+        else break;
+      }
+    }
+    if (rightmost_r < end && clipped_r && qend_cigar_i == r.n_cigar - 1) {
+      while (qend_q < r.l_seq - 1 && qend_cigar_i < r.n_cigar) {
+        const int op = cig_op(cg, qend_cigar_i - 1), ol = cig_len(cg, qend_cigar_i - 1);
+        if (op == 2) ++qend_cigar_i;
+        else if (op == 5 || op == 4 || op == 1) { qend_q += ol; ++qend_cigar_i; }
+        else break;
+      }
+    }
+    msg.spanning_l = leftmost_q >= 0 && leftmost_r <= start;
+    msg.spanning_r = rightmost_q >= 0 && rightmost_r >= end;
+    msg.successful = true;
+  }
+  have = false;
+  if (msg.successful) {
+    have = true;
+    if (msg.spanning_l && msg.spanning_r) { q_first = qstart_q; q_second = qend_q; }
+    else if (msg.spanning_l) { q_first = qstart_q; q_second = r.l_seq; }
+    else if (msg.spanning_r) { q_first = 0; q_second = qend_q; }
+    else { q_first = 0; q_second = r.l_seq; }
+  }
+}
+
+} // namespace
+
+extern "C" {
+
+int otg_bam_open(const char* bam_path, otg_bam** out)
+{
+  if (!bam_path || !out) return otg_fail(nullptr, OTG_ERR_ARG, "otg_bam_open: null argument");
+  otg_bam* b = new otg_bam();
+  auto bail = [&](const std::string& m) { const int rc = otg_fail(nullptr, OTG_ERR_ARG, "otg_bam_open(%s): %s", bam_path, m.c_str()); delete b; return rc; };
+  if (!b->fp.open(bam_path)) return bail("cannot open");
+  char magic[4]; int32_t l_text = 0, n_ref = 0;
+  if (b->fp.read(magic, 4) != 4 || memcmp(magic, "BAM\1", 4) != 0) { b->fp.close(); return bail("not a BAM file"); }
+  if (b->fp.read(&l_text, 4) != 4 || l_text < 0) { b->fp.close(); return bail("truncated header"); }
+  std::vector<char> text((size_t)l_text + 1);
+  if (l_text && b->fp.read(text.data(), (size_t)l_text) != (size_t)l_text) { b->fp.close(); return bail("truncated header text"); }
+  if (b->fp.read(&n_ref, 4) != 4 || n_ref < 0) { b->fp.close(); return bail("truncated reference list"); }
+  for (int32_t i = 0; i < n_ref; ++i) {
+    int32_t l_name = 0; uint32_t l_ref = 0;
+    if (b->fp.read(&l_name, 4) != 4 || l_name <= 0) { b->fp.close(); return bail("bad reference name"); }
+    std::string nm((size_t)l_name, '\0');
+    if (b->fp.read(&nm[0], (size_t)l_name) != (size_t)l_name || b->fp.read(&l_ref, 4) != 4) { b->fp.close(); return bail("truncated reference entry"); }
+    nm.resize(strlen(nm.c_str()));
+    b->name2id.emplace(nm, i);
+    b->names.push_back(nm); b->lengths.push_back(l_ref);
+  }
+  if (!load_bai(b, std::string(bam_path) + ".bai")) { const std::string e = b->err; b->fp.close(); return bail(e); }   // src/anbamfilehelper.cpp:20
+  b->path = bam_path;
+  *out = b;
+  return OTG_OK;
+}
+
+void otg_bam_close(otg_bam* b) { if (b) { b->fp.close(); delete b; } }
+
+uint32_t otg_bam_n_targets(const otg_bam* b) { return b ? (uint32_t)b->names.size() : 0; }
+const char* otg_bam_target(const otg_bam* b, uint32_t i, uint64_t* length)
+{
+  if (!b || i >= b->names.size()) return nullptr;
+  if (length) *length = b->lengths[i];
+  return b->names[i].c_str();
+}
+
+// one contiguous slice of regions on its own file handle: reads + bytes into private vectors, regions[].first_read relative
+static int ingest_slice(const otg_bam* b, const char* path, const otg_bed* beds, const char* chr_arena, uint32_t g0, uint32_t g1,
+                        const otg_ingest_opts* opts, std::vector<otg_read>& reads, std::vector<uint8_t>& arena, otg_region* regions, std::string& err)
+{
+  static const char nt16[] = "=ACMGRSVTWYHKDBN";
+  otg_bam local;                               // private BGZF reader + record buffer; the index is read through `b`
+  if (!local.fp.open(path)) { err = "cannot reopen BAM"; return OTG_ERR_ARG; }
+  std::vector<uint32_t> bins;
+  std::vector<std::pair<uint64_t, uint64_t>> chunks;
+  std::string seq;
+  int rc_out = OTG_OK;
+  for (uint32_t g = g0; g < g1 && rc_out == OTG_OK; ++g) {
+    memset(&regions[g], 0, sizeof(otg_region));
+    const uint32_t first = (uint32_t)reads.size();
+    regions[g].first_read = first;
+    // the query region is the BED region widened by the offsets (src/assemble.cpp:55-57), passed to htslib as "chr:start-end":
+    // the start is read 1-based (beg = start - 1, src/hts.c:813).  BED coordinates are unsigned in the reference, so a start
+    // below the offset wraps; the wrapped number parses to a negative int, which htslib clamps to 0, while the CIGAR walk
+    // sees the (negative) int — exactly what the plain int arithmetic here gives.
+    const int start = beds[g].start - opts->offset_l, end = beds[g].end + opts->offset_r;
+    const std::string chr(chr_arena + beds[g].chr_off, beds[g].chr_len);
+    auto it = b->name2id.find(chr);
+    long long qbeg = (long long)start - 1; if (qbeg < 0) qbeg = 0;
+    const long long qend = end;
+    if (it == b->name2id.end() || end < 0 || qbeg > qend) { regions[g].n_reads = 0; continue; }
+    const int tid = it->second;
+    const RefIndex& ri = b->idx[(size_t)tid];
+    uint64_t min_off = 0;
+    if (!ri.linear.empty()) { const size_t w = (size_t)(qbeg >> 14); min_off = ri.linear[w < ri.linear.size() ? w : ri.linear.size() - 1]; }
+    bins.clear(); chunks.clear();
+    reg2bins(qbeg, qend, bins);
+    for (uint32_t bn : bins) { auto f = ri.bins.find(bn); if (f != ri.bins.end()) for (auto& c : f->second) if (c.second > min_off) chunks.push_back(c); }
+    std::sort(chunks.begin(), chunks.end());
+    size_t m = 0;
+    for (size_t i = 0; i < chunks.size(); ++i) {              // merge overlapping / adjacent chunks
+      if (m && chunks[i].first <= chunks[m - 1].second) chunks[m - 1].second = std::max(chunks[m - 1].second, chunks[i].second);
+      else chunks[m++] = chunks[i];
+    }
+    chunks.resize(m);
+    bool finished = false;
+    for (size_t ci = 0; ci < chunks.size() && !finished; ++ci) {
+      if (!local.fp.seek(chunks[ci].first)) { err = "cannot seek in BAM"; rc_out = OTG_ERR_ARG; break; }
+      while (local.fp.tell() < chunks[ci].second) {
+        Rec r;
+        const int rc = read_record(&local, &r);
+        if (rc == 0) { finished = true; break; }
+        if (rc < 0) { err = "malformed BAM record"; rc_out = OTG_ERR_ARG; finished = true; break; }
+        const long long rend = (long long)r.pos + (r.n_cigar ? cigar_rlen(r) : 1);
+        if (r.tid != tid || r.pos >= qend) { finished = true; break; }
+        if (!(rend > qbeg && qend > r.pos)) continue;
+        // ---- parse_anreads (src/anseqs.cpp:444-457)
+        if (!((int)r.mapq >= opts->mapq && (opts->nonprimary || !(r.flag & 0x100u || r.flag & 0x800u)))) continue;
+        ParseMsg msg; bool have = false; int q_first = 0, q_second = 0;
+        get_breakpoints(start, end, r, msg, have, q_first, q_second);
+        if (!msg.successful) continue;
+        seq.clear();
+        if (q_first == -1 || r.l_seq < (q_second - q_first)) seq = "N";          // parse_alignment :421-432
+        else {
+          const int l_sub = q_second - q_first, l_og = msg.c_second - msg.c_first;
+          msg.c_first = msg.c_first - q_first;
+          msg.c_second = msg.c_first + l_og;
+          seq.resize(l_sub > 0 ? (size_t)l_sub : 0);
+          for (int i = 0; i < l_sub; ++i) { const int qi = i + q_first; seq[(size_t)i] = nt16[(r.seq[qi >> 1] >> ((~qi & 1) << 2)) & 0xf]; }
+          if (seq.empty()) seq = "N";
+        }
+        if (opts->omit_nonspanning && !(msg.spanning_l && msg.spanning_r)) continue;
+        int32_t hp = -1, ps = -1; double rq = 0.0;
+        if (const uint8_t* a = aux_get(r, 'H', 'P')) hp = aux2i(a);
+        if (const uint8_t* a = aux_get(r, 'P', 'S')) ps = aux2i(a);
+        if (const uint8_t* a = aux_get(r, 'r', 'q')) rq = aux2f(a);
+        if (!(rq >= opts->read_quality)) continue;
+        otg_read o;
+        memset(&o, 0, sizeof(o));
+        o.seq_off = arena.size(); o.seq_len = (uint32_t)seq.size();
+        o.spanning_l = msg.spanning_l ? 1 : 0; o.spanning_r = msg.spanning_r ? 1 : 0;
+        o.ps = ps; o.hp = hp; o.ccoord_first = msg.c_first; o.ccoord_second = msg.c_second;
+        arena.insert(arena.end(), seq.begin(), seq.end());
+        reads.push_back(o);
+      }
+    }
+    regions[g].n_reads = (uint32_t)reads.size() - first;
+  }
+  local.fp.close();
+  return rc_out;
+}
+
+int otg_ingest_regions(otg_bam* b, const otg_bed* beds, const char* chr_arena, uint32_t n_regions, const otg_ingest_opts* opts,
+                       uint8_t* arena, uint64_t arena_capacity, uint64_t* arena_used, otg_read* reads, uint32_t reads_capacity,
+                       uint32_t* n_reads, otg_region* regions)
+{
+  if (!b || (n_regions && (!beds || !regions)) || !opts || !arena_used || !n_reads) return otg_fail(nullptr, OTG_ERR_ARG, "otg_ingest_regions: null argument");
+  // regions are independent: contiguous slices on separate threads (each with its own file handle, as the reference's pool
+  // threads have, src/assemble.cpp:45-46), merged in region order afterwards
+  uint32_t T = opts->threads > 1 ? (uint32_t)opts->threads : 1u;
+  if (T > n_regions) T = n_regions ? n_regions : 1;
+  std::vector<std::vector<otg_read>> R(T);
+  std::vector<std::vector<uint8_t>> A(T);
+  std::vector<int> rcs(T, OTG_OK);
+  std::vector<std::string> errs(T);
+  auto work = [&](uint32_t t) {
+    const uint32_t g0 = (uint32_t)((uint64_t)n_regions * t / T), g1 = (uint32_t)((uint64_t)n_regions * (t + 1) / T);
+    rcs[t] = ingest_slice(b, b->path.c_str(), beds, chr_arena, g0, g1, opts, R[t], A[t], regions, errs[t]);
+  };
+  if (T == 1) work(0);
+  else {
+    std::vector<std::thread> th;
+    for (uint32_t t = 0; t < T; ++t) th.emplace_back(work, t);
+    for (auto& x : th) x.join();
+  }
+  for (uint32_t t = 0; t < T; ++t) if (rcs[t] != OTG_OK) return otg_fail(nullptr, rcs[t], "otg_ingest_regions: %s", errs[t].c_str());
+  uint64_t used = *arena_used; uint32_t nr = *n_reads;
+  bool overflow = false;
+  for (uint32_t t = 0; t < T; ++t) {
+    const uint32_t g0 = (uint32_t)((uint64_t)n_regions * t / T), g1 = (uint32_t)((uint64_t)n_regions * (t + 1) / T);
+    for (uint32_t g = g0; g < g1; ++g) regions[g].first_read += nr;
+    const bool fits = (uint64_t)nr + R[t].size() <= reads_capacity && used + A[t].size() + 64 <= arena_capacity;
+    if (fits && !overflow) {
+      for (size_t i = 0; i < R[t].size(); ++i) { reads[nr + i] = R[t][i]; reads[nr + i].seq_off += used; }
+      if (!A[t].empty()) memcpy(arena + used, A[t].data(), A[t].size());
+    } else overflow = true;
+    nr += (uint32_t)R[t].size(); used += A[t].size();
+  }
+  *arena_used = used; *n_reads = nr;
+  return overflow ? OTG_ERR_CAPACITY : OTG_OK;
+}
+
+} // extern "C"

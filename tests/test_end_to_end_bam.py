@@ -60,3 +60,25 @@ def test_bam_with_reference_flanks_realign(gpu, oracle, tmp_path):
     beds, carena = abi.make_beds(ds["regions"])
     assert np.array_equal(res["labels"], ora["labels"])
     assert otter_amd.emit_alleles(beds, carena, res, "", True) == oracle.emit_alleles(beds, carena, ora, "", True)
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_bam_to_sam_text_all_native(gpu, oracle, tmp_path):
+    """The whole chain without the reference at run time: otg_bam_open / otg_ingest_regions -> GPU hot path ->
+    otg_emit_alleles, against reference ingest -> oracle -> oracle emit (the BAM itself is written by the reference's
+    htslib-lite, which is why the prebuilt _ref library is still needed to make the fixture)."""
+    import os
+    import e2e_bam
+    ds = e2e_bam.make_dataset(str(tmp_path), n_regions=10, seed=65)
+    ref_batch = e2e_bam.ingest_with_reference(ds, str(tmp_path), offset_l=1, offset_r=1, mapq=10)
+    bam = otter_amd.Bam(os.path.join(str(tmp_path), "reads.bam"))
+    batch = bam.ingest(ds["regions"], offset_l=1, offset_r=1, mapq=10)
+    targets = bam.targets()
+    bam.close()
+    P = abi.default_params()
+    res = gpu.assemble(P, batch)
+    ora = oracle.assemble_batch(P, ref_batch)
+    beds, carena = abi.make_beds(ds["regions"])
+    assert otter_amd.emit_sam_header(targets, "s1", 1, 1) + otter_amd.emit_alleles(beds, carena, res, "s1", False) == \
+        oracle.emit_sam_header([(ds["chrom"], ds["ref_len"])], "s1", 1, 1) + oracle.emit_alleles(beds, carena, ora, "s1", False)

@@ -1,0 +1,139 @@
+"""BAM/BAI region ingest: the product's own reader (otg_bam_open / otg_ingest_regions: BGZF on zlib, BAI,
+CIGAR walk) against the REFERENCE's ingest built from its sources (parse_anreads over its htslib-lite,
+oracle/_ref/libotter_ref_io.so), on BAM files written by that htslib-lite from synthetic SAM text.  Host code: runs
+without a GPU.  Skipped when the reference build is absent."""
+import ctypes as C
+import os
+import numpy as np
+import pytest
+import otter_amd
+from otter_amd import abi
+import oracle_lib
+
+pytestmark = pytest.mark.skipif(oracle_lib.ref_io() is None, reason="oracle/_ref/libotter_ref_io.so not built")
+
+
+def _random_sam(path, rng, chroms, n_records, read_len=(20, 400)):
+    """Coordinate-sorted SAM with arbitrary (not biologically meaningful) CIGARs: every op the reference's walk
+    distinguishes (M I D N S H P = X), clips at either end, zero-length reads, tags HP/PS/rq in several integer widths."""
+    recs = []
+    for i in range(n_records):
+        ci = int(rng.integers(0, len(chroms)))
+        name, clen = chroms[ci]
+        pos = int(rng.integers(1, clen - 2000))
+        ops = []
+        if rng.random() < 0.3:
+            ops.append((int(rng.integers(1, 40)), "SH"[int(rng.integers(0, 2))]))
+        n_mid = int(rng.integers(1, 9))
+        for j in range(n_mid):
+            ops.append((int(rng.integers(1, 120)), "M=X"[int(rng.choice([0, 0, 0, 1, 2]))]))
+            if j + 1 < n_mid:
+                k = rng.random()
+                if k < 0.35:
+                    ops.append((int(rng.integers(1, 60)), "I"))
+                elif k < 0.7:
+                    ops.append((int(rng.integers(1, 300)), "D"))
+                elif k < 0.8:
+                    ops.append((int(rng.integers(1, 500)), "N"))
+                elif k < 0.85:
+                    ops.append((int(rng.integers(1, 5)), "P"))
+        if rng.random() < 0.3:
+            ops.append((int(rng.integers(1, 40)), "SH"[int(rng.integers(0, 2))]))
+        qlen = sum(l for l, o in ops if o in "MIS=X")
+        seq = "".join("ACGTN"[int(x)] for x in rng.choice(5, qlen, p=[0.24, 0.24, 0.24, 0.24, 0.04])) if qlen else "*"
+        cigar = "".join("%d%s" % (l, o) for l, o in ops)
+        tags = ""
+        t = int(rng.integers(0, 6))
+        if t == 1:
+            tags = "\tHP:i:%d\tPS:i:%d" % (int(rng.integers(0, 3)), int(rng.integers(0, 70000)))
+        elif t == 2:
+            tags = "\tPS:i:%d" % int(rng.integers(0, 200))
+        elif t == 3:
+            tags = "\trq:f:%.4f\tHP:i:1" % float(rng.random())
+        elif t == 4:
+            tags = "\tXZ:Z:foo\tXB:B:c,1,2,3\trq:f:0.5\tXA:A:q"
+        flag = int(rng.choice([0, 16, 256, 2048, 4, 1024]))
+        recs.append((ci, pos, "q%d" % i, flag, int(rng.integers(0, 61)), cigar, seq, tags))
+    recs.sort(key=lambda r: (r[0], r[1]))
+    with open(path, "w") as f:
+        f.write("@HD\tVN:1.4\tSO:coordinate\n")
+        for name, clen in chroms:
+            f.write("@SQ\tSN:%s\tLN:%d\n" % (name, clen))
+        for ci, pos, qn, flag, mq, cigar, seq, tags in recs:
+            f.write("%s\t%d\t%s\t%d\t%d\t%s\t*\t0\t0\t%s\t*%s\n" % (qn, flag, chroms[ci][0], pos, mq, cigar, seq, tags))
+    return len(recs)
+
+
+def _ref_ingest(bam, regions, **kw):
+    R = oracle_lib.ref_io()
+    R.ref_ingest_open.restype = C.c_void_p
+    R.ref_ingest_region.restype = C.c_int64
+    h = C.c_void_p(R.ref_ingest_open(bam.encode(), b""))
+    reads = np.zeros(1 << 21, dtype=abi.read_dt)
+    arena = np.zeros(256 << 20, dtype=np.uint8)
+    used = C.c_uint64(0)
+    regs = np.zeros(len(regions), dtype=abi.region_dt)
+    nr = 0
+    for r, (c, s, e) in enumerate(regions):
+        sub = reads[nr:]
+        k = R.ref_ingest_region(h, c.encode(), C.c_int(s), C.c_int(e), C.c_int(kw.get("offset_l", 0)), C.c_int(kw.get("offset_r", 0)),
+                                C.c_int(kw.get("mapq", 0)), C.c_int(int(kw.get("nonprimary", False))), C.c_double(kw.get("read_quality", 0.0)),
+                                C.c_int(int(kw.get("omit_nonspanning", False))), abi.ptr(sub), C.c_uint64(len(sub)), abi.ptr(arena), C.c_uint64(arena.size), C.byref(used))
+        assert k >= 0
+        regs[r]["first_read"] = nr; regs[r]["n_reads"] = k
+        nr += k
+    R.ref_ingest_close(h)
+    return {"arena": arena[:used.value], "reads": reads[:nr].copy(), "regions": regs}
+
+
+def _same(a, b):
+    assert np.array_equal(a["regions"]["n_reads"], b["regions"]["n_reads"]), (a["regions"]["n_reads"][:20], b["regions"]["n_reads"][:20])
+    assert np.array_equal(a["regions"]["first_read"], b["regions"]["first_read"])
+    for f in ("seq_len", "spanning_l", "spanning_r", "ps", "hp", "ccoord_first", "ccoord_second", "seq_off"):
+        assert np.array_equal(a["reads"][f], b["reads"][f]), f
+    n = int(b["reads"]["seq_len"].astype(np.int64).sum())
+    assert a["arena"][:n].tobytes() == b["arena"][:n].tobytes()
+
+
+@pytest.mark.parametrize("seed,n_records", [(71, 3000), (72, 40000)])
+def test_ingest_matches_reference_on_random_bam(tmp_path, seed, n_records):
+    rng = np.random.default_rng(seed)
+    chroms = [("chr1", 2_000_000), ("chr2_random:alt", 300_000), ("chrM", 17_000), ("chrBig", 400_000_000)]
+    sam, bam = str(tmp_path / "x.sam"), str(tmp_path / "x.bam")
+    n = _random_sam(sam, rng, chroms, n_records)
+    assert oracle_lib.ref_io().ref_sam_to_bam(sam.encode(), bam.encode()) == n
+    regions = []
+    for _ in range(300):
+        name, clen = chroms[int(rng.integers(0, len(chroms)))]
+        if name == "chrBig" and rng.random() < 0.5:
+            s = int(rng.integers(0, clen - 3000))
+        else:
+            s = int(rng.integers(0, min(clen, 2_000_000) - 3000))
+        regions.append((name, s, s + int(rng.integers(1, 2500))))
+    regions += [("chr1", 0, 10), ("chr1", 5, 5), ("chrM", 16_990, 17_050), ("nochr", 10, 20), ("chr1", 1_999_000, 2_100_000)]
+    bamh = otter_amd.Bam(bam)
+    assert bamh.targets() == chroms
+    for kw in (dict(), dict(offset_l=1, offset_r=1, mapq=10), dict(offset_l=30, offset_r=31, nonprimary=True, read_quality=0.4),
+               dict(omit_nonspanning=True, mapq=1), dict(offset_l=100000)):
+        ref = _ref_ingest(bam, regions, **kw)
+        _same(bamh.ingest(regions, **kw), ref)
+        _same(bamh.ingest(regions, threads=5, **kw), ref)          # region slices on host threads, merged in region order
+    bamh.close()
+
+
+def test_ingest_on_realistic_tr_bam(tmp_path):
+    """The end-to-end fixture (reads aligned over tandem repeats): same batch as the reference's ingest."""
+    import e2e_bam
+    ds = e2e_bam.make_dataset(str(tmp_path), n_regions=8, seed=64)
+    ref = e2e_bam.ingest_with_reference(ds, str(tmp_path), offset_l=1, offset_r=1, mapq=10)
+    got = otter_amd.Bam(os.path.join(str(tmp_path), "reads.bam")).ingest(ds["regions"], offset_l=1, offset_r=1, mapq=10)
+    _same(got, {"arena": ref["arena"], "reads": ref["reads"], "regions": ref["regions"]})
+
+
+def test_bam_open_errors(tmp_path):
+    with pytest.raises(otter_amd.OtterGpuError):
+        otter_amd.Bam(str(tmp_path / "missing.bam"))
+    p = tmp_path / "junk.bam"
+    p.write_bytes(b"not a bam")
+    with pytest.raises(otter_amd.OtterGpuError):
+        otter_amd.Bam(str(p))
