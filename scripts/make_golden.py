@@ -75,3 +75,32 @@ gold = {k: O.emit_alleles(beds, carena, res, rg, fa, which="ref").decode() for k
 gold["header"] = O.emit_sam_header(TARGETS, "sampleA", 30, 31).decode()
 json.dump(gold, open(os.path.join(out, "emit_ref.json"), "w"))
 print("emit_ref.json", {k: len(v) for k, v in gold.items()})
+
+
+# G6: BAM ingest — a small BAM/BAI written by the reference's htslib-lite from synthetic SAM text, and what the reference's own
+# parse_anreads (oracle/_ref/libotter_ref_io.so) returns for a fixed region list under three option sets
+import shutil, tempfile  # noqa: E402
+import test_ingest as TI  # noqa: E402
+rng = np.random.default_rng(20241009)
+tmp = tempfile.mkdtemp()
+chroms = [("chr1", 300_000), ("chr2_random:alt", 80_000), ("chrBig", 400_000_000)]
+sam, bam = os.path.join(tmp, "g.sam"), os.path.join(tmp, "g.bam")
+n = TI._random_sam(sam, rng, chroms, 900, read_len=(20, 150))
+assert O.ref_io().ref_sam_to_bam(sam.encode(), bam.encode()) == n
+shutil.copy(bam, os.path.join(out, "ingest_small.bam"))
+shutil.copy(bam + ".bai", os.path.join(out, "ingest_small.bam.bai"))
+regions = []
+for _ in range(120):
+    name, clen = chroms[int(rng.integers(0, len(chroms)))]
+    s0 = int(rng.integers(0, min(clen, 300_000) - 3000)) if name != "chrBig" or rng.random() < 0.5 else int(rng.integers(0, clen - 3000))
+    regions.append((name, s0, s0 + int(rng.integers(1, 2500))))
+regions += [("chr1", 0, 10), ("chr1", 5, 5), ("nochr", 10, 20), ("chr1", 299_000, 310_000)]
+rec = {"regions_chr": np.array([r[0] for r in regions]), "regions_start": np.array([r[1] for r in regions], dtype=np.int64),
+       "regions_end": np.array([r[2] for r in regions], dtype=np.int64)}
+OPTS = [dict(), dict(offset_l=1, offset_r=1, mapq=10), dict(offset_l=50000, offset_r=7, nonprimary=True), dict(omit_nonspanning=True, mapq=3),
+             dict(read_quality=0.4, nonprimary=True)]
+for i, kw in enumerate(OPTS):
+    b = TI._ref_ingest(bam, regions, **kw)
+    rec["reads%d" % i] = b["reads"]; rec["arena%d" % i] = np.ascontiguousarray(b["arena"]); rec["n_reads%d" % i] = b["regions"]["n_reads"]
+np.savez_compressed(os.path.join(out, "ingest_ref.npz"), **rec)
+print("ingest_small.bam", os.path.getsize(os.path.join(out, "ingest_small.bam")), "bytes;", {k: len(v) for k, v in rec.items() if k.startswith("reads")})

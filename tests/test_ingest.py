@@ -10,7 +10,31 @@ import otter_amd
 from otter_amd import abi
 import oracle_lib
 
-pytestmark = pytest.mark.skipif(oracle_lib.ref_io() is None, reason="oracle/_ref/libotter_ref_io.so not built")
+needs_ref = pytest.mark.skipif(oracle_lib.ref_io() is None, reason="oracle/_ref/libotter_ref_io.so not built")
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+GOLD_OPTS = [dict(), dict(offset_l=1, offset_r=1, mapq=10), dict(offset_l=50000, offset_r=7, nonprimary=True), dict(omit_nonspanning=True, mapq=3),
+             dict(read_quality=0.4, nonprimary=True)]
+
+
+def test_ingest_against_committed_golden():
+    """Runs everywhere: tests/golden/ingest_small.bam(.bai) was written by the reference's htslib-lite and
+    tests/golden/ingest_ref.npz holds what the reference's parse_anreads returned for it (scripts/make_golden.py)."""
+    g = np.load(os.path.join(GOLD, "ingest_ref.npz"))
+    regions = [(str(c), int(s), int(e)) for c, s, e in zip(g["regions_chr"], g["regions_start"], g["regions_end"])]
+    bam = otter_amd.Bam(os.path.join(GOLD, "ingest_small.bam"))
+    assert [t[0] for t in bam.targets()] == ["chr1", "chr2_random:alt", "chrBig"]
+    for i, kw in enumerate(GOLD_OPTS):
+        for threads in (1, 3):
+            got = bam.ingest(regions, threads=threads, **kw)
+            exp = g["reads%d" % i]
+            assert np.array_equal(got["regions"]["n_reads"], g["n_reads%d" % i])
+            assert len(got["reads"]) == len(exp)
+            for f in ("seq_off", "seq_len", "spanning_l", "spanning_r", "ps", "hp", "ccoord_first", "ccoord_second"):
+                assert np.array_equal(got["reads"][f], exp[f]), (i, f)
+            n = int(exp["seq_len"].astype(np.int64).sum())
+            assert got["arena"][:n].tobytes() == g["arena%d" % i][:n].tobytes()
+    bam.close()
+
 
 
 def _random_sam(path, rng, chroms, n_records, read_len=(20, 400)):
@@ -95,6 +119,7 @@ def _same(a, b):
     assert a["arena"][:n].tobytes() == b["arena"][:n].tobytes()
 
 
+@needs_ref
 @pytest.mark.parametrize("seed,n_records", [(71, 3000), (72, 40000)])
 def test_ingest_matches_reference_on_random_bam(tmp_path, seed, n_records):
     rng = np.random.default_rng(seed)
@@ -121,6 +146,7 @@ def test_ingest_matches_reference_on_random_bam(tmp_path, seed, n_records):
     bamh.close()
 
 
+@needs_ref
 def test_ingest_on_realistic_tr_bam(tmp_path):
     """The end-to-end fixture (reads aligned over tandem repeats): same batch as the reference's ingest."""
     import e2e_bam
