@@ -265,6 +265,55 @@ int  otg_ingest_regions(otg_bam* bam, const otg_bed* beds, const char* chr_arena
                         const otg_ingest_opts* opts, uint8_t* arena, uint64_t arena_capacity, uint64_t* arena_used,
                         otg_read* reads, uint32_t reads_capacity, uint32_t* n_reads, otg_region* regions);
 
+/* The same, also returning what `--reads-only` prints per read: ANREAD::name and ANREAD::rq (src/anseqs.cpp:447,250-251).
+ * meta[i] belongs to reads[i]; names are appended to name_arena (in-out counter *name_used, no terminators).  meta == NULL:
+ * exactly otg_ingest_regions. */
+typedef struct otg_read_meta {
+  uint64_t name_off;         /* into name_arena                                   */
+  uint32_t name_len;
+  uint32_t reserved;
+  double   rq;               /* tag rq, 0 when absent                             */
+} otg_read_meta;
+int  otg_ingest_regions_named(otg_bam* bam, const otg_bed* beds, const char* chr_arena, uint32_t n_regions,
+                              const otg_ingest_opts* opts, uint8_t* arena, uint64_t arena_capacity, uint64_t* arena_used,
+                              otg_read* reads, uint32_t reads_capacity, uint32_t* n_reads, otg_region* regions,
+                              otg_read_meta* meta, char* name_arena, uint64_t name_capacity, uint64_t* name_used);
+/* `otter assemble --reads-only`: the read records of each region instead of alleles (src/assemble.cpp:82-89 ->
+ * ANREAD::stdout_sam / stdout_fa, src/anseqs.cpp:83-106).  Regions with more than max_cov reads print nothing
+ * (src/assemble.cpp:69; max_cov < 0: no limit).  Same buffer protocol as otg_emit_alleles. */
+int  otg_emit_reads(const otg_bed* beds, const char* chr_arena, uint32_t n_regions, const otg_region* regions,
+                    const otg_read* reads, const uint8_t* seq_arena, const otg_read_meta* meta, const char* name_arena,
+                    const char* read_group, int is_fasta, int32_t max_cov, char* out, uint64_t out_capacity, uint64_t* out_len);
+
+/* ---------------------------------------------------------------------------------------------
+ * The two text inputs beside the BAM: the BED file of regions and the indexed FASTA the reference
+ * flanks of local_realignment come from.  Host code.
+ * ------------------------------------------------------------------------------------------- */
+/* parse_bed_file (src/anbed.cpp:23-80): tab-separated `chr start end [...]` or single-column `chr:start-end` lines;
+ * '#' lines, empty lines and lines the reference calls ambiguous are skipped (*n_skipped counts the latter two kinds,
+ * nullable); coordinates go through the same unsigned-32-bit conversion.  A coordinate that is not a number makes the
+ * reference terminate: OTG_ERR_ARG here.  OTG_ERR_CAPACITY: *n_beds / *chr_used hold the needed sizes. */
+int  otg_parse_bed_file(const char* path, otg_bed* beds, uint32_t beds_capacity, uint32_t* n_beds, char* chr_arena,
+                        uint64_t chr_capacity, uint64_t* chr_used, uint32_t* n_skipped);
+/* FaidxInstance (src/anfahelper.cpp:6-20) over an uncompressed FASTA with its `.fai` (read when present, otherwise built
+ * as src/faidx.c:64-133 does and written beside the file when possible).  Handles are read-only after open: one may be
+ * shared by threads. */
+typedef struct otg_fasta otg_fasta;
+int  otg_fasta_open(const char* fasta_path, otg_fasta** out);
+void otg_fasta_close(otg_fasta* fa);
+uint32_t otg_fasta_n_seqs(const otg_fasta* fa);
+const char* otg_fasta_seq(const otg_fasta* fa, uint32_t i, int64_t* length);
+/* FaidxInstance::fetch: bases [beg, end_inclusive] (0-based), clamped into the contig as faidx_fetch_seq clamps them
+ * (src/faidx.c:418-445), upper-cased; an unknown contig gives length 0. */
+int  otg_fasta_fetch(const otg_fasta* fa, const char* chr, uint32_t chr_len, int32_t beg, int32_t end_inclusive,
+                     char* out, uint64_t out_capacity, uint64_t* out_len);
+/* The two flanks of every region, [start - offset_l - flank, start - offset_l] and [end + offset_r, end + offset_r + flank]
+ * (src/analignments.cpp:22,28 on mod_bed, src/assemble.cpp:55-57), appended to the region batch's arena (in-out counter
+ * *arena_used); fills regions[i].flank_{l,r}_{off,len} and leaves the read fields alone. */
+int  otg_fasta_region_flanks(const otg_fasta* fa, const otg_bed* beds, const char* chr_arena, uint32_t n_regions,
+                             int32_t offset_l, int32_t offset_r, int32_t flank, uint8_t* arena, uint64_t arena_capacity,
+                             uint64_t* arena_used, otg_region* regions);
+
 /* Workload statistics of the last otg_assemble_run (for the roofline figure). */
 typedef struct otg_run_stats {
   uint64_t n_regions, n_regions_ok;

@@ -1459,7 +1459,7 @@ uint64_t oto_emit_alleles(const otg_bed* beds, const char* chr_arena, uint32_t n
   const std::string rg = read_group ? read_group : "";
   for (uint32_t r = 0; r < n_regions; ++r) {
     const std::string chr(chr_arena + beds[r].chr_off, beds[r].chr_len);
-    const std::string sc = chr + ":" + std::to_string(beds[r].start) + "-" + std::to_string(beds[r].end);      /* toScString */
+    const std::string sc = chr + ":" + std::to_string((uint32_t)beds[r].start) + "-" + std::to_string((uint32_t)beds[r].end);      /* toScString */
     for (uint32_t l = 0; l < regions[r].n_alleles; ++l) {
       const otg_allele& A = alleles[regions[r].first_allele + l];
       const std::string seq((const char*)seqs + A.seq_off, A.seq_len);

@@ -125,4 +125,50 @@ int ref_fetch(void* hnd, const char* chr, int beg, int end_incl, char* out, int 
   return (int)s.size();
 }
 
+// `otter assemble --reads-only` for one region: parse_anreads on the widened region, then ANREAD::stdout_fa / stdout_sam with the
+// un-widened BED (src/assemble.cpp:55-65,82-89; regions above max_cov print nothing, :69).  Returns the text length.
+uint64_t ref_reads_only(void* hnd, const char* chr, int start, int end, int offset_l, int offset_r, int mapq, int nonprimary,
+                        double read_quality, int omitnonspanning, int max_cov, const char* read_group, int is_fasta, char* out, uint64_t cap)
+{
+  RefIngest* r = (RefIngest*)hnd;
+  OtterOpts params{};
+  params.mapq = mapq; params.nonprimary = nonprimary != 0; params.read_quality = read_quality; params.omitnonspanning = omitnonspanning != 0;
+  BED local_bed;
+  local_bed.chr = chr; local_bed.start = start; local_bed.end = end;
+  BED mod_bed = local_bed;
+  mod_bed.start -= offset_l; mod_bed.end += offset_r;
+  std::vector<ANREAD> block;
+  parse_anreads(params, mod_bed, r->bam, block);
+  std::ostringstream os;
+  std::streambuf* old = std::cout.rdbuf(os.rdbuf());
+  const std::string rg = read_group ? read_group : "";
+  if (!((int)block.size() > max_cov)) {
+    for (const auto& read : block) {
+      if (is_fasta) read.stdout_fa(local_bed.toScString());
+      else read.stdout_sam(local_bed.chr, local_bed.start, local_bed.end, rg);
+    }
+  }
+  std::cout.rdbuf(old);
+  const std::string t = os.str();
+  if (out && cap) memcpy(out, t.data(), t.size() < cap ? t.size() : cap);
+  return t.size();
+}
+
+// parse_bed_file (src/anbed.cpp:65-80) -> "chr\tstart\tend\n" per accepted region (BED::toString), stderr chatter dropped.
+// Returns the text length, or -1 when the reference's parser threw (std::stoul on a non-number).
+int64_t ref_parse_bed_file(const char* path, char* out, uint64_t cap)
+{
+  std::vector<BED> v;
+  std::ostringstream sink;
+  std::streambuf* old = std::cerr.rdbuf(sink.rdbuf());
+  bool threw = false;
+  try { parse_bed_file(path, v); } catch (...) { threw = true; }
+  std::cerr.rdbuf(old);
+  if (threw) return -1;
+  std::string t;
+  for (const BED& b : v) t += b.toString() + "\n";
+  if (out && cap) memcpy(out, t.data(), t.size() < cap ? t.size() : cap);
+  return (int64_t)t.size();
+}
+
 } // extern "C"

@@ -16,6 +16,8 @@ EXPORTS = [
     "otg_assemble_collect", "otg_assemble_device_results", "otg_assemble_stats",
     "otg_emit_alleles", "otg_emit_sam_header",
     "otg_bam_open", "otg_bam_close", "otg_bam_n_targets", "otg_bam_target", "otg_ingest_regions",
+    "otg_ingest_regions_named", "otg_emit_reads", "otg_parse_bed_file", "otg_fasta_open", "otg_fasta_close", "otg_fasta_n_seqs",
+    "otg_fasta_seq", "otg_fasta_fetch", "otg_fasta_region_flanks",
 ]
 
 _lib = None
@@ -287,10 +289,12 @@ class Bam:
             out.append((nm.decode(), int(ln.value)))
         return out
 
-    def ingest(self, regions, offset_l=0, offset_r=0, mapq=0, nonprimary=False, omit_nonspanning=False, read_quality=0.0, threads=1):
-        """regions: list of (chr, start, end) -> batch dict {"arena", "reads", "regions"} for Context.assemble_submit
-        (reference flanks, needed only with -r, are the caller's to append)."""
-        beds, carena = abi.make_beds(regions)
+    def ingest(self, regions, offset_l=0, offset_r=0, mapq=0, nonprimary=False, omit_nonspanning=False, read_quality=0.0, threads=1,
+               names=False):
+        """regions: list of (chr, start, end), or the (beds, chr_arena) pair of parse_bed_file -> batch dict {"arena", "reads",
+        "regions"} for Context.assemble_submit (reference flanks, needed only with -r: Fasta.region_flanks appends them).
+        names=True adds "meta" / "names" (read name and rq per read, what --reads-only prints)."""
+        beds, carena = regions if isinstance(regions, tuple) else abi.make_beds(regions)
         opts = np.zeros(1, dtype=abi.ingest_opts_dt)
         opts[0]["offset_l"] = offset_l; opts[0]["offset_r"] = offset_r; opts[0]["mapq"] = mapq
         opts[0]["nonprimary"] = int(nonprimary); opts[0]["omit_nonspanning"] = int(omit_nonspanning); opts[0]["read_quality"] = read_quality; opts[0]["threads"] = threads
@@ -298,17 +302,134 @@ class Bam:
         # generous first guess from the file size (untouched pages cost nothing), exact retry if it was too small
         fsz = os.path.getsize(self._path)
         cap_r, cap_a = max(1024, fsz // 64), max(1 << 20, 8 * fsz)
+        cap_n = max(4096, fsz // 16) if names else 0
         while True:
             reads = np.empty(cap_r, dtype=abi.read_dt)
             arena = np.empty(cap_a, dtype=np.uint8)
-            used, nr = C.c_uint64(0), C.c_uint32(0)
-            rc = self._L.otg_ingest_regions(self._h, abi.ptr(beds), abi.ptr(carena, C.c_char_p), C.c_uint32(len(beds)), abi.ptr(opts),
-                                            abi.ptr(arena), C.c_uint64(cap_a), C.byref(used), abi.ptr(reads), C.c_uint32(cap_r), C.byref(nr),
-                                            abi.ptr(regs))
+            meta = np.empty(cap_r, dtype=abi.read_meta_dt) if names else None
+            narena = np.empty(cap_n, dtype=np.uint8) if names else None
+            used, nr, nused = C.c_uint64(0), C.c_uint32(0), C.c_uint64(0)
+            rc = self._L.otg_ingest_regions_named(self._h, abi.ptr(beds), abi.ptr(carena, C.c_char_p), C.c_uint32(len(beds)), abi.ptr(opts),
+                                                  abi.ptr(arena), C.c_uint64(cap_a), C.byref(used), abi.ptr(reads), C.c_uint32(cap_r), C.byref(nr),
+                                                  abi.ptr(regs), abi.ptr(meta) if names else None, abi.ptr(narena, C.c_char_p) if names else None,
+                                                  C.c_uint64(cap_n), C.byref(nused) if names else None)
             if rc == abi.OTG_ERR_CAPACITY:
                 cap_r, cap_a = max(cap_r, nr.value + 16), max(cap_a, used.value + 64 * (nr.value + 2) + 4096)
+                cap_n = max(cap_n, nused.value + 64) if names else 0
                 continue
             if rc != 0:
                 raise OtterGpuError("otg_ingest_regions failed (%d): %s" % (rc, (self._L.otg_last_error(None) or b"").decode()))
             arena[used.value:used.value + 64] = 0
+            if names:
+                return {"arena": np.ascontiguousarray(arena[:used.value + 64]), "reads": np.ascontiguousarray(reads[:nr.value]), "regions": regs,
+                        "meta": np.ascontiguousarray(meta[:nr.value]), "names": np.ascontiguousarray(narena[:nused.value])}
             return {"arena": np.ascontiguousarray(arena[:used.value + 64]), "reads": np.ascontiguousarray(reads[:nr.value]), "regions": regs}
+
+
+def _err(L):
+    return (L.otg_last_error(None) or b"").decode()
+
+
+def parse_bed_file(path):
+    """parse_bed_file (src/anbed.cpp:65-80) through the library -> (beds, chr_arena, n_skipped); beds is an abi.bed_dt array."""
+    L = load()
+    cap_b, cap_c = 1024, 1 << 14
+    while True:
+        beds = np.zeros(cap_b, dtype=abi.bed_dt)
+        carena = np.zeros(cap_c, dtype=np.uint8)
+        n, used, skipped = C.c_uint32(0), C.c_uint64(0), C.c_uint32(0)
+        rc = L.otg_parse_bed_file(C.c_char_p(path.encode()), abi.ptr(beds), C.c_uint32(cap_b), C.byref(n), abi.ptr(carena, C.c_char_p),
+                                  C.c_uint64(cap_c), C.byref(used), C.byref(skipped))
+        if rc == abi.OTG_ERR_CAPACITY:
+            cap_b, cap_c = max(cap_b, n.value), max(cap_c, used.value)
+            continue
+        if rc != 0:
+            raise OtterGpuError("otg_parse_bed_file failed (%d): %s" % (rc, _err(L)))
+        return np.ascontiguousarray(beds[:n.value]), np.ascontiguousarray(carena[:max(1, used.value)]), int(skipped.value)
+
+
+def bed_tuples(beds, chr_arena):
+    """(chr, start, end) per region with the coordinates as BED::toString prints them (unsigned 32-bit, src/anbed.hpp:16-17)."""
+    raw = chr_arena.tobytes()
+    return [(raw[int(b["chr_off"]):int(b["chr_off"]) + int(b["chr_len"])].decode("latin-1"), int(b["start"]) & 0xffffffff, int(b["end"]) & 0xffffffff)
+            for b in beds]
+
+
+def emit_reads(beds, chr_arena, batch, read_group="", fasta=False, max_cov=-1):
+    """The --reads-only records of an ingested batch (Bam.ingest(..., names=True)) as bytes (otg_emit_reads)."""
+    L = load()
+    meta, names = batch.get("meta"), batch.get("names")
+    cap = int(batch["reads"]["seq_len"].sum()) * 2 + 512 * (len(batch["reads"]) + 1)
+    while True:
+        out = np.empty(cap, dtype=np.uint8)
+        n = C.c_uint64(0)
+        rc = L.otg_emit_reads(abi.ptr(beds), abi.ptr(chr_arena, C.c_char_p), C.c_uint32(len(beds)), abi.ptr(batch["regions"]),
+                              abi.ptr(batch["reads"]), abi.ptr(batch["arena"]), abi.ptr(meta) if meta is not None else None,
+                              abi.ptr(names, C.c_char_p) if names is not None else None, C.c_char_p(read_group.encode()),
+                              C.c_int(int(fasta)), C.c_int32(max_cov), abi.ptr(out, C.c_char_p), C.c_uint64(cap), C.byref(n))
+        if rc == abi.OTG_ERR_CAPACITY:
+            cap = n.value
+            continue
+        if rc != 0:
+            raise OtterGpuError("otg_emit_reads failed (%d): %s" % (rc, _err(L)))
+        return out[:n.value].tobytes()
+
+
+class Fasta:
+    """An indexed, uncompressed FASTA (otg_fasta_open) — the source of the reference flanks of local_realignment (-r)."""
+
+    def __init__(self, path):
+        L = load()
+        h = C.c_void_p()
+        rc = L.otg_fasta_open(C.c_char_p(path.encode()), C.byref(h))
+        if rc != 0:
+            raise OtterGpuError("otg_fasta_open failed (%d): %s" % (rc, _err(L)))
+        self._h, self._L = h, L
+        L.otg_fasta_seq.restype = C.c_char_p
+        L.otg_fasta_n_seqs.restype = C.c_uint32
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.otg_fasta_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def seqs(self):
+        out = []
+        for i in range(self._L.otg_fasta_n_seqs(self._h)):
+            ln = C.c_int64(0)
+            nm = self._L.otg_fasta_seq(self._h, C.c_uint32(i), C.byref(ln))
+            out.append((nm.decode(), int(ln.value)))
+        return out
+
+    def fetch(self, chr_, beg, end_inclusive):
+        c = chr_.encode()
+        cap = max(16, abs(int(end_inclusive) - int(beg)) + 2)
+        out = C.create_string_buffer(cap)
+        n = C.c_uint64(0)
+        rc = self._L.otg_fasta_fetch(self._h, C.c_char_p(c), C.c_uint32(len(c)), C.c_int32(beg), C.c_int32(end_inclusive), out,
+                                     C.c_uint64(cap), C.byref(n))
+        if rc != 0:
+            raise OtterGpuError("otg_fasta_fetch failed (%d): %s" % (rc, _err(self._L)))
+        return out.raw[:n.value]
+
+    def region_flanks(self, beds, chr_arena, batch, flank=100, offset_l=0, offset_r=0):
+        """Appends the two flanks of every region to batch["arena"] and fills the flank fields of batch["regions"] (in place)."""
+        arena = batch["arena"]
+        base = len(arena)
+        cap = base + 2 * (int(flank) + 1) * len(beds) + 128
+        big = np.zeros(cap, dtype=np.uint8)
+        big[:base] = arena
+        used = C.c_uint64(base)
+        rc = self._L.otg_fasta_region_flanks(self._h, abi.ptr(beds), abi.ptr(chr_arena, C.c_char_p), C.c_uint32(len(beds)), C.c_int32(offset_l),
+                                             C.c_int32(offset_r), C.c_int32(flank), abi.ptr(big), C.c_uint64(cap), C.byref(used),
+                                             abi.ptr(batch["regions"]))
+        if rc != 0:
+            raise OtterGpuError("otg_fasta_region_flanks failed (%d): %s" % (rc, _err(self._L)))
+        batch["arena"] = np.ascontiguousarray(big[:used.value + 64])
+        return batch

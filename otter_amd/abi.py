@@ -86,6 +86,8 @@ assert allele_dt.itemsize == 48
 
 bed_dt = np.dtype([("chr_off", "<u8"), ("chr_len", "<u4"), ("start", "<i4"), ("end", "<i4"), ("reserved", "<u4")], align=True)
 assert bed_dt.itemsize == 24
+read_meta_dt = np.dtype([("name_off", "<u8"), ("name_len", "<u4"), ("reserved", "<u4"), ("rq", "<f8")], align=True)
+assert read_meta_dt.itemsize == 24
 
 
 ingest_opts_dt = np.dtype([("offset_l", "<i4"), ("offset_r", "<i4"), ("mapq", "<i4"), ("nonprimary", "<i4"), ("omit_nonspanning", "<i4"),
@@ -99,7 +101,7 @@ def make_beds(regions):
     arena = bytearray()
     for i, (c, st, en) in enumerate(regions):
         cb = c.encode() if isinstance(c, str) else bytes(c)
-        beds[i]["chr_off"] = len(arena); beds[i]["chr_len"] = len(cb); beds[i]["start"] = st; beds[i]["end"] = en
+        beds[i]["chr_off"] = len(arena); beds[i]["chr_len"] = len(cb); beds[i]["start"] = np.uint32(st & 0xffffffff).astype(np.int32); beds[i]["end"] = np.uint32(en & 0xffffffff).astype(np.int32)
         arena += cb
     return beds, np.frombuffer(bytes(arena) + b"\0", dtype=np.uint8).copy()
 assert region_result_dt.itemsize == 24

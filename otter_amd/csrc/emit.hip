@@ -1,5 +1,7 @@
 // emit.hip — record emit of `otter assemble`: SAM / FASTA lines of the allele records and the SAM
-// header, byte-identical to the reference (src/assemble.cpp:143-149,167-177; ANALLELE::stdout_sam / stdout_fa
+// header, byte-identical to the reference (BED coordinates are unsigned 32-bit there, src/anbed.hpp:16-17: the region name built by
+// toScString prints them unsigned, the POS column and the ta tag take them as int — same bits, two spellings above 2^31)
+// — (src/assemble.cpp:143-149,167-177; ANALLELE::stdout_sam / stdout_fa
 // src/anseqs.cpp:42-63; BED::toScString src/anbed.cpp:17-20).  Host-side formatting only; lives in the library so
 // that a caller of the C-ABI gets the wire format the parity diff is taken on without re-implementing it.
 #include "otg_common.hpp"
@@ -15,6 +17,7 @@ struct Sink {
   void i64(long long v) { char b[32]; const int n = snprintf(b, sizeof b, "%lld", v); put(b, (size_t)n); }
   void u64(unsigned long long v) { char b[32]; const int n = snprintf(b, sizeof b, "%llu", v); put(b, (size_t)n); }
   // `std::cout << float`: default float field, precision 6 == printf %g of the value widened to double
+  void dbl(double v) { char b[48]; const int n = snprintf(b, sizeof b, "%g", v); put(b, (size_t)n); }
   void flt(float v) { char b[48]; const int n = snprintf(b, sizeof b, "%g", (double)v); put(b, (size_t)n); }
   void fill(char c, size_t n) { if (len + n <= cap && out) memset(out + len, c, n); len += n; }
 };
@@ -38,14 +41,14 @@ int otg_emit_alleles(const otg_bed* beds, const char* chr_arena, uint32_t n_regi
       const char* seq = (const char*)seqs + A.seq_off;
       if (is_fasta) {
         // stdout_fa(name = read group, region = toScString() + '#' + l)  (src/assemble.cpp:146, src/anseqs.cpp:56-63)
-        s.ch('>'); s.put(rg); s.ch('#'); s.put(chr, b.chr_len); s.ch(':'); s.i64(b.start); s.ch('-'); s.i64(b.end); s.ch('#'); s.i64(a);
+        s.ch('>'); s.put(rg); s.ch('#'); s.put(chr, b.chr_len); s.ch(':'); s.u64((uint32_t)b.start); s.ch('-'); s.u64((uint32_t)b.end); s.ch('#'); s.i64(a);
         s.put("#tc:i:"); s.i64(A.tcov); s.put("#ac:i:"); s.i64(A.acov); s.put("#sc:i:"); s.i64(A.scov);
         if (A.ps >= 0) { s.put("#PS:i:"); s.i64(A.ps); }
         if (A.hp >= 0) { s.put("#HP:i:"); s.i64(A.hp); }
         s.ch('\n'); s.put(seq, A.seq_len); s.ch('\n');
       } else {
         // stdout_sam(name = toScString() + "_" + l, chr, start, end, rg)  (src/assemble.cpp:147, src/anseqs.cpp:42-54)
-        s.put(chr, b.chr_len); s.ch(':'); s.i64(b.start); s.ch('-'); s.i64(b.end); s.ch('_'); s.i64(a);
+        s.put(chr, b.chr_len); s.ch(':'); s.u64((uint32_t)b.start); s.ch('-'); s.u64((uint32_t)b.end); s.ch('_'); s.i64(a);
         s.put("\t0\t"); s.put(chr, b.chr_len); s.ch('\t'); s.i64(b.start); s.put("\t0\t"); s.u64(A.seq_len); s.put("M\t*\t0\t0\t");
         s.put(seq, A.seq_len); s.ch('\t'); s.fill('!', A.seq_len);
         if (rg[0]) { s.put("\tRG:Z:"); s.put(rg); }
@@ -54,6 +57,50 @@ int otg_emit_alleles(const otg_bed* beds, const char* chr_arena, uint32_t n_regi
         s.put("\tic:i:"); s.i64(A.ic); s.put("\tse:f:"); s.flt(A.se);
         if (A.ps >= 0) { s.put("\tPS:i:"); s.i64(A.ps); }
         if (A.hp >= 0) { s.put("\tHP:i:"); s.i64(A.hp); }
+        s.ch('\n');
+      }
+    }
+  }
+  *out_len = s.len;
+  if (s.len > out_capacity || (!out && s.len)) return OTG_ERR_CAPACITY;
+  return OTG_OK;
+}
+
+// `otter assemble --reads-only`: the reads of each region as they entered the hot path (src/assemble.cpp:82-89 ->
+// ANREAD::stdout_sam / stdout_fa, src/anseqs.cpp:83-106)
+int otg_emit_reads(const otg_bed* beds, const char* chr_arena, uint32_t n_regions, const otg_region* regions, const otg_read* reads,
+                   const uint8_t* seq_arena, const otg_read_meta* meta, const char* name_arena, const char* read_group, int is_fasta,
+                   int32_t max_cov, char* out, uint64_t out_capacity, uint64_t* out_len)
+{
+  if ((n_regions && (!beds || !regions)) || !out_len) return otg_fail(nullptr, OTG_ERR_ARG, "otg_emit_reads: null argument");
+  const char* rg = read_group ? read_group : "";
+  Sink s{out, out_capacity, 0};
+  for (uint32_t r = 0; r < n_regions; ++r) {
+    const otg_bed& b = beds[r];
+    const char* chr = chr_arena + b.chr_off;
+    if (max_cov >= 0 && regions[r].n_reads > (uint32_t)max_cov) continue;     // "abnormal coverage" regions print nothing (:69)
+    for (uint32_t k = 0; k < regions[r].n_reads; ++k) {
+      const uint32_t i = regions[r].first_read + k;
+      const otg_read& R = reads[i];
+      const char* seq = (const char*)seq_arena + R.seq_off;
+      const char sp = R.spanning_l && R.spanning_r ? 'b' : R.spanning_l ? 'l' : R.spanning_r ? 'r' : 'n';
+      if (is_fasta) {
+        s.ch('>'); if (meta) s.put(name_arena + meta[i].name_off, meta[i].name_len);
+        s.ch('#'); s.put(chr, b.chr_len); s.ch(':'); s.u64((uint32_t)b.start); s.ch('-'); s.u64((uint32_t)b.end);
+        s.put("#sp:A:"); s.ch(sp);
+        if (R.ps >= 0) { s.put("#PS:i:"); s.i64(R.ps); }
+        if (R.hp >= 0) { s.put("#HP:i:"); s.i64(R.hp); }
+        s.ch('\n'); s.put(seq, R.seq_len); s.ch('\n');
+      } else {
+        if (meta) s.put(name_arena + meta[i].name_off, meta[i].name_len);
+        s.put("\t0\t"); s.put(chr, b.chr_len); s.ch('\t'); s.i64(b.start); s.put("\t0\t"); s.u64(R.seq_len); s.put("M\t*\t0\t0\t");
+        s.put(seq, R.seq_len); s.ch('\t'); s.fill('!', R.seq_len);
+        if (rg[0]) { s.put("\tRG:Z:"); s.put(rg); }
+        s.put("\tta:Z:"); s.put(chr, b.chr_len); s.ch(':'); s.i64(b.start); s.ch('-'); s.i64(b.end);
+        s.put("\tsp:A:"); s.ch(sp);
+        if (R.ps >= 0) { s.put("\tPS:i:"); s.i64(R.ps); }
+        if (R.hp >= 0) { s.put("\tHP:i:"); s.i64(R.hp); }
+        s.put("\trq:f:"); s.dbl(meta ? meta[i].rq : 0.0);
         s.ch('\n');
       }
     }

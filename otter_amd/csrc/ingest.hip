@@ -171,6 +171,8 @@ struct Rec {
   const uint8_t* seq;
   const uint8_t* aux;
   const uint8_t* aux_end;
+  const char* name;            // NUL-terminated query name inside the record
+  uint32_t l_name;             // its length without the terminator
 };
 
 inline int cig_op(const uint8_t* c, uint32_t i) { return (int)(rd32(c + 4 * i) & 0xf); }
@@ -194,6 +196,8 @@ int read_record(otg_bam* b, Rec* r)
   const size_t need = 32 + (size_t)l_name + 4 * (size_t)r->n_cigar + ((size_t)r->l_seq + 1) / 2 + (size_t)r->l_seq;
   if (r->l_seq < 0 || need > (size_t)block_len) return -1;
   const uint8_t* q = p + 32 + l_name;
+  r->name = (const char*)p + 32;
+  r->l_name = l_name ? (uint32_t)strnlen((const char*)p + 32, l_name) : 0;
   r->cigar = (const uint32_t*)q;
   r->seq = q + 4 * (size_t)r->n_cigar;
   r->aux = r->seq + ((size_t)r->l_seq + 1) / 2 + (size_t)r->l_seq;
@@ -367,7 +371,8 @@ const char* otg_bam_target(const otg_bam* b, uint32_t i, uint64_t* length)
 
 // one contiguous slice of regions on its own file handle: reads + bytes into private vectors, regions[].first_read relative
 static int ingest_slice(const otg_bam* b, const char* path, const otg_bed* beds, const char* chr_arena, uint32_t g0, uint32_t g1,
-                        const otg_ingest_opts* opts, std::vector<otg_read>& reads, std::vector<uint8_t>& arena, otg_region* regions, std::string& err)
+                        const otg_ingest_opts* opts, std::vector<otg_read>& reads, std::vector<uint8_t>& arena, otg_region* regions, std::string& err,
+                        std::vector<otg_read_meta>* meta, std::string* names)
 {
   static const char nt16[] = "=ACMGRSVTWYHKDBN";
   otg_bam local;                               // private BGZF reader + record buffer; the index is read through `b`
@@ -443,6 +448,13 @@ static int ingest_slice(const otg_bam* b, const char* path, const otg_bed* beds,
         o.ps = ps; o.hp = hp; o.ccoord_first = msg.c_first; o.ccoord_second = msg.c_second;
         arena.insert(arena.end(), seq.begin(), seq.end());
         reads.push_back(o);
+        if (meta) {                                                              // ANREAD::name / ANREAD::rq for the reads-only records
+          otg_read_meta mm;
+          memset(&mm, 0, sizeof(mm));
+          mm.name_off = names->size(); mm.name_len = r.l_name; mm.rq = rq;
+          names->append(r.name, r.l_name);
+          meta->push_back(mm);
+        }
       }
     }
     regions[g].n_reads = (uint32_t)reads.size() - first;
@@ -451,22 +463,28 @@ static int ingest_slice(const otg_bam* b, const char* path, const otg_bed* beds,
   return rc_out;
 }
 
-int otg_ingest_regions(otg_bam* b, const otg_bed* beds, const char* chr_arena, uint32_t n_regions, const otg_ingest_opts* opts,
-                       uint8_t* arena, uint64_t arena_capacity, uint64_t* arena_used, otg_read* reads, uint32_t reads_capacity,
-                       uint32_t* n_reads, otg_region* regions)
+int otg_ingest_regions_named(otg_bam* b, const otg_bed* beds, const char* chr_arena, uint32_t n_regions, const otg_ingest_opts* opts,
+                             uint8_t* arena, uint64_t arena_capacity, uint64_t* arena_used, otg_read* reads, uint32_t reads_capacity,
+                             uint32_t* n_reads, otg_region* regions, otg_read_meta* meta, char* name_arena, uint64_t name_capacity,
+                             uint64_t* name_used)
 {
   if (!b || (n_regions && (!beds || !regions)) || !opts || !arena_used || !n_reads) return otg_fail(nullptr, OTG_ERR_ARG, "otg_ingest_regions: null argument");
+  const bool want_meta = meta != nullptr;
+  if (want_meta && !name_used) return otg_fail(nullptr, OTG_ERR_ARG, "otg_ingest_regions_named: name_used is null");
   // regions are independent: contiguous slices on separate threads (each with its own file handle, as the reference's pool
   // threads have, src/assemble.cpp:45-46), merged in region order afterwards
   uint32_t T = opts->threads > 1 ? (uint32_t)opts->threads : 1u;
   if (T > n_regions) T = n_regions ? n_regions : 1;
   std::vector<std::vector<otg_read>> R(T);
   std::vector<std::vector<uint8_t>> A(T);
+  std::vector<std::vector<otg_read_meta>> M(T);
+  std::vector<std::string> N(T);
   std::vector<int> rcs(T, OTG_OK);
   std::vector<std::string> errs(T);
   auto work = [&](uint32_t t) {
     const uint32_t g0 = (uint32_t)((uint64_t)n_regions * t / T), g1 = (uint32_t)((uint64_t)n_regions * (t + 1) / T);
-    rcs[t] = ingest_slice(b, b->path.c_str(), beds, chr_arena, g0, g1, opts, R[t], A[t], regions, errs[t]);
+    rcs[t] = ingest_slice(b, b->path.c_str(), beds, chr_arena, g0, g1, opts, R[t], A[t], regions, errs[t],
+                          want_meta ? &M[t] : nullptr, want_meta ? &N[t] : nullptr);
   };
   if (T == 1) work(0);
   else {
@@ -476,19 +494,34 @@ int otg_ingest_regions(otg_bam* b, const otg_bed* beds, const char* chr_arena, u
   }
   for (uint32_t t = 0; t < T; ++t) if (rcs[t] != OTG_OK) return otg_fail(nullptr, rcs[t], "otg_ingest_regions: %s", errs[t].c_str());
   uint64_t used = *arena_used; uint32_t nr = *n_reads;
+  uint64_t nused = want_meta ? *name_used : 0;
   bool overflow = false;
   for (uint32_t t = 0; t < T; ++t) {
     const uint32_t g0 = (uint32_t)((uint64_t)n_regions * t / T), g1 = (uint32_t)((uint64_t)n_regions * (t + 1) / T);
     for (uint32_t g = g0; g < g1; ++g) regions[g].first_read += nr;
-    const bool fits = (uint64_t)nr + R[t].size() <= reads_capacity && used + A[t].size() + 64 <= arena_capacity;
+    const bool fits = (uint64_t)nr + R[t].size() <= reads_capacity && used + A[t].size() + 64 <= arena_capacity &&
+                      (!want_meta || (name_arena && nused + N[t].size() <= name_capacity));
     if (fits && !overflow) {
       for (size_t i = 0; i < R[t].size(); ++i) { reads[nr + i] = R[t][i]; reads[nr + i].seq_off += used; }
       if (!A[t].empty()) memcpy(arena + used, A[t].data(), A[t].size());
+      if (want_meta) {
+        for (size_t i = 0; i < M[t].size(); ++i) { meta[nr + i] = M[t][i]; meta[nr + i].name_off += nused; }
+        if (!N[t].empty()) memcpy(name_arena + nused, N[t].data(), N[t].size());
+      }
     } else overflow = true;
-    nr += (uint32_t)R[t].size(); used += A[t].size();
+    nr += (uint32_t)R[t].size(); used += A[t].size(); nused += N[t].size();
   }
   *arena_used = used; *n_reads = nr;
+  if (want_meta) *name_used = nused;
   return overflow ? OTG_ERR_CAPACITY : OTG_OK;
+}
+
+int otg_ingest_regions(otg_bam* b, const otg_bed* beds, const char* chr_arena, uint32_t n_regions, const otg_ingest_opts* opts,
+                       uint8_t* arena, uint64_t arena_capacity, uint64_t* arena_used, otg_read* reads, uint32_t reads_capacity,
+                       uint32_t* n_reads, otg_region* regions)
+{
+  return otg_ingest_regions_named(b, beds, chr_arena, n_regions, opts, arena, arena_capacity, arena_used, reads, reads_capacity,
+                                  n_reads, regions, nullptr, nullptr, 0, nullptr);
 }
 
 } // extern "C"

@@ -82,3 +82,30 @@ def test_bam_to_sam_text_all_native(gpu, oracle, tmp_path):
     beds, carena = abi.make_beds(ds["regions"])
     assert otter_amd.emit_sam_header(targets, "s1", 1, 1) + otter_amd.emit_alleles(beds, carena, res, "s1", False) == \
         oracle.emit_sam_header([(ds["chrom"], ds["ref_len"])], "s1", 1, 1) + oracle.emit_alleles(beds, carena, ora, "s1", False)
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_bed_bam_fasta_to_sam_text_all_native_with_realign(gpu, oracle, tmp_path):
+    """`otter assemble -b regions.bed -r ref.fa reads.bam` through the C-ABI alone: otg_parse_bed_file -> otg_ingest_regions ->
+    otg_fasta_region_flanks -> GPU hot path with local_realignment -> otg_emit_alleles, against the reference's own ingest + FASTA
+    helper -> oracle -> oracle emit."""
+    import os
+    import e2e_bam
+    ds = e2e_bam.make_dataset(str(tmp_path), n_regions=8, seed=68)
+    ref_batch = e2e_bam.ingest_with_reference(ds, str(tmp_path), offset_l=1, offset_r=1, mapq=10, flank=100)
+    bed_path = os.path.join(str(tmp_path), "regions.bed")
+    with open(bed_path, "w") as f:
+        f.write("# synthetic tandem-repeat loci\n")
+        for i, (c, s, e) in enumerate(ds["regions"]):
+            f.write("%s:%d-%d\n" % (c, s, e) if i % 3 == 0 else "%s\t%d\t%d\tlocus%d\n" % (c, s, e, i))
+    beds, carena, _ = otter_amd.parse_bed_file(bed_path)
+    assert otter_amd.bed_tuples(beds, carena) == ds["regions"]
+    bam = otter_amd.Bam(os.path.join(str(tmp_path), "reads.bam"))
+    batch = bam.ingest((beds, carena), offset_l=1, offset_r=1, mapq=10, threads=2)
+    otter_amd.Fasta(ds["fasta"]).region_flanks(beds, carena, batch, flank=100, offset_l=1, offset_r=1)
+    P = abi.default_params(realign=1)
+    res = gpu.assemble(P, batch)
+    ora = oracle.assemble_batch(P, ref_batch)
+    assert np.array_equal(res["labels"], ora["labels"])
+    assert otter_amd.emit_alleles(beds, carena, res, "s1", False) == oracle.emit_alleles(beds, carena, ora, "s1", False)
