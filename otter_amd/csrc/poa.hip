@@ -43,22 +43,29 @@ struct PoaDev {
   // outputs
   const uint64_t* out_off; uint32_t* out_len; uint8_t* out_arena; uint32_t* out_start; int32_t* status;
   const uint32_t* order;      // graphs in decreasing order of work (longest first: shortest tail)
+  unsigned long long* prof;   // OTG_POA_PROFILE: wall-clock ticks per phase, summed over graphs (null otherwise)
+  uint32_t* fb_list;          // graphs left to the global-memory kernel (too large for LDS, or outgrew the optimistic capacities)
+  uint32_t* fb_count;
 };
 
+// capacity bounds per member: alt = ops that can create a node (X, I); mrun = 'M' ops not preceded by an 'M' — with the X / I ops the
+// only ones that can create an edge outside the backbone (insert_edge from a non-'M' predecessor, src/anppoa.hpp:96-110)
 __global__ void poa_count_kernel(const uint8_t* __restrict__ cig_arena, const otg_poa_member* __restrict__ members,
-                                 uint32_t n_members, uint32_t* __restrict__ n_alt, uint32_t* __restrict__ n_nonm)
+                                 uint32_t n_members, uint32_t* __restrict__ n_alt, uint32_t* __restrict__ n_mrun)
 {
   const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= n_members) return;
   const uint8_t* c = cig_arena + members[m].cigar_off;
   const uint32_t n = members[m].cigar_len;
-  uint32_t alt = 0, nonm = 0;
+  uint32_t alt = 0, mrun = 0;
+  uint8_t prev = 0;
   for (uint32_t i = 0; i < n; ++i) {
     const uint8_t op = c[i];
     alt += (op == 'X' || op == 'I');
-    nonm += (op != 'M');
+    mrun += (op == 'M' && prev != 'M');
+    prev = op;
   }
-  n_alt[m] = alt; n_nonm[m] = nonm;
+  n_alt[m] = alt; n_mrun[m] = mrun;
 }
 
 // PPOA::init (src/anppoa.hpp:64-84), one block per graph
@@ -235,23 +242,61 @@ __global__ __launch_bounds__(64) void poa_graph_kernel(PoaDev P)
 // prefix counts, and an 'M' that follows an 'M' only bumps the implicit backbone edge ref-1 -> ref (distinct
 // addresses per lane), so only the ops around mismatches and gaps (15-35 % for ONT reads) take the serial path.
 // One wave owns a graph, so plain read-modify-writes replace the atomics of v1.
-__global__ __launch_bounds__(64, 8) void poa_graph_wave_kernel(PoaDev P)
+//
+// The serial part is a chain of dependent loads (edge list walks, the Kahn sweep: ~4 us per node out of L2), so the
+// graph lives in LDS whenever it fits (LDS = true): 16-bit node / edge ids and counts, 19 bytes per node + 6 per edge —
+// a consensus window of otter (150-base backbone, 30 reads) needs about 8 KB.  The LDS capacities are optimistic (half of
+// the worst-case alt-node / edge bounds); a graph that outgrows them is queued for the global-memory instantiation
+// (LDS = false), which has the worst-case capacities and is also the path for graphs too large for 16-bit ids.
+#define OTG_LDS __attribute__((address_space(3)))
+template <bool LDS> struct PoaTypes;
+template <> struct PoaTypes<false> { using idx = int32_t; using cnt = uint32_t; using w = float; using f = float; using b = uint8_t; };
+template <> struct PoaTypes<true> {
+  using idx = OTG_LDS int16_t; using cnt = OTG_LDS uint16_t; using w = OTG_LDS uint16_t; using f = OTG_LDS float; using b = OTG_LDS uint8_t;
+};
+template <bool LDS> struct PoaStore {
+  typename PoaTypes<LDS>::b *nbase, *isend, *hdef;
+  typename PoaTypes<LDS>::idx *head, *tail, *pred, *enext;
+  typename PoaTypes<LDS>::cnt *indeg, *bbc, *queue, *esink, *starts;
+  typename PoaTypes<LDS>::w* ew;
+  typename PoaTypes<LDS>::f* hw;
+  uint32_t node_cap, edge_cap;      // capacities of THIS storage
+  bool reduced;                     // LDS: capacities below the worst-case bounds (overflow = retry in global memory)
+};
+
+// returns false when the graph has to be redone with larger capacities (LDS only)
+template <bool LDS>
+__device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g, const PoaStore<LDS>& S, const uint32_t out_cap)
 {
   const int lane = threadIdx.x & 63;
-  const uint32_t g = P.order[blockIdx.x];      // one single-wave block per graph: the dispatcher refills a wave slot as soon as its graph is done
-  if (g >= P.n_graphs) return;
   const otg_poa_graph G = P.graphs[g];
-  const uint64_t no = P.node_off[g], eo = P.edge_off[g], so = P.start_off[g];
-  const uint32_t node_cap = (uint32_t)(P.node_off[g + 1] - no), edge_cap = (uint32_t)(P.edge_off[g + 1] - eo);
-  uint8_t* nbase = P.node_base + no; uint8_t* isend = P.is_end + no; uint8_t* hdef = P.hdef + no;
-  int32_t* head = P.head + no; int32_t* tail = P.tail + no; uint32_t* indeg = P.indeg + no; uint32_t* bbc = P.bb_cnt + no;
-  float* hw = P.hw + no; int32_t* pred = P.pred + no; uint32_t* queue = P.queue + no;
-  uint32_t* esink = P.e_sink + eo; float* ew = P.e_w + eo; int32_t* enext = P.e_next + eo;
-  uint32_t* starts = P.start_list + so;
+  const uint32_t node_cap = S.node_cap, edge_cap = S.edge_cap;
+  auto nbase = S.nbase; auto isend = S.isend; auto hdef = S.hdef;
+  auto head = S.head; auto tail = S.tail; auto indeg = S.indeg; auto bbc = S.bbc;
+  auto hw = S.hw; auto pred = S.pred; auto queue = S.queue;
+  auto esink = S.esink; auto ew = S.ew; auto enext = S.enext;
+  auto starts = S.starts;
   const int B = (int)G.backbone_len;
   uint32_t n_nodes = (uint32_t)B, n_edges = 0, n_start = B >= 2 ? 1u : 0u;
   int status = 0;
   const unsigned long long lt = (1ull << lane) - 1ull;
+  const unsigned long long t0 = P.prof ? wall_clock64() : 0ull;
+
+  // ---- PPOA::init (src/anppoa.hpp:64-84)
+  {
+    const uint8_t* bb = P.seq_arena + G.backbone_off;
+    for (uint32_t i = (uint32_t)lane; i < node_cap; i += 64) {
+      const bool isb = (int)i < B && B >= 2;
+      nbase[i] = isb ? bb[i] : (uint8_t)0;
+      isend[i] = (isb && i >= 1 && B - (int)i <= 10) ? 1 : 0;
+      indeg[i] = (isb && i >= 1) ? 1 : 0;
+      head[i] = -1; tail[i] = -1;
+      bbc[i] = 0; hdef[i] = 0; hw[i] = 0.0f; pred[i] = -1;
+    }
+    if (B >= 2) starts[0] = 0;
+    if (LDS) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+    else __threadfence();
+  }
 
   auto new_node = [&](uint8_t base) -> uint32_t {
     if (n_nodes >= node_cap) { status = 1; return n_nodes - 1; }
@@ -259,20 +304,20 @@ __global__ __launch_bounds__(64, 8) void poa_graph_wave_kernel(PoaDev P)
     return n_nodes++;
   };
   auto insert_edge = [&](uint32_t src, uint32_t sink) {     // src/anppoa.hpp:96-110
-    if ((int)src < B - 1 && sink == src + 1) { bbc[src] = bbc[src] + 1u; return; }
-    for (int e = head[src]; e >= 0; e = enext[e]) if (esink[e] == sink) { ew[e] = ew[e] + 1.0f; return; }
+    if ((int)src < B - 1 && sink == src + 1) { bbc[src] = bbc[src] + 1; return; }
+    for (int e = head[src]; e >= 0; e = enext[e]) if (esink[e] == sink) { ew[e] = ew[e] + 1; return; }
     if (n_edges >= edge_cap) { status = 2; return; }
     const int e = (int)n_edges++;
-    esink[e] = sink; ew[e] = 1.0f; enext[e] = -1;
+    esink[e] = sink; ew[e] = 1; enext[e] = -1;
     const int tl_ = tail[src];
     if (tl_ >= 0) enext[tl_] = e; else head[src] = e;
     tail[src] = e;
-    indeg[sink] = indeg[sink] + 1u;
+    indeg[sink] = indeg[sink] + 1;
   };
   auto alt_step = [&](uint32_t prev, uint8_t tc) -> uint32_t {   // :162-186 / :206-233
     for (int e = head[prev]; e >= 0; e = enext[e]) {
       const uint32_t sk = esink[e];
-      if ((int)sk >= B && nbase[sk] == tc) { ew[e] = ew[e] + 1.0f; return sk; }
+      if ((int)sk >= B && nbase[sk] == tc) { ew[e] = ew[e] + 1; return sk; }
     }
     const uint32_t nn = new_node(tc);
     if (!status) insert_edge(prev, nn);
@@ -316,15 +361,18 @@ __global__ __launch_bounds__(64, 8) void poa_graph_wave_kernel(PoaDev P)
       // 'M' after 'M': prev == ref-1, not the first op -> insert_edge(ref-1, ref) is the implicit backbone edge
       const bool simple = valid && isM && pc == 'M' && ref_at < B;
       if (simple) {
-        bbc[ref_at - 1] = bbc[ref_at - 1] + 1u;
+        bbc[ref_at - 1] = bbc[ref_at - 1] + 1;
         if (B - (ref_at + 1) <= 10 && spr && (uint32_t)ref_at < node_cap) isend[ref_at] = 1;
       }
+      // the target base of every op travels with it (one coalesced read instead of a dependent load per serial op)
+      const int tb = (valid && (isX || isI) && tgt_at < slen) ? (int)seq[tgt_at] : 0;
       unsigned long long todo = __ballot(valid && !simple);
       while (todo && !status) {
         const int l = (int)__builtin_ctzll(todo);
         todo &= todo - 1ull;
         const int op = __builtin_amdgcn_readlane(c, l), pop = __builtin_amdgcn_readlane(pc, l);
-        const int r = __builtin_amdgcn_readlane(ref_at, l), tg = __builtin_amdgcn_readlane(tgt_at, l);
+        const int r = __builtin_amdgcn_readlane(ref_at, l);
+        const uint8_t tc = (uint8_t)__builtin_amdgcn_readlane(tb, l);
         if (pop == 'M') { prev = r - 1; first = false; }
         int ref_after = r;
         if (op == 'M') {
@@ -333,7 +381,6 @@ __global__ __launch_bounds__(64, 8) void poa_graph_wave_kernel(PoaDev P)
           else insert_edge((uint32_t)prev, (uint32_t)r);
           prev = r; ref_after = r + 1;
         } else if (op == 'X') {
-          const uint8_t tc = tg < slen ? seq[tg] : 0;
           if (first) {
             bool need_new = true;
             for (uint32_t q = 0; q < n_start; ++q) if (nbase[starts[q]] == tc) { need_new = false; break; }
@@ -346,7 +393,6 @@ __global__ __launch_bounds__(64, 8) void poa_graph_wave_kernel(PoaDev P)
           ref_after = r + 1;
           if (first) prev = ref_after;
         } else if (op == 'I') {
-          const uint8_t tc = tg < slen ? seq[tg] : 0;
           if (first) { prev = (int)new_node(tc); starts[n_start++] = (uint32_t)prev; first = false; }
           else if ((uint32_t)prev >= n_nodes) { status = 3; break; }
           else prev = (int)alt_step((uint32_t)prev, tc);
@@ -360,7 +406,10 @@ __global__ __launch_bounds__(64, 8) void poa_graph_wave_kernel(PoaDev P)
       ci += 64;
     }
   }
-  __threadfence();
+  if (LDS) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+  else __threadfence();
+  if (LDS && S.reduced && (status == 1 || status == 2)) return false;     // outgrew the optimistic LDS capacities
+  const unsigned long long t1 = P.prof ? wall_clock64() : 0ull;
 
   // ---- heaviest path: Kahn sweep pushing (weight, source) along out-edges (wave-uniform)
   const float c_ = G.c, t_ = G.t;
@@ -372,7 +421,7 @@ __global__ __launch_bounds__(64, 8) void poa_graph_wave_kernel(PoaDev P)
   auto relax = [&](uint32_t u, uint32_t v, float w) {
     const float cand = hw[u] + w;
     if (!hdef[v]) { hdef[v] = 1; hw[v] = cand; pred[v] = (int32_t)u; }
-    else if (cand > hw[v] || (cand == hw[v] && (int32_t)u < pred[v])) { hw[v] = cand; pred[v] = (int32_t)u; }
+    else if (cand > hw[v] || (cand == hw[v] && (int32_t)u < (int32_t)pred[v])) { hw[v] = cand; pred[v] = (int32_t)u; }
   };
   uint32_t qh = 0, qt = 0;
   if (!status) {
@@ -383,6 +432,7 @@ __global__ __launch_bounds__(64, 8) void poa_graph_wave_kernel(PoaDev P)
       if (z) queue[qt + __builtin_popcountll(zm & lt)] = i;
       qt += (uint32_t)__builtin_popcountll(zm);
     }
+    if (LDS) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
     while (qh < qt) {
       const uint32_t u = queue[qh++];
       if ((int)u < B - 1) {
@@ -394,7 +444,7 @@ __global__ __launch_bounds__(64, 8) void poa_graph_wave_kernel(PoaDev P)
       }
       for (int e = head[u]; e >= 0; e = enext[e]) {
         const uint32_t v = esink[e];
-        relax(u, v, damp(ew[e]));
+        relax(u, v, damp((float)ew[e]));
         const uint32_t left = indeg[v] - 1;
         indeg[v] = left;
         if (left == 0) queue[qt++] = v;
@@ -403,8 +453,10 @@ __global__ __launch_bounds__(64, 8) void poa_graph_wave_kernel(PoaDev P)
     if (qt != n_nodes) status = 4;    // cycle: the reference would never return
   }
   // ---- pick the end node (:346-367: first strictly heaviest in ascending id) and emit the path (:373-378)
+  const unsigned long long t2 = P.prof ? wall_clock64() : 0ull;
   uint32_t len = 0, startpos = 0;
   if (!status && n_nodes > 0) {
+    if (LDS) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
     float bw = 0.0f; uint32_t bi = 0xffffffffu;
     for (uint32_t i = (uint32_t)lane; i < n_nodes; i += 64) {
       if (isend[i]) { const float w = hw[i]; if (bi == 0xffffffffu || w > bw) { bw = w; bi = i; } }
@@ -415,17 +467,110 @@ __global__ __launch_bounds__(64, 8) void poa_graph_wave_kernel(PoaDev P)
     }
     const uint32_t h_node = bi == 0xffffffffu ? 0u : bi;
     uint8_t* out = P.out_arena + P.out_off[g];
-    const uint32_t cap = node_cap;
-    uint32_t pos = cap;
+    const uint32_t cap = out_cap;
     int32_t cur = (int32_t)h_node;
-    while (cur >= 0 && pos > 0) {
-      const uint8_t b = nbase[cur];
-      if (b) out[--pos] = b;
-      cur = pred[cur];
+    if (LDS) {
+      // walk the predecessor chain in LDS (bases parked in the now idle queue), then one coalesced copy to HBM
+      uint32_t k = 0;
+      while (cur >= 0 && k < cap && k < node_cap) {
+        const uint8_t b = nbase[cur];
+        if (b) queue[k++] = b;
+        cur = pred[cur];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+      for (uint32_t j = (uint32_t)lane; j < k; j += 64) out[cap - 1 - j] = (uint8_t)queue[j];
+      startpos = cap - k; len = k;
+    } else {
+      uint32_t pos = cap;
+      while (cur >= 0 && pos > 0) {
+        const uint8_t b = nbase[cur];
+        if (b) out[--pos] = b;
+        cur = pred[cur];
+      }
+      startpos = pos; len = cap - pos;
     }
-    startpos = pos; len = cap - pos;
+  }
+  if (P.prof && lane == 0) {
+    const unsigned long long t3 = wall_clock64();
+    atomicAdd(P.prof + 0, t1 - t0); atomicAdd(P.prof + 1, t2 - t1); atomicAdd(P.prof + 2, t3 - t2); atomicAdd(P.prof + 3, 1ull);
+    atomicAdd(P.prof + 4, (unsigned long long)n_nodes); atomicAdd(P.prof + 5, (unsigned long long)n_edges); atomicAdd(P.prof + 6, (unsigned long long)B);
+    if (LDS) atomicAdd(P.prof + 7, 1ull);
   }
   P.out_len[g] = len; P.out_start[g] = startpos; P.status[g] = status;
+  return true;
+}
+
+// LDS instantiation: one single-wave block per graph (the dispatcher refills the slot as soon as its graph is done); a graph
+// that does not fit, or outgrows its optimistic capacities, goes onto the list of the global-memory kernel below.
+__global__ __launch_bounds__(64) void poa_graph_lds_kernel(PoaDev P, uint32_t lds_bytes)
+{
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_graph[];
+  const int lane = threadIdx.x & 63;
+  const uint32_t g = P.order[blockIdx.x];
+  if (g >= P.n_graphs) return;
+  const otg_poa_graph G = P.graphs[g];
+  const uint32_t ncap_true = (uint32_t)(P.node_off[g + 1] - P.node_off[g]), ecap_true = (uint32_t)(P.edge_off[g + 1] - P.edge_off[g]);
+  const uint32_t B = G.backbone_len, nm = G.n_members;
+  // optimistic need: the backbone + half of the worst-case alt nodes, half of the worst-case edges
+  const uint32_t start_b = (2u * (nm + 2u) + 7u) & ~7u;
+  bool fits = lds_bytes > start_b + 64u && ncap_true < 32768u && ecap_true < 32768u && nm < 32768u;
+  uint32_t N = 0, E = 0;
+  bool reduced = false;
+  if (fits) {
+    const uint32_t avail = lds_bytes - start_b - 32u;
+    const float estN = (float)B + 0.5f * (float)(ncap_true - B) + 4.0f, estE = 0.5f * (float)ecap_true + 4.0f;
+    const float f = (float)avail / (19.0f * estN + 6.0f * estE);
+    N = (uint32_t)(estN * f) & ~3u; E = (uint32_t)(estE * f) & ~1u;
+    if (N >= ncap_true) { N = ncap_true; E = ((avail - 19u * N) / 6u) & ~1u; }     // node arrays at their bound: edges take the rest
+    if (E >= ecap_true) { E = ecap_true; const uint32_t n2 = ((avail - 6u * E) / 19u) & ~3u; N = n2 < ncap_true ? n2 : ncap_true; }
+    reduced = N < ncap_true || E < ecap_true;
+    fits = N >= B + 2u && f >= 1.0f;
+  }
+  if (!fits) {
+    if (lane == 0) { const uint32_t k = atomicAdd(P.fb_count, 1u); P.fb_list[k] = g; }
+    return;
+  }
+  PoaStore<true> S;
+  uint32_t o = 0;
+  S.hw = (OTG_LDS float*)(s_graph + o); o += 4u * N;
+  S.head = (OTG_LDS int16_t*)(s_graph + o); o += 2u * N;
+  S.tail = (OTG_LDS int16_t*)(s_graph + o); o += 2u * N;
+  S.pred = (OTG_LDS int16_t*)(s_graph + o); o += 2u * N;
+  S.indeg = (OTG_LDS uint16_t*)(s_graph + o); o += 2u * N;
+  S.bbc = (OTG_LDS uint16_t*)(s_graph + o); o += 2u * N;
+  S.queue = (OTG_LDS uint16_t*)(s_graph + o); o += 2u * N;
+  S.nbase = (OTG_LDS uint8_t*)(s_graph + o); o += N;
+  S.isend = (OTG_LDS uint8_t*)(s_graph + o); o += N;
+  S.hdef = (OTG_LDS uint8_t*)(s_graph + o); o += N;
+  o = (o + 3u) & ~3u;
+  S.esink = (OTG_LDS uint16_t*)(s_graph + o); o += 2u * E;
+  S.ew = (OTG_LDS uint16_t*)(s_graph + o); o += 2u * E;
+  S.enext = (OTG_LDS int16_t*)(s_graph + o); o += 2u * E;
+  S.starts = (OTG_LDS uint16_t*)(s_graph + o);
+  S.node_cap = N; S.edge_cap = E; S.reduced = reduced;
+  if (!poa_graph_body<true>(P, g, S, ncap_true)) {
+    if (lane == 0) { const uint32_t k = atomicAdd(P.fb_count, 1u); P.fb_list[k] = g; }
+  }
+}
+
+// global-memory instantiation over a list of graphs: those too large for the LDS kernel, then what the LDS kernel left behind
+__global__ __launch_bounds__(64, 8) void poa_graph_wave_kernel(PoaDev P, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count_ptr,
+                                                               uint32_t count_imm)
+{
+  const uint32_t n = count_ptr ? *count_ptr : count_imm;
+  for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {
+    const uint32_t g = list[k];
+    if (g >= P.n_graphs) continue;
+    const uint64_t no = P.node_off[g], eo = P.edge_off[g];
+    PoaStore<false> S;
+    S.nbase = P.node_base + no; S.isend = P.is_end + no; S.hdef = P.hdef + no;
+    S.head = P.head + no; S.tail = P.tail + no; S.indeg = P.indeg + no; S.bbc = P.bb_cnt + no;
+    S.hw = P.hw + no; S.pred = P.pred + no; S.queue = P.queue + no;
+    S.esink = P.e_sink + eo; S.ew = P.e_w + eo; S.enext = P.e_next + eo;
+    S.starts = P.start_list + P.start_off[g];
+    S.node_cap = (uint32_t)(P.node_off[g + 1] - no); S.edge_cap = (uint32_t)(P.edge_off[g + 1] - eo); S.reduced = false;
+    poa_graph_body<false>(P, g, S, S.node_cap);
+  }
 }
 
 } // namespace
@@ -454,10 +599,10 @@ int otg_launch_poa(otg_ctx* ctx, const uint8_t* d_seq_arena, const uint8_t* d_ci
   node_off.assign(n_graphs + 1, 0);
   node_off[0] = edge_off[0] = start_off[0] = 0;
   for (uint32_t g = 0; g < n_graphs; ++g) {
-    uint64_t alt = 0, nonm = 0;
-    for (uint32_t m = 0; m < h_graphs[g].n_members; ++m) { alt += h_alt[h_graphs[g].first_member + m]; nonm += h_nonm[h_graphs[g].first_member + m]; }
+    uint64_t alt = 0, mrun = 0;
+    for (uint32_t m = 0; m < h_graphs[g].n_members; ++m) { alt += h_alt[h_graphs[g].first_member + m]; mrun += h_nonm[h_graphs[g].first_member + m]; }
     node_off[g + 1] = node_off[g] + (((uint64_t)h_graphs[g].backbone_len + alt + 2 + 3) & ~3ull);
-    edge_off[g + 1] = edge_off[g] + 2 * nonm + 2;
+    edge_off[g + 1] = edge_off[g] + ((alt + mrun + 2 + 1) & ~1ull);
     start_off[g + 1] = start_off[g] + h_graphs[g].n_members + 2;
   }
   const uint64_t NN = node_off[n_graphs], NE = edge_off[n_graphs], NS = start_off[n_graphs];
@@ -490,17 +635,48 @@ int otg_launch_poa(otg_ctx* ctx, const uint8_t* d_seq_arena, const uint8_t* d_ci
   P.node_off = d_node_off; P.edge_off = d_edge_off; P.start_off = d_start_off;
   P.out_off = d_node_off;     // consensus g is written into [node_off[g], node_off[g+1]) of out_arena
   P.out_len = d_out_len;
+  // Graph slots without backbone and members (the pipeline keeps one slot per read) produce nothing: zero their outputs here and
+  // leave them out of the launches.  The others are split by size: LDS bytes per graph block = the optimistic need (same formula
+  // as poa_graph_lds_kernel) of 97 % of them; graphs within it go to the LDS kernel, the rest to the global-memory kernel.  Above
+  // 16 KB per block too few graphs would be resident per CU to beat the 32 latency-bound waves of the global-memory kernel.
+  static const bool no_lds = getenv("OTG_POA_NO_LDS") != nullptr;
+  uint32_t lds_bytes = 0, n_lds = 0, n_glob = 0;
   {
-    // longest graphs first (work ~ op-string bytes = nodes + edges capacity computed above)
-    std::vector<uint32_t> order(n_graphs);
-    for (uint32_t g = 0; g < n_graphs; ++g) order[g] = g;
-    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+    std::vector<uint32_t> est(n_graphs, 0u), live;
+    live.reserve(n_graphs);
+    for (uint32_t g = 0; g < n_graphs; ++g) {
+      if (h_graphs[g].backbone_len == 0 && h_graphs[g].n_members == 0) continue;
+      const double B = (double)h_graphs[g].backbone_len, ncap = (double)(node_off[g + 1] - node_off[g]), ecap = (double)(edge_off[g + 1] - edge_off[g]);
+      const double need = 19.0 * (B + 0.5 * (ncap - B) + 4.0) + 6.0 * (0.5 * ecap + 4.0) + (double)((2u * (h_graphs[g].n_members + 2u) + 7u) & ~7u) + 32.0 + 64.0;
+      est[g] = need > 4.0e9 ? 0xffffffffu : (uint32_t)need;
+      live.push_back(g);
+    }
+    if (!live.empty() && !no_lds) {
+      std::vector<uint32_t> e2(live.size());
+      for (size_t i = 0; i < live.size(); ++i) e2[i] = est[live[i]];
+      const size_t k = (size_t)((double)(live.size() - 1) * 0.97);
+      std::nth_element(e2.begin(), e2.begin() + k, e2.end());
+      if (e2[k] <= 16u * 1024u) lds_bytes = std::max<uint32_t>((e2[k] + 511u) & ~511u, 4096u);
+    }
+    // longest graphs first within each launch (work ~ op-string bytes = nodes + edges capacity computed above)
+    auto heavier = [&](uint32_t a, uint32_t b) {
       const uint64_t wa = (edge_off[a + 1] - edge_off[a]) + (node_off[a + 1] - node_off[a]), wb = (edge_off[b + 1] - edge_off[b]) + (node_off[b + 1] - node_off[b]);
       return wa != wb ? wa > wb : a < b;
-    });
-    uint32_t* d_order = (uint32_t*)otg_slot(ctx, SLOT_P18, (size_t)n_graphs * sizeof(uint32_t));
+    };
+    std::vector<uint32_t> order;
+    order.reserve(live.size());
+    for (uint32_t g : live) if (lds_bytes && est[g] <= lds_bytes) order.push_back(g);
+    n_lds = (uint32_t)order.size();
+    for (uint32_t g : live) if (!(lds_bytes && est[g] <= lds_bytes)) order.push_back(g);
+    n_glob = (uint32_t)order.size() - n_lds;
+    std::sort(order.begin(), order.begin() + n_lds, heavier);
+    std::sort(order.begin() + n_lds, order.end(), heavier);
+    uint32_t* d_order = (uint32_t*)otg_slot(ctx, SLOT_P18, (size_t)(n_graphs + 1) * sizeof(uint32_t));
     if (!d_order) return OTG_ERR_HIP;
-    HIP_TRY(ctx, hipMemcpyAsync(d_order, order.data(), (size_t)n_graphs * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    if (!order.empty()) HIP_TRY(ctx, hipMemcpyAsync(d_order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(d_out_len, 0, (size_t)n_graphs * sizeof(uint32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(P.out_start, 0, (size_t)n_graphs * sizeof(uint32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(P.status, 0, (size_t)n_graphs * sizeof(int32_t), ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     P.order = d_order;
   }
@@ -508,11 +684,39 @@ int otg_launch_poa(otg_ctx* ctx, const uint8_t* d_seq_arena, const uint8_t* d_ci
   HIP_TRY(ctx, hipMemcpyAsync(d_edge_off, edge_off.data(), (size_t)(n_graphs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(d_start_off, start_off.data(), (size_t)(n_graphs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // host vectors go out of scope after return
-  uint32_t gi = n_graphs < (uint32_t)ctx->n_cu * 8 ? n_graphs : (uint32_t)ctx->n_cu * 8;
-  hipLaunchKernelGGL(poa_init_kernel, dim3(gi), dim3(256), 0, ctx->stream, P);
+  static const bool profile = getenv("OTG_POA_PROFILE") != nullptr;
+  P.prof = nullptr;
+  if (profile) {
+    P.prof = (unsigned long long*)otg_slot(ctx, SLOT_P19, 8 * sizeof(unsigned long long));
+    if (!P.prof) return OTG_ERR_HIP;
+    HIP_TRY(ctx, hipMemsetAsync(P.prof, 0, 8 * sizeof(unsigned long long), ctx->stream));
+  }
+  P.fb_list = (uint32_t*)otg_slot(ctx, SLOT_P22, (size_t)(n_graphs + 1) * sizeof(uint32_t));
+  if (!P.fb_list) return OTG_ERR_HIP;
+  P.fb_count = P.fb_list + n_graphs;
   static const bool thread_per_graph = getenv("OTG_POA_THREAD") != nullptr;
-  if (thread_per_graph) hipLaunchKernelGGL(poa_graph_kernel, dim3((n_graphs + 63) / 64), dim3(64), 0, ctx->stream, P);
-  else hipLaunchKernelGGL(poa_graph_wave_kernel, dim3(n_graphs), dim3(64), 0, ctx->stream, P);
+  if (thread_per_graph) {
+    uint32_t gi = n_graphs < (uint32_t)ctx->n_cu * 8 ? n_graphs : (uint32_t)ctx->n_cu * 8;
+    hipLaunchKernelGGL(poa_init_kernel, dim3(gi), dim3(256), 0, ctx->stream, P);
+    hipLaunchKernelGGL(poa_graph_kernel, dim3((n_graphs + 63) / 64), dim3(64), 0, ctx->stream, P);
+  } else {
+    // one single-wave block per graph: the dispatcher refills a wave slot as soon as its graph is done
+    if (n_glob) hipLaunchKernelGGL(poa_graph_wave_kernel, dim3(n_glob), dim3(64), 0, ctx->stream, P, P.order + n_lds, (const uint32_t*)nullptr, n_glob);
+    if (n_lds) {
+      HIP_TRY(ctx, hipMemsetAsync(P.fb_count, 0, sizeof(uint32_t), ctx->stream));
+      hipLaunchKernelGGL(poa_graph_lds_kernel, dim3(n_lds), dim3(64), lds_bytes, ctx->stream, P, lds_bytes);
+      const uint32_t fg = n_lds < (uint32_t)ctx->n_cu * 32 ? n_lds : (uint32_t)ctx->n_cu * 32;
+      hipLaunchKernelGGL(poa_graph_wave_kernel, dim3(fg), dim3(64), 0, ctx->stream, P, (const uint32_t*)P.fb_list, (const uint32_t*)P.fb_count, 0u);
+    }
+  }
   HIP_TRY(ctx, hipGetLastError());
+  if (profile) {
+    unsigned long long h[8];
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(h, P.prof, sizeof(h), hipMemcpyDeviceToHost));
+    const double n = h[3] ? (double)h[3] : 1.0;     // wall_clock64: 100 MHz
+    fprintf(stderr, "[otg] poa profile: %u LDS + %u global launches; %llu graphs done (%llu in LDS, %u bytes each), per graph: insert %.1f us, sweep %.1f us, emit %.1f us; nodes %.0f (backbone %.0f), edges %.0f\n",
+            n_lds, n_glob, h[3], h[7], lds_bytes, h[0] / n / 100.0, h[1] / n / 100.0, h[2] / n / 100.0, h[4] / n, h[6] / n, h[5] / n);
+  }
   return OTG_OK;
 }

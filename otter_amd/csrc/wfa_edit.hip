@@ -160,6 +160,23 @@ __device__ __forceinline__ u128 load16(const uint8_t* p)
   return v;
 }
 
+// bit-parallel tier whose band holds an estimated distance `need` (same threshold function the tier itself applies)
+__device__ __forceinline__ int otg_route_tier(const otg_align_task& t, int need)
+{
+  const int pl = (int)t.pattern_len, tl = (int)t.text_len;
+  const bool ef = t.endsfree != 0;
+  int tier = 6;
+  const bool swap = !ef && pl < tl;                       // the bit-parallel kernel puts the longer sequence in the rows
+  const int dd = swap ? tl - pl : pl - tl;
+  const int fb = ef ? (int)t.pattern_begin_free : 0, fe2 = ef ? (int)t.pattern_end_free : 0;
+  if (dd >= 0) {
+    const int rows[6] = {456, 904, 1936, 4000, 8128, 16192};    // (GL-1)*64*BPL + GL of the six tiers (myers_edit.hip)
+#pragma unroll
+    for (int q = 5; q >= 0; --q) if (need <= otg_myers_threshold(rows[q], dd, fb < dd ? fb : dd, fe2 < dd ? fe2 : dd)) tier = q;
+  }
+  return tier;
+}
+
 template <int CAP, int WPB>
 __global__ __launch_bounds__(WPB * 64) void wfa_edit_kernel_v2(
     const uint8_t* __restrict__ arena, const otg_align_task* __restrict__ tasks,
@@ -353,17 +370,7 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_kernel_v2(
       // estimate is the cheapest choice (OTG_EDIT_ROUTE_MARGIN overrides, in percent)
       const int need = (int)(route_margin * (est + (ef ? 0.0f : (float)dlen)));
       // threshold of tier t for this pair's length difference and free ends (same function the tier itself uses)
-      int tier = 6;
-      {
-        const bool swap = !ef && pl < tl;                       // the bit-parallel kernel puts the longer sequence in the rows
-        const int dd = swap ? tl - pl : pl - tl;
-        const int fb = ef ? (int)t.pattern_begin_free : 0, fe2 = ef ? (int)t.pattern_end_free : 0;
-        if (dd >= 0) {
-          const int rows[6] = {456, 904, 1936, 4000, 8128, 16192};    // (GL-1)*64*BPL + GL of the six tiers (myers_edit.hip)
-#pragma unroll
-          for (int q = 5; q >= 0; --q) if (need <= otg_myers_threshold(rows[q], dd, fb < dd ? fb : dd, fe2 < dd ? fe2 : dd)) tier = q;
-        }
-      }
+      const int tier = otg_route_tier(t, need);
       const uint32_t q = otg_wave_atomic_add(route_cnt + tier, 1u);
       route_lists[(size_t)tier * route_stride + q] = ti;
     } else if (overflow && overflow_list) {
@@ -371,6 +378,114 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_kernel_v2(
       overflow_list[q] = ti;
     } else {
       scores[ti] = -1;
+    }
+  }
+}
+
+// ---- tier routing by sampling (one pair per LANE).  The bit-parallel tiers only need to know roughly how far apart two reads
+// are; measuring that with wavefronts costs a chain of dependent sequence probes per score.  Instead: edit distance of the first 64
+// bases of the pattern against a prefix of the text, and of the last 64 against a suffix (one 64-bit block of Myers' recurrence per
+// lane, registers only, text end free), scaled to the whole pair.  A scheduling hint exactly like the wavefront estimate it replaces:
+// every tier is exact and passes a pair on when its band turns out too narrow.  Pairs the estimate cannot judge (free ends, short
+// sequences) and pairs that look near-identical (the wavefront pass finishes those by itself) go to the wavefront pass.
+__device__ __forceinline__ uint32_t otg_ld_u32_unaligned(const uint8_t* p)
+{
+  const uintptr_t a = (uintptr_t)p;
+  const uint32_t* q = (const uint32_t*)(a & ~(uintptr_t)3);
+  const uint32_t sh = (uint32_t)(a & 3u);
+  const uint32_t lo = q[0];
+  if (sh == 0) return lo;
+  return __builtin_amdgcn_alignbyte(q[1], lo, sh);
+}
+
+template <bool REV>
+__device__ __forceinline__ void otg_sample64(const uint8_t* P, int pl, const uint8_t* T, int tl, int ncols, int* dmin, int* jmin)
+{
+  // rows: P[0..63] (REV: P[pl-1-i]); columns: T[0..ncols) (REV: T[tl-1-j]); D[0][j] = j, D[i][0] = i; result min_j D[64][j]
+  uint64_t eq0 = 0, eq1 = 0, eq2 = 0, eq3 = 0;
+#pragma unroll 4
+  for (int w = 0; w < 16; ++w) {
+    uint32_t v = otg_ld_u32_unaligned(REV ? P + pl - 4 - 4 * w : P + 4 * w);
+    if (REV) v = __builtin_bswap32(v);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const uint32_t c = ((v >> (8 * b)) >> 1) & 3u;
+      const uint64_t m = 1ull << (4 * w + b);
+      eq0 |= c == 0 ? m : 0ull; eq1 |= c == 1 ? m : 0ull; eq2 |= c == 2 ? m : 0ull; eq3 |= c == 3 ? m : 0ull;
+    }
+  }
+  uint64_t Pv = ~0ull, Mv = 0ull;
+  int score = 64, best = 64, bj = 0;
+  for (int j0 = 0; j0 < ncols; j0 += 4) {
+    uint32_t v = otg_ld_u32_unaligned(REV ? T + tl - 4 - j0 : T + j0);
+    if (REV) v = __builtin_bswap32(v);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const uint32_t c = ((v >> (8 * b)) >> 1) & 3u;
+      const uint64_t Eq = c == 0 ? eq0 : c == 1 ? eq1 : c == 2 ? eq2 : eq3;
+      const uint64_t Xv = Eq | Mv;
+      const uint64_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+      uint64_t Ph = Mv | ~(Xh | Pv);
+      uint64_t Mh = Pv & Xh;
+      score += (int)(Ph >> 63) - (int)(Mh >> 63);
+      Ph = (Ph << 1) | 1ull;                      // D[0][j] = j: the top boundary grows by one per column
+      Mh = Mh << 1;
+      Pv = Mh | ~(Xv | Ph);
+      Mv = Ph & Xv;
+      if (score < best) { best = score; bj = j0 + b + 1; }
+    }
+  }
+  *dmin = best; *jmin = bj;
+}
+
+// route_cnt[0..6] / route_lists as in wfa_edit_kernel_v2; list 7 (count wf_cnt) = input of the wavefront pass
+__global__ __launch_bounds__(256) void edit_route_kernel(
+    const uint8_t* __restrict__ arena, const otg_align_task* __restrict__ tasks, const uint32_t* __restrict__ todo,
+    const uint32_t* __restrict__ n_todo_ptr, uint32_t n_todo_imm, float cap_coeff, uint32_t* __restrict__ route_cnt,
+    uint32_t* __restrict__ route_lists, uint32_t route_stride, float route_margin, uint32_t* __restrict__ wf_cnt, uint32_t* __restrict__ wf_list)
+{
+  const uint32_t n_todo = n_todo_ptr ? *n_todo_ptr : n_todo_imm;
+  const int lane = threadIdx.x & 63;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  for (uint32_t base = blockIdx.x * blockDim.x; base < n_todo; base += gridDim.x * blockDim.x) {
+    const uint32_t tk = base + threadIdx.x;
+    const bool act = tk < n_todo;
+    uint32_t ti = 0;
+    int tier = -1;                      // -1: not active; 0..6: list of that tier; 7: wavefront pass
+    if (act) {
+      ti = todo ? todo[tk] : tk;
+      const otg_align_task t = tasks[ti];
+      const int pl = (int)t.pattern_len, tl = (int)t.text_len;
+      tier = 7;
+      if (!t.endsfree && pl >= 160 && tl >= 160 && pl < 65535 && tl < 65535) {
+        const uint8_t* P = arena + t.pattern_off;
+        const uint8_t* T = arena + t.text_off;
+        int d1, j1, d2, j2;
+        otg_sample64<false>(P, pl, T, tl, 96, &d1, &j1);
+        otg_sample64<true>(P, pl, T, tl, 96, &d2, &j2);
+        const int dlen = pl > tl ? pl - tl : tl - pl;
+        float est = (float)(d1 + d2) * (float)(pl + tl) / (float)(128 + j1 + j2);
+        if (est > (float)(pl + tl)) est = (float)(pl + tl);
+        int cap = (int)(cap_coeff * sqrtf((float)(pl > tl ? pl : tl)));
+        if (cap < 48) cap = 48;
+        const int need = (int)(route_margin * (est + (float)dlen));
+        // near-identical pairs (projected distance within the wavefront pass's score cap) are finished there
+        if ((int)est + dlen > cap) tier = otg_route_tier(t, need);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const unsigned long long m = __ballot(tier == q);
+      if (m) {
+        uint32_t* c = q == 7 ? wf_cnt : route_cnt + q;
+        uint32_t b0 = 0;
+        if (lane == (int)__builtin_ctzll(m)) b0 = atomicAdd(c, (uint32_t)__builtin_popcountll(m));
+        b0 = (uint32_t)__builtin_amdgcn_readlane((int)b0, (int)__builtin_ctzll(m));
+        if (tier == q) {
+          uint32_t* l = q == 7 ? wf_list : route_lists + (size_t)q * route_stride;
+          l[b0 + (uint32_t)__builtin_popcountll(m & lt)] = ti;
+        }
+      }
     }
   }
 }
@@ -450,7 +565,7 @@ int otg_launch_edit_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_t
 {
   if (n_tasks == 0) return OTG_OK;
   uint32_t* cnt = (uint32_t*)otg_slot(ctx, SLOT_COUNTERS, 64 * sizeof(uint32_t));
-  uint32_t* todo = (uint32_t*)otg_slot(ctx, SLOT_TODO, 9 * (size_t)n_tasks * sizeof(uint32_t));
+  uint32_t* todo = (uint32_t*)otg_slot(ctx, SLOT_TODO, 10 * (size_t)n_tasks * sizeof(uint32_t));
   if (!cnt || !todo) return OTG_ERR_HIP;
   HIP_TRY(ctx, hipMemsetAsync(cnt, 0, 8 * sizeof(uint32_t), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(cnt + 16, 0, 16 * sizeof(uint32_t), ctx->stream));
@@ -479,8 +594,19 @@ int otg_launch_edit_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_t
     } else {
       constexpr int CAP = 1024;
       uint32_t grid = std::min<uint32_t>((uint32_t)ctx->n_cu * 8, want);
+      const uint32_t* in = d_todo; const uint32_t* in_n = d_n_todo; uint32_t in_imm = n_tasks;
+      static const bool no_sample = getenv("OTG_NO_EDIT_SAMPLE") != nullptr;
+      if (!no_route && !no_sample) {
+        // tier choice from two 64-base samples per pair (one pair per lane); only what it leaves goes through the wavefront pass
+        uint32_t* wf_list = todo + 9 * (size_t)n_tasks;
+        HIP_TRY(ctx, hipMemsetAsync(cnt + 40, 0, 4 * sizeof(uint32_t), ctx->stream));
+        const uint32_t rg = std::min<uint32_t>((n_tasks + 255) / 256, (uint32_t)ctx->n_cu * 16);
+        hipLaunchKernelGGL(edit_route_kernel, dim3(rg), dim3(256), 0, ctx->stream, d_arena, d_tasks, d_todo, d_n_todo, n_tasks, 1.0f, rc, lists,
+                           n_tasks, route_margin, cnt + 40, wf_list);
+        in = wf_list; in_n = cnt + 40; in_imm = 0;
+      }
       hipLaunchKernelGGL((wfa_edit_kernel_v2<CAP, WPB>), dim3(grid), dim3(WPB * 64), (size_t)CAP * 2 * WPB * sizeof(uint16_t), ctx->stream, d_arena, d_tasks,
-                         d_todo, d_n_todo, n_tasks, d_scores, d_cells, cnt + 0, rc + 0, lists, 1.0f,
+                         in, in_n, in_imm, d_scores, d_cells, cnt + 0, rc + 0, lists, 1.0f,
                          no_route ? (uint32_t*)nullptr : rc, lists, n_tasks, route_margin);
     }
   }
@@ -531,8 +657,10 @@ int otg_launch_edit_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_t
     hipError_t er = hipStreamSynchronize(ctx->stream);
     uint32_t h[40];
     (void)hipMemcpy(h, cnt, sizeof(h), hipMemcpyDeviceToHost);
-    fprintf(stderr, "[otg] edit: %s; inputs of the bit-parallel tiers 0..5: %u %u %u %u %u %u, wide wavefront tier %u, its overflow %u\n",
-            hipGetErrorString(er), h[32], h[33], h[34], h[35], h[36], h[37], h[38], h[17]);
+    uint32_t hw4[4] = {0, 0, 0, 0};
+    (void)hipMemcpy(hw4, cnt + 40, sizeof(hw4), hipMemcpyDeviceToHost);
+    fprintf(stderr, "[otg] edit: %s; wavefront pass input %u; inputs of the bit-parallel tiers 0..5: %u %u %u %u %u %u, wide wavefront tier %u, its overflow %u\n",
+            hipGetErrorString(er), hw4[0], h[32], h[33], h[34], h[35], h[36], h[37], h[38], h[17]);
   }
   if (kernel_ms) {
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));

@@ -77,3 +77,36 @@ def test_poa_op_string_fuzz(gpu, oracle):
         c = np.float32(n * 0.4) if n >= 4 else np.float32(1.0)
         specs.append((bb, mem, c, np.float32(0.3)))
     _check(gpu, oracle, specs)
+
+
+def test_poa_lds_capacity_mix(gpu, oracle):
+    """The LDS kernel sizes its block for the optimistic need of 97 % of the batch: a crowd of small, clean windows sets a small
+    block; graphs of the same backbone length whose members disagree everywhere (random target bases: alt nodes and edges close
+    to the worst-case bound) outgrow it mid-way and must be redone by the global-memory kernel; a few long backbones never fit.
+    With 40 members a window also passes 255 edges per node list.  All must equal the oracle."""
+    from helpers import rand_seq, mutate
+    rng = np.random.default_rng(45)
+    specs = []
+    for g in range(400):
+        B = int(rng.integers(120, 180))
+        bb = rand_seq(rng, B)
+        kind = 0 if g % 20 else (1 + (g // 20) % 3)
+        mem = []
+        nmem = 40 if kind == 1 else int(rng.integers(8, 30))
+        if kind == 3:
+            B = int(rng.integers(2500, 4000)); bb = rand_seq(rng, B); nmem = 6
+        for _ in range(nmem):
+            ops, ref = [], 0
+            noisy = kind in (1, 2)
+            while ref < B:
+                k = rng.choice(["M", "X", "D", "I"], p=[0.55, 0.25, 0.05, 0.15] if noisy else [0.93, 0.03, 0.02, 0.02])
+                run = int(rng.integers(1, 4)) if k != "M" else int(rng.integers(1, 6 if noisy else 40))
+                if k in "MXD":
+                    run = min(run, B - ref); ref += run
+                ops.append(k * run)
+            cig = "".join(ops).encode()
+            tlen = cig.count(b"M") + cig.count(b"X") + cig.count(b"I")
+            mem.append((rand_seq(rng, max(tlen, 1))[:tlen], cig, bool(rng.random() < 0.9), bool(rng.random() < 0.9)))
+        n = len(mem)
+        specs.append((bb, mem, np.float32(n * 0.4), np.float32(0.3)))
+    _check(gpu, oracle, specs)
