@@ -1327,6 +1327,59 @@ int gcd3(int a, int b, int c)
   return g2(g2(a, b), c);
 }
 
+// ---- counting sort of the alignment list by score bound, largest first: the exact pass of an alignment costs ~ bound^2, and the
+// persistent tier kernels hand alignments out in list order, so the longest run first and the tail of each kernel is short ones
+constexpr int ASORT_BUCKETS = 512;
+__device__ __forceinline__ int asort_bucket(int U)
+{
+  const int b = (U < 0 || U >= 0x40000000) ? ASORT_BUCKETS - 1 : (U >> 3);
+  return ASORT_BUCKETS - 1 - (b < ASORT_BUCKETS ? b : ASORT_BUCKETS - 1);
+}
+__global__ __launch_bounds__(256) void K_asort_hist(const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_ptr, uint32_t n_imm,
+                                                    const int32_t* __restrict__ bound, uint32_t* __restrict__ hist)
+{
+  __shared__ uint32_t h[ASORT_BUCKETS];
+  for (int b = (int)threadIdx.x; b < ASORT_BUCKETS; b += 256) h[b] = 0;
+  __syncthreads();
+  const uint32_t n = n_ptr ? *n_ptr : n_imm;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) atomicAdd(&h[asort_bucket(bound[list ? list[i] : i])], 1u);
+  __syncthreads();
+  for (int b = (int)threadIdx.x; b < ASORT_BUCKETS; b += 256) if (h[b]) atomicAdd(&hist[b], h[b]);
+}
+__global__ __launch_bounds__(ASORT_BUCKETS) void K_asort_scan(uint32_t* __restrict__ hist)
+{
+  __shared__ uint32_t sc[ASORT_BUCKETS];
+  const int i = (int)threadIdx.x;
+  sc[i] = hist[i];
+  __syncthreads();
+  for (int off = 1; off < ASORT_BUCKETS; off <<= 1) {
+    const uint32_t v = i >= off ? sc[i - off] : 0u;
+    __syncthreads();
+    sc[i] += v;
+    __syncthreads();
+  }
+  hist[i] = sc[i] - hist[i];
+}
+__global__ __launch_bounds__(256) void K_asort_scatter(const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_ptr, uint32_t n_imm,
+                                                       const int32_t* __restrict__ bound, uint32_t* __restrict__ pos, uint32_t* __restrict__ out)
+{
+  __shared__ uint32_t cnt[ASORT_BUCKETS], basep[ASORT_BUCKETS];
+  const uint32_t n = n_ptr ? *n_ptr : n_imm;
+  const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
+  const uint32_t lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+  for (int b = (int)threadIdx.x; b < ASORT_BUCKETS; b += 256) cnt[b] = 0;
+  __syncthreads();
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) atomicAdd(&cnt[asort_bucket(bound[list ? list[i] : i])], 1u);
+  __syncthreads();
+  for (int b = (int)threadIdx.x; b < ASORT_BUCKETS; b += 256) { basep[b] = cnt[b] ? atomicAdd(&pos[b], cnt[b]) : 0u; cnt[b] = 0; }
+  __syncthreads();
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
+    const uint32_t ti = list ? list[i] : i;
+    const int b = asort_bucket(bound[ti]);
+    out[basep[b] + atomicAdd(&cnt[b], 1u)] = ti;
+  }
+}
+
 } // namespace
 
 int otg_launch_affine(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_task* d_tasks, uint32_t n_tasks,
@@ -1347,7 +1400,7 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
   const int xs = x / g, oes = (o + e) / g, es = e / g;
   if (std::max(xs, oes) + 1 > 64 || es + 1 > 64) return otg_fail(ctx, OTG_ERR_ARG, "affine penalties too large after gcd reduction");
   uint32_t* cnt = (uint32_t*)otg_slot(ctx, SLOT_COUNTERS, 64 * sizeof(uint32_t));
-  uint32_t* todo = (uint32_t*)otg_slot(ctx, SLOT_TODO, 6 * (size_t)n_tasks * sizeof(uint32_t));
+  uint32_t* todo = (uint32_t*)otg_slot(ctx, SLOT_TODO, 7 * (size_t)n_tasks * sizeof(uint32_t));
   if (!cnt || !todo) return OTG_ERR_HIP;
   HIP_TRY(ctx, hipMemsetAsync(cnt + 8, 0, 8 * sizeof(uint32_t), ctx->stream));   // tickets / overflow counters of the tiers
   HIP_TRY(ctx, hipMemsetAsync(cnt + 24, 0, 8 * sizeof(uint32_t), ctx->stream));
@@ -1444,13 +1497,27 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
     if (d_bound && !no_v4) {
       static const int nws = getenv("OTG_V4_NWS") ? atoi(getenv("OTG_V4_NWS")) : 2;
       static const int nwm = getenv("OTG_V4_NWM") ? atoi(getenv("OTG_V4_NWM")) : 4;
+      // alignments in decreasing order of their bound (work ~ bound^2): short tails in every tier kernel
+      const uint32_t* inS = d_todo;
+      static const bool no_asort = getenv("OTG_NO_AFFINE_SORT") != nullptr;
+      if (!no_asort) {
+        uint32_t* hist = (uint32_t*)otg_slot(ctx, SLOT_ROWTAB, ASORT_BUCKETS * sizeof(uint32_t));
+        uint32_t* sortedU = todo + 6 * (size_t)n_tasks;
+        if (!hist) return OTG_ERR_HIP;
+        HIP_TRY(ctx, hipMemsetAsync(hist, 0, ASORT_BUCKETS * sizeof(uint32_t), ctx->stream));
+        const uint32_t sg = std::min<uint32_t>((n_tasks + 2047) / 2048, (uint32_t)ctx->n_cu * 2);
+        hipLaunchKernelGGL(K_asort_hist, dim3(sg), dim3(256), 0, ctx->stream, d_todo, d_n_todo, n_tasks, (const int32_t*)d_bound, hist);
+        hipLaunchKernelGGL(K_asort_scan, dim3(1), dim3(ASORT_BUCKETS), 0, ctx->stream, hist);
+        hipLaunchKernelGGL(K_asort_scatter, dim3(sg), dim3(256), 0, ctx->stream, d_todo, d_n_todo, n_tasks, (const int32_t*)d_bound, hist, sortedU);
+        inS = sortedU;
+      }
 #define OTG_V4_LAUNCH(CAPV, NWV, SEQV, WPEUV, BLOCKS, TODO, NTODO, IMM, TICK, OVF, LIST, WS)                                 \
       hipLaunchKernelGGL((wfa_affine_kernel_v4<CAPV, 256, NWV, SEQV, WPEUV>), dim3(BLOCKS), dim3(NWV * 64), 0, ctx->stream, d_arena, d_tasks, \
                          TODO, NTODO, IMM, g, d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, TICK, OVF, LIST, WS,       \
                          (const int32_t*)d_bound)
       static const bool no_mid = getenv("OTG_V4_NO_MID") != nullptr;
-      if (nws == 1) OTG_V4_LAUNCH(1024, 1, 2304, 3, blocksS, d_todo, d_n_todo, n_tasks, cnt + 24, cnt + 25, listS, wsS);
-      else OTG_V4_LAUNCH(1024, 2, 2304, 5, blocksS, d_todo, d_n_todo, n_tasks, cnt + 24, cnt + 25, listS, wsS);
+      if (nws == 1) OTG_V4_LAUNCH(1024, 1, 2304, 3, blocksS, inS, d_n_todo, n_tasks, cnt + 24, cnt + 25, listS, wsS);
+      else OTG_V4_LAUNCH(1024, 2, 2304, 5, blocksS, inS, d_n_todo, n_tasks, cnt + 24, cnt + 25, listS, wsS);
       const uint32_t* inM = listS; const uint32_t* inM_n = cnt + 25;
       if (!no_mid) {
         OTG_V4_LAUNCH(1472, 4, 2688, 7, blocksX, (const uint32_t*)listS, (const uint32_t*)(cnt + 25), 0u, cnt + 28, cnt + 29, listX, wsX);

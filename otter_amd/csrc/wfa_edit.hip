@@ -457,13 +457,17 @@ __global__ __launch_bounds__(256) void edit_route_kernel(
       const otg_align_task t = tasks[ti];
       const int pl = (int)t.pattern_len, tl = (int)t.text_len;
       tier = 7;
-      if (!t.endsfree && pl >= 160 && tl >= 160 && pl < 65535 && tl < 65535) {
+      // an end that is free on either sequence cannot anchor a sample: use the other end alone, or leave the pair to the wavefront pass
+      const bool ef = t.endsfree != 0;
+      const bool fwd_ok = !ef || (t.pattern_begin_free == 0 && t.text_begin_free == 0);
+      const bool rev_ok = !ef || (t.pattern_end_free == 0 && t.text_end_free == 0);
+      if ((fwd_ok || rev_ok) && pl >= 160 && tl >= 160 && pl < 65535 && tl < 65535) {
         const uint8_t* P = arena + t.pattern_off;
         const uint8_t* T = arena + t.text_off;
-        int d1, j1, d2, j2;
-        otg_sample64<false>(P, pl, T, tl, 96, &d1, &j1);
-        otg_sample64<true>(P, pl, T, tl, 96, &d2, &j2);
-        const int dlen = pl > tl ? pl - tl : tl - pl;
+        int d1 = 0, j1 = -64, d2 = 0, j2 = -64;
+        if (fwd_ok) otg_sample64<false>(P, pl, T, tl, 96, &d1, &j1);
+        if (rev_ok) otg_sample64<true>(P, pl, T, tl, 96, &d2, &j2);
+        const int dlen = ef ? 0 : (pl > tl ? pl - tl : tl - pl);
         float est = (float)(d1 + d2) * (float)(pl + tl) / (float)(128 + j1 + j2);
         if (est > (float)(pl + tl)) est = (float)(pl + tl);
         int cap = (int)(cap_coeff * sqrtf((float)(pl > tl ? pl : tl)));

@@ -14,6 +14,7 @@ CASES = [
     ("OTG_NO_AFFINE_BOUND", ["tests/test_gpu_affine.py"]),
     ("OTG_NO_AFFINE_V4", ["tests/test_gpu_affine.py"]),
     ("OTG_AFFINE_BOUND_STATIC", ["tests/test_gpu_affine.py"]),
+    ("OTG_NO_AFFINE_SORT", ["tests/test_gpu_affine.py::test_affine_small_mixed", "tests/test_gpu_affine.py::test_affine_long_ont"]),
     ("OTG_NO_MYERS", ["tests/test_gpu_edit.py::test_edit_small_mixed", "tests/test_gpu_edit.py::test_edit_long_ont"]),
     ("OTG_NO_EDIT_ROUTE", ["tests/test_gpu_edit.py"]),
     ("OTG_NO_EDIT_SORT", ["tests/test_gpu_edit.py"]),
