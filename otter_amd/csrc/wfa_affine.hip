@@ -23,6 +23,8 @@
 
 namespace {
 
+__device__ unsigned long long otg_dbg_v4_cells[2];     // OTG_DEBUG: cells the LDS tiers visited / alignments they finished
+
 struct AffWs {
   uint8_t* base;        // per-wave workspaces, contiguous
   size_t stride;        // bytes per wave
@@ -32,6 +34,7 @@ struct AffWs {
   int rm, ri;           // ring depths
   int nrows;            // row-table entries
   size_t rev_cap;
+  int dbg;              // OTG_DEBUG: count visited cells
 };
 
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
@@ -1318,6 +1321,7 @@ __global__ __launch_bounds__(NW * 64, WPEU) void wfa_affine_kernel_v4(
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");      // provenance bytes of the other waves (same CU, through L2)
     if (!backtrace_unpack(P, pl, T, tl, s_end, k_end, xs, oes, es, rowtab, slab, rev, ws.rev_cap, cig_arena + cig_off[ti], lane, &scores[ti], &cig_len[ti], g)) continue;
     if (cells) cells[ti] = affine_cells(t, xs, oes, s_end);
+    if (ws.dbg && threadIdx.x == 0) { atomicAdd(&otg_dbg_v4_cells[0], (unsigned long long)slab_top); atomicAdd(&otg_dbg_v4_cells[1], 1ull); }
   }
 }
 
@@ -1412,6 +1416,8 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
   ws.ri = es + 1;
   ws.nrows = (int)(2 * (size_t)oes + (size_t)es * 2 * maxlen + 16);
   ws.rev_cap = 4 * maxlen + 64;
+  ws.dbg = getenv("OTG_DEBUG") != nullptr;
+  if (ws.dbg) { const unsigned long long z[2] = {0, 0}; HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(otg_dbg_v4_cells), z, sizeof(z))); }
   size_t ring_bytes = (size_t)(ws.rm + 2 * ws.ri) * ws.capa * sizeof(int32_t);
   ws.off_rowtab = (ring_bytes + 255) & ~(size_t)255;
   ws.off_rev = (ws.off_rowtab + (size_t)ws.nrows * sizeof(int64_t) + 255) & ~(size_t)255;
@@ -1553,6 +1559,11 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
     uint32_t h[32];
     HIP_TRY(ctx, hipMemcpy(h, cnt, sizeof(h), hipMemcpyDeviceToHost));
     fprintf(stderr, "[otg] affine: LDS tiers overflow %u / %u, tier A overflow %u, tier B overflow %u\n", h[25], h[27], h[9], h[11]);
+    {
+      unsigned long long vc[2] = {0, 0};
+      HIP_TRY(ctx, hipMemcpyFromSymbol(vc, HIP_SYMBOL(otg_dbg_v4_cells), sizeof(vc)));
+      fprintf(stderr, "[otg] affine: LDS tiers finished %llu alignments over %llu visited cells (%.0f per alignment)\n", vc[1], vc[0], vc[1] ? (double)vc[0] / (double)vc[1] : 0.0);
+    }
     if (d_bound_dbg) {
       std::vector<int32_t> hb(n_tasks), hs(n_tasks);
       HIP_TRY(ctx, hipMemcpy(hb.data(), d_bound_dbg, (size_t)n_tasks * 4, hipMemcpyDeviceToHost));

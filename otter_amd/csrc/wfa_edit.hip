@@ -468,7 +468,15 @@ __global__ __launch_bounds__(256) void edit_route_kernel(
         if (fwd_ok) otg_sample64<false>(P, pl, T, tl, 96, &d1, &j1);
         if (rev_ok) otg_sample64<true>(P, pl, T, tl, 96, &d2, &j2);
         const int dlen = ef ? 0 : (pl > tl ? pl - tl : tl - pl);
-        float est = (float)(d1 + d2) * (float)(pl + tl) / (float)(128 + j1 + j2);
+        // the sampled rate (edits per row + column) times the rows + columns the alignment will cover: everything for a global
+        // alignment; with free ends on one sequence only, the other one twice (it is covered whole, the free-ended one by as much)
+        int extent = pl + tl;
+        if (ef) {
+          const bool pfree = t.pattern_begin_free > 0 || t.pattern_end_free > 0, tfree = t.text_begin_free > 0 || t.text_end_free > 0;
+          if (pfree && !tfree) extent = 2 * tl < extent ? 2 * tl : extent;
+          else if (tfree && !pfree) extent = 2 * pl < extent ? 2 * pl : extent;
+        }
+        float est = (float)(d1 + d2) * (float)extent / (float)(128 + j1 + j2);
         if (est > (float)(pl + tl)) est = (float)(pl + tl);
         int cap = (int)(cap_coeff * sqrtf((float)(pl > tl ? pl : tl)));
         if (cap < 48) cap = 48;
@@ -582,7 +590,9 @@ int otg_launch_edit_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_t
   HIP_TRY(ctx, hipMemsetAsync(rc, 0, 8 * sizeof(uint32_t), ctx->stream));
   static const bool no_myers = getenv("OTG_NO_MYERS") != nullptr;
   static const bool no_route = getenv("OTG_NO_EDIT_ROUTE") != nullptr;
-  static const float route_margin = getenv("OTG_EDIT_ROUTE_MARGIN") ? (float)atoi(getenv("OTG_EDIT_ROUTE_MARGIN")) / 100.0f : 1.0f;
+  // a tier that turns out too narrow costs about half of going one tier up straight away, so the cheapest choice sits a little below
+  // the median estimate (measured at config 1: 0.85-0.92 flat optimum; OTG_EDIT_ROUTE_MARGIN overrides, in percent)
+  static const float route_margin = getenv("OTG_EDIT_ROUTE_MARGIN") ? (float)atoi(getenv("OTG_EDIT_ROUTE_MARGIN")) / 100.0f : 0.88f;
   if (kernel_ms) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   {
     // with the bit-parallel tiers behind it this pass only has to hold wavefronts of ~2 x cap diagonals: 1024 diagonals

@@ -195,3 +195,50 @@ def test_edit_threshold_sweep(gpu, oracle):
     exp = oracle.edit_distance_batch(arena, tasks)
     bad = [(meta[i], int(got[i]), int(exp[i])) for i in range(len(pairs)) if got[i] != exp[i]]
     assert not bad, bad[:10]
+
+
+def test_edit_misleading_samples(gpu, oracle):
+    """The tier choice comes from two 64-base samples (first and last 64 bases of the pattern against the ends of the text).  Pairs
+    built to mislead it: identical ends around a divergent middle (looks near-identical), garbage ends around an identical middle
+    (looks hopeless), one good and one bad end, ends shifted by an indel run inside the sampled window, non-ACGT bytes in the
+    samples, lengths around the 160-base minimum of the sampler, one-sided free ends.  Every route must end in the exact distance."""
+    rng = np.random.default_rng(77)
+    pairs, forms = [], []
+    for i in range(240):
+        L = int(rng.integers(150, 2600)) if i % 6 else int(rng.choice([158, 159, 160, 161, 192, 255, 256, 257]))
+        core = rand_seq(rng, L)
+        kind = i % 8
+        a = core
+        if kind == 0:      # clean ends, divergent middle
+            b = core[:100] + mutate(rng, core[100:-100], 0.25) + core[-100:] if L > 260 else mutate(rng, core, 0.2)
+        elif kind == 1:    # garbage ends, identical middle
+            b = rand_seq(rng, 90) + core[90:-90] + rand_seq(rng, 90) if L > 260 else rand_seq(rng, L)
+        elif kind == 2:    # good left, bad right
+            b = core[:-120] + rand_seq(rng, 120) if L > 260 else core
+        elif kind == 3:    # bad left, good right
+            b = rand_seq(rng, 120) + core[120:] if L > 260 else core
+        elif kind == 4:    # indel run inside the sampled windows
+            g = int(rng.integers(5, 40))
+            b = core[:20] + rand_seq(rng, g) + core[20:-30] + core[-30 + min(g, 25):]
+        elif kind == 5:    # non-ACGT bytes in the samples
+            bb = bytearray(mutate(rng, core, 0.05))
+            for p in (3, 17, 40, len(bb) - 5, len(bb) - 33):
+                bb[p] = b"NnRy"[int(rng.integers(0, 4))]
+            b = bytes(bb)
+        elif kind == 6:    # homopolymer / short-period ends (every shift matches)
+            b = b"A" * 70 + mutate(rng, core[70:-70], 0.1) + b"CA" * 35 if L > 200 else core
+            a = b"A" * 80 + core[70:-70] + b"CA" * 30 if L > 200 else core
+        else:
+            b = mutate(rng, core, [0.01, 0.08, 0.3][(i // 8) % 3])
+        if len(b) > len(a):
+            a, b = b, a
+        f = None
+        if i % 5 == 0:
+            d = len(a) - len(b)
+            f = [(0, d, 0, 0), (d, 0, 0, 0)][(i // 5) % 2]
+        pairs.append((a, b))
+        forms.append(f)
+    arena, tasks = pair_tasks(pairs, forms)
+    gs = gpu.edit_distance_batch(arena, tasks)
+    es = oracle.edit_distance_batch(arena, tasks)
+    assert np.array_equal(gs, es), np.nonzero(gs != es)[0][:10]
