@@ -15,14 +15,19 @@
 // incoming-scan order = ascending source id (one edge per (source,sink) pair, so the source id alone orders
 // ties), first candidate always accepted; the end node is the lowest id among the heaviest ending nodes.
 // Damping is applied on the fly with the reference's FP32 operations (-ffp-contract=off).
-// v1 mapping: one thread per graph (graphs are independent and the threading is inherently sequential);
-// node initialisation is a separate fully parallel kernel.
 #include "otg_common.hpp"
 #include <vector>
 #include <cstdlib>
 #include <algorithm>
 
 namespace {
+
+// node / edge records: everything the heaviest-path sweep and the list walks need about a node (or an edge) comes with ONE load
+struct NodeG { float hw; int32_t pred; uint32_t indeg; int32_t head; };          // best weight, its source (-1 = none yet), in-degree, first extra out-edge;
+                                                                                  // while the graph is being built `pred` holds the LAST extra out-edge (list tail)
+struct EdgeG { uint32_t sink; float w; int32_t next; uint32_t base; };            // base = base of an alt-node sink (0 for backbone sinks)
+struct NodeL { float hw; int16_t pred; uint16_t indeg; int16_t head; uint16_t pad; };
+struct EdgeL { uint16_t sink; uint16_t w; int16_t next; uint16_t base; };
 
 struct PoaDev {
   const uint8_t* seq_arena;
@@ -35,16 +40,15 @@ struct PoaDev {
   const uint64_t* edge_off;   // [n_graphs+1]
   const uint64_t* start_off;  // [n_graphs+1]
   // node arrays
-  uint8_t* node_base; uint8_t* is_end; uint8_t* hdef;
-  int32_t* head; int32_t* tail; uint32_t* indeg; uint32_t* bb_cnt; float* hw; int32_t* pred; uint32_t* queue;
-  // edge arrays
-  uint32_t* e_sink; float* e_w; int32_t* e_next;
+  NodeG* nodes; uint8_t* node_base; uint8_t* is_end; uint32_t* bb_cnt; uint32_t* queue;
+  // edge array
+  EdgeG* edges;
   uint32_t* start_list;
   // outputs
   const uint64_t* out_off; uint32_t* out_len; uint8_t* out_arena; uint32_t* out_start; int32_t* status;
-  const uint32_t* order;      // graphs in decreasing order of work (longest first: shortest tail)
+  const uint32_t* order;      // launch lists: graphs for the LDS kernel, then graphs for the global-memory kernel (longest first each)
   unsigned long long* prof;   // OTG_POA_PROFILE: wall-clock ticks per phase, summed over graphs (null otherwise)
-  uint32_t* fb_list;          // graphs left to the global-memory kernel (too large for LDS, or outgrew the optimistic capacities)
+  uint32_t* fb_list;          // graphs left to the global-memory kernel by the LDS kernel (outgrew the optimistic capacities)
   uint32_t* fb_count;
 };
 
@@ -68,201 +72,68 @@ __global__ void poa_count_kernel(const uint8_t* __restrict__ cig_arena, const ot
   n_alt[m] = alt; n_mrun[m] = mrun;
 }
 
-// PPOA::init (src/anppoa.hpp:64-84), one block per graph
-__global__ void poa_init_kernel(PoaDev P)
-{
-  for (uint32_t g = blockIdx.x; g < P.n_graphs; g += gridDim.x) {
-    const otg_poa_graph G = P.graphs[g];
-    const uint64_t no = P.node_off[g];
-    const uint32_t B = G.backbone_len;
-    const uint8_t* bb = P.seq_arena + G.backbone_off;
-    const uint64_t cap = P.node_off[g + 1] - no;
-    for (uint64_t i = threadIdx.x; i < cap; i += blockDim.x) {
-      const bool isb = i < B && B >= 2;
-      P.node_base[no + i] = isb ? bb[i] : 0;
-      P.is_end[no + i] = (isb && i >= 1 && B - i <= 10) ? 1 : 0;
-      P.indeg[no + i] = (isb && i >= 1) ? 1u : 0u;
-      P.head[no + i] = -1; P.tail[no + i] = -1;
-      P.bb_cnt[no + i] = 0; P.hdef[no + i] = 0; P.hw[no + i] = 0.0f; P.pred[no + i] = -1;
-    }
-    if (threadIdx.x == 0 && B >= 2) P.start_list[P.start_off[g]] = 0;
-  }
-}
-
-__global__ __launch_bounds__(64) void poa_graph_kernel(PoaDev P)
-{
-  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= P.n_graphs) return;
-  const otg_poa_graph G = P.graphs[g];
-  const uint64_t no = P.node_off[g], eo = P.edge_off[g], so = P.start_off[g];
-  const uint32_t node_cap = (uint32_t)(P.node_off[g + 1] - no), edge_cap = (uint32_t)(P.edge_off[g + 1] - eo);
-  uint8_t* nbase = P.node_base + no; uint8_t* isend = P.is_end + no; uint8_t* hdef = P.hdef + no;
-  int32_t* head = P.head + no; int32_t* tail = P.tail + no; uint32_t* indeg = P.indeg + no; uint32_t* bbc = P.bb_cnt + no;
-  float* hw = P.hw + no; int32_t* pred = P.pred + no; uint32_t* queue = P.queue + no;
-  uint32_t* esink = P.e_sink + eo; float* ew = P.e_w + eo; int32_t* enext = P.e_next + eo;
-  uint32_t* starts = P.start_list + so;
-  const int B = (int)G.backbone_len;
-  uint32_t n_nodes = (uint32_t)B, n_edges = 0, n_start = B >= 2 ? 1u : 0u;
-  int status = 0;
-
-  auto new_node = [&](uint8_t base) -> uint32_t {
-    if (n_nodes >= node_cap) { status = 1; return n_nodes - 1; }
-    nbase[n_nodes] = base;
-    return n_nodes++;
-  };
-  auto insert_edge = [&](uint32_t src, uint32_t sink) {     // src/anppoa.hpp:96-110
-    if ((int)src < B - 1 && sink == src + 1) { atomicAdd(&bbc[src], 1u); return; }
-    for (int e = head[src]; e >= 0; e = enext[e]) if (esink[e] == sink) { ew[e] += 1.0f; return; }
-    if (n_edges >= edge_cap) { status = 2; return; }
-    const int e = (int)n_edges++;
-    esink[e] = sink; ew[e] = 1.0f; enext[e] = -1;
-    if (tail[src] >= 0) enext[tail[src]] = e; else head[src] = e;
-    tail[src] = e;
-    atomicAdd(&indeg[sink], 1u);
-  };
-  auto alt_step = [&](uint32_t prev, uint8_t tc) -> uint32_t {   // :162-186 / :206-233
-    for (int e = head[prev]; e >= 0; e = enext[e]) {
-      const uint32_t sk = esink[e];
-      if ((int)sk >= B && nbase[sk] == tc) { ew[e] += 1.0f; return sk; }
-    }
-    const uint32_t nn = new_node(tc);
-    if (!status) insert_edge(prev, nn);
-    return nn;
-  };
-
-  // ---- insert_alignment for every member, in order (src/anppoa.hpp:112-241)
-  for (uint32_t mi = 0; mi < G.n_members && !status; ++mi) {
-    const otg_poa_member M = P.members[G.first_member + mi];
-    const uint8_t* seq = P.seq_arena + M.seq_off;
-    const uint8_t* cig = P.cig_arena + M.cigar_off;
-    const int clen = (int)M.cigar_len, slen = (int)M.seq_len;
-    const bool spl = M.spanning_l != 0, spr = M.spanning_r != 0;
-    int prev = 0, ref_i = 0, tgt = 0, ci = 0;
-    bool first = true;
-    if (!spl) {
-      first = false;
-      while (ci < clen) {
-        const uint8_t c = cig[ci];
-        if (c != 'D' && c != 'I') break;
-        if (c == 'D') { ++ref_i; prev = ref_i; } else ++tgt;
-        ++ci;
-      }
-    }
-    while (ci < clen && !status) {
-      const uint8_t c = cig[ci];
-      if (c == 'M') {
-        if (first || prev == ref_i) first = false;
-        else if ((uint32_t)prev >= n_nodes) { status = 3; break; }    // the reference indexes edges[] out of range here
-        else insert_edge((uint32_t)prev, (uint32_t)ref_i);
-        prev = ref_i; ++ref_i; ++tgt;
-      } else if (c == 'X') {
-        const uint8_t tc = tgt < slen ? seq[tgt] : 0;
-        if (first) {
-          bool need_new = true;
-          for (uint32_t q = 0; q < n_start; ++q) if (nbase[starts[q]] == tc) { need_new = false; break; }
-          if (need_new) { prev = (int)new_node(tc); starts[n_start++] = (uint32_t)prev; }
-          first = false;
-        } else if ((uint32_t)prev >= n_nodes) { status = 3; break; }
-        else prev = (int)alt_step((uint32_t)prev, tc);
-        ++ref_i; ++tgt;
-      } else if (c == 'D') {
-        if (!first) ++ref_i; else { ++ref_i; prev = ref_i; }
-      } else if (c == 'I') {
-        const uint8_t tc = tgt < slen ? seq[tgt] : 0;
-        if (first) { prev = (int)new_node(tc); starts[n_start++] = (uint32_t)prev; first = false; }
-        else if ((uint32_t)prev >= n_nodes) { status = 3; break; }
-        else prev = (int)alt_step((uint32_t)prev, tc);
-        ++tgt;
-      }
-      if (B - ref_i <= 10 && spr && (uint32_t)prev < node_cap) isend[prev] = 1;   // ids not yet created are remembered too (std::set of ids)
-      ++ci;
-    }
-  }
-  __threadfence();   // bb_cnt / indeg atomics of this thread are visible to its own loads below
-
-  // ---- heaviest path: Kahn sweep pushing (weight, source) along out-edges
-  const float c_ = G.c, t_ = G.t;
-  auto damp = [&](float w) -> float {                      // adjust_weights :243-252
-    const float t_applied = t_ * w;
-    const float final_weight = c_ > t_applied ? c_ : t_applied;
-    return w - final_weight;
-  };
-  auto relax = [&](uint32_t u, uint32_t v, float w) {
-    const float cand = hw[u] + w;
-    if (!hdef[v]) { hdef[v] = 1; hw[v] = cand; pred[v] = (int32_t)u; }
-    else if (cand > hw[v] || (cand == hw[v] && (int32_t)u < pred[v])) { hw[v] = cand; pred[v] = (int32_t)u; }
-  };
-  uint32_t qh = 0, qt = 0;
-  if (!status) {
-    for (uint32_t i = 0; i < n_nodes; ++i) if (__hip_atomic_load(&indeg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) queue[qt++] = i;
-    while (qh < qt) {
-      const uint32_t u = queue[qh++];
-      if ((int)u < B - 1) {
-        const uint32_t v = u + 1;
-        const float w = damp(1.0f + (float)__hip_atomic_load(&bbc[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        relax(u, v, w);
-        const uint32_t left = __hip_atomic_load(&indeg[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1;
-        __hip_atomic_store(&indeg[v], left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (left == 0) queue[qt++] = v;
-      }
-      for (int e = head[u]; e >= 0; e = enext[e]) {
-        const uint32_t v = esink[e];
-        relax(u, v, damp(ew[e]));
-        const uint32_t left = __hip_atomic_load(&indeg[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1;
-        __hip_atomic_store(&indeg[v], left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (left == 0) queue[qt++] = v;
-      }
-    }
-    if (qt != n_nodes) status = 4;    // cycle: the reference would never return
-  }
-  // ---- pick the end node (:346-367) and emit the path (:373-378)
-  uint32_t len = 0, startpos = 0;
-  if (!status && n_nodes > 0) {
-    uint32_t h_node = 0; bool not_init = true; float best = 0.0f;
-    for (uint32_t i = 0; i < n_nodes; ++i) {
-      if (isend[i]) { const float w = hw[i]; if (not_init || w > best) { not_init = false; h_node = i; best = w; } }
-    }
-    uint8_t* out = P.out_arena + P.out_off[g];
-    const uint32_t cap = node_cap;
-    uint32_t pos = cap;
-    int32_t cur = (int32_t)h_node;
-    while (cur >= 0 && pos > 0) {
-      const uint8_t b = nbase[cur];
-      if (b) out[--pos] = b;
-      cur = pred[cur];
-    }
-    startpos = pos; len = cap - pos;
-  }
-  P.out_len[g] = len; P.out_start[g] = startpos; P.status[g] = status;
-}
-
-// v2 mapping: one WAVE per graph.  Everything that is sequential in the reference stays sequential but runs
+// Mapping: one WAVE per graph.  Everything that is sequential in the reference stays sequential but runs
 // wave-uniform (all lanes execute the same instruction on the same address: one memory request, no divergence);
 // the bulk of the threading is data-parallel: op strings are read 64 ops at a time, positions come from ballot
 // prefix counts, and an 'M' that follows an 'M' only bumps the implicit backbone edge ref-1 -> ref (distinct
 // addresses per lane), so only the ops around mismatches and gaps (15-35 % for ONT reads) take the serial path.
-// One wave owns a graph, so plain read-modify-writes replace the atomics of v1.
+// One wave owns a graph, so plain read-modify-writes need no atomics.
 //
-// The serial part is a chain of dependent loads (edge list walks, the Kahn sweep: ~4 us per node out of L2), so the
-// graph lives in LDS whenever it fits (LDS = true): 16-bit node / edge ids and counts, 19 bytes per node + 6 per edge —
-// a consensus window of otter (150-base backbone, 30 reads) needs about 8 KB.  The LDS capacities are optimistic (half of
-// the worst-case alt-node / edge bounds); a graph that outgrows them is queued for the global-memory instantiation
-// (LDS = false), which has the worst-case capacities and is also the path for graphs too large for 16-bit ids.
+// The serial part is a chain of dependent loads, so the data layout is built to keep the chain short: a node record
+// {weight, source, in-degree, first edge} and an edge record {sink, weight, next, sink base} are one 16-byte load each; the
+// Kahn sweep carries the record it has just written in registers (on a backbone run the next node IS that record) and
+// remembers its latest push instead of reading the queue back, so a backbone step needs one round of independent loads
+// (successor record + backbone count) where separate arrays needed four dependent ones; an op that follows an alt node
+// compares the base stored in the edge instead of loading the sink node.
+//
+// Small graphs live in LDS (LDS = true: 16-bit ids, 18 bytes per node + 8 per edge).  The LDS capacities are optimistic
+// (half of the worst-case alt-node / edge bounds); a graph that outgrows them is queued for the global-memory instantiation
+// (LDS = false), which has the worst-case capacities and is also the path for large graphs — otter's allele graphs
+// (~6200 nodes for a 3 kb allele) among them.
 #define OTG_LDS __attribute__((address_space(3)))
-template <bool LDS> struct PoaTypes;
-template <> struct PoaTypes<false> { using idx = int32_t; using cnt = uint32_t; using w = float; using f = float; using b = uint8_t; };
-template <> struct PoaTypes<true> {
-  using idx = OTG_LDS int16_t; using cnt = OTG_LDS uint16_t; using w = OTG_LDS uint16_t; using f = OTG_LDS float; using b = OTG_LDS uint8_t;
+template <bool LDS> struct PoaStore;
+template <> struct PoaStore<false> {
+  NodeG* nodes; EdgeG* edges;
+  uint8_t *nbase, *isend; uint32_t *bbc, *queue, *starts;
+  uint32_t node_cap, edge_cap; bool reduced;
+  __device__ __forceinline__ NodeG ldN(uint32_t i) const { return nodes[i]; }
+  __device__ __forceinline__ void stN(uint32_t i, const NodeG& n) const { nodes[i] = n; }
+  __device__ __forceinline__ void stList(uint32_t i, int head, int tail) const { nodes[i].head = head; nodes[i].pred = tail; }
+  __device__ __forceinline__ void stTail(uint32_t i, int tail) const { nodes[i].pred = tail; }
+  __device__ __forceinline__ void stPred(uint32_t i, int pr) const { nodes[i].pred = pr; }
+  __device__ __forceinline__ void incIndeg(uint32_t i) const { nodes[i].indeg = nodes[i].indeg + 1u; }
+  __device__ __forceinline__ void incIndegAtomic(uint32_t i) const { atomicAdd(&nodes[i].indeg, 1u); }
+  __device__ __forceinline__ float ldHw(uint32_t i) const { return nodes[i].hw; }
+  __device__ __forceinline__ int ldPred(uint32_t i) const { return nodes[i].pred; }
+  __device__ __forceinline__ EdgeG ldE(int e) const { return edges[e]; }
+  __device__ __forceinline__ void stE(int e, const EdgeG& x) const { edges[e] = x; }
+  __device__ __forceinline__ void stEw(int e, float w) const { edges[e].w = w; }
+  __device__ __forceinline__ void stEnext(int e, int nx) const { edges[e].next = nx; }
 };
-template <bool LDS> struct PoaStore {
-  typename PoaTypes<LDS>::b *nbase, *isend, *hdef;
-  typename PoaTypes<LDS>::idx *head, *tail, *pred, *enext;
-  typename PoaTypes<LDS>::cnt *indeg, *bbc, *queue, *esink, *starts;
-  typename PoaTypes<LDS>::w* ew;
-  typename PoaTypes<LDS>::f* hw;
-  uint32_t node_cap, edge_cap;      // capacities of THIS storage
-  bool reduced;                     // LDS: capacities below the worst-case bounds (overflow = retry in global memory)
+template <> struct PoaStore<true> {
+  OTG_LDS NodeL* nodes; OTG_LDS EdgeL* edges;
+  OTG_LDS uint8_t *nbase, *isend; OTG_LDS uint16_t *bbc, *queue, *starts;
+  uint32_t node_cap, edge_cap; bool reduced;
+  __device__ __forceinline__ NodeG ldN(uint32_t i) const { NodeG n; n.hw = nodes[i].hw; n.pred = nodes[i].pred; n.indeg = nodes[i].indeg; n.head = nodes[i].head; return n; }
+  __device__ __forceinline__ void stN(uint32_t i, const NodeG& n) const { nodes[i].hw = n.hw; nodes[i].pred = (int16_t)n.pred; nodes[i].indeg = (uint16_t)n.indeg; nodes[i].head = (int16_t)n.head; }
+  __device__ __forceinline__ void stList(uint32_t i, int head, int tail) const { nodes[i].head = (int16_t)head; nodes[i].pred = (int16_t)tail; }
+  __device__ __forceinline__ void stTail(uint32_t i, int tail) const { nodes[i].pred = (int16_t)tail; }
+  __device__ __forceinline__ void stPred(uint32_t i, int pr) const { nodes[i].pred = (int16_t)pr; }
+  __device__ __forceinline__ void incIndeg(uint32_t i) const { nodes[i].indeg = (uint16_t)(nodes[i].indeg + 1u); }
+  __device__ __forceinline__ void incIndegAtomic(uint32_t i) const { incIndeg(i); }     // not used: the LDS pass is wave-uniform
+  __device__ __forceinline__ float ldHw(uint32_t i) const { return nodes[i].hw; }
+  __device__ __forceinline__ int ldPred(uint32_t i) const { return nodes[i].pred; }
+  __device__ __forceinline__ EdgeG ldE(int e) const { EdgeG x; x.sink = edges[e].sink; x.w = (float)edges[e].w; x.next = edges[e].next; x.base = edges[e].base; return x; }
+  __device__ __forceinline__ void stE(int e, const EdgeG& x) const { edges[e].sink = (uint16_t)x.sink; edges[e].w = (uint16_t)x.w; edges[e].next = (int16_t)x.next; edges[e].base = (uint16_t)x.base; }
+  __device__ __forceinline__ void stEw(int e, float w) const { edges[e].w = (uint16_t)w; }
+  __device__ __forceinline__ void stEnext(int e, int nx) const { edges[e].next = (int16_t)nx; }
 };
+
+template <bool LDS> __device__ __forceinline__ void poa_phase_fence()
+{
+  if (LDS) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+  else __threadfence();
+}
 
 // returns false when the graph has to be redone with larger capacities (LDS only)
 template <bool LDS>
@@ -271,11 +142,7 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
   const int lane = threadIdx.x & 63;
   const otg_poa_graph G = P.graphs[g];
   const uint32_t node_cap = S.node_cap, edge_cap = S.edge_cap;
-  auto nbase = S.nbase; auto isend = S.isend; auto hdef = S.hdef;
-  auto head = S.head; auto tail = S.tail; auto indeg = S.indeg; auto bbc = S.bbc;
-  auto hw = S.hw; auto pred = S.pred; auto queue = S.queue;
-  auto esink = S.esink; auto ew = S.ew; auto enext = S.enext;
-  auto starts = S.starts;
+  auto nbase = S.nbase; auto isend = S.isend; auto bbc = S.bbc; auto queue = S.queue; auto starts = S.starts;
   const int B = (int)G.backbone_len;
   uint32_t n_nodes = (uint32_t)B, n_edges = 0, n_start = B >= 2 ? 1u : 0u;
   int status = 0;
@@ -289,38 +156,54 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
       const bool isb = (int)i < B && B >= 2;
       nbase[i] = isb ? bb[i] : (uint8_t)0;
       isend[i] = (isb && i >= 1 && B - (int)i <= 10) ? 1 : 0;
-      indeg[i] = (isb && i >= 1) ? 1 : 0;
-      head[i] = -1; tail[i] = -1;
-      bbc[i] = 0; hdef[i] = 0; hw[i] = 0.0f; pred[i] = -1;
+      NodeG n; n.hw = 0.0f; n.pred = -1; n.indeg = (isb && i >= 1) ? 1u : 0u; n.head = -1;
+      S.stN(i, n);              // pred = -1: empty extra-edge list (tail) for now
+      bbc[i] = 0;
     }
     if (B >= 2) starts[0] = 0;
-    if (LDS) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
-    else __threadfence();
+    poa_phase_fence<LDS>();
   }
 
+  // Extra out-edge list (head, tail) of a node.  Two ways around the dependent load: the lists of the node created last are
+  // still in registers (cn_*: a fresh node has none, and an op string that leaves the known graph keeps creating nodes), and the
+  // lists of the backbone node an op starts from are read for all 64 ops of a chunk at once (pf_* below).
+  uint32_t cn_id = 0xffffffffu; int cn_head = -1, cn_tail = -1;
+  auto node_lists = [&](uint32_t x, int& head, int& tail) {
+    if (x == cn_id) { head = cn_head; tail = cn_tail; }
+    else { const NodeG n = S.ldN(x); head = n.head; tail = n.pred; }
+  };
   auto new_node = [&](uint8_t base) -> uint32_t {
     if (n_nodes >= node_cap) { status = 1; return n_nodes - 1; }
     nbase[n_nodes] = base;
+    cn_id = n_nodes; cn_head = -1; cn_tail = -1;
     return n_nodes++;
   };
-  auto insert_edge = [&](uint32_t src, uint32_t sink) {     // src/anppoa.hpp:96-110
-    if ((int)src < B - 1 && sink == src + 1) { bbc[src] = bbc[src] + 1; return; }
-    for (int e = head[src]; e >= 0; e = enext[e]) if (esink[e] == sink) { ew[e] = ew[e] + 1; return; }
+  auto append_edge = [&](uint32_t src, int src_head, int src_tail, uint32_t sink, uint32_t sink_base) {
     if (n_edges >= edge_cap) { status = 2; return; }
     const int e = (int)n_edges++;
-    esink[e] = sink; ew[e] = 1; enext[e] = -1;
-    const int tl_ = tail[src];
-    if (tl_ >= 0) enext[tl_] = e; else head[src] = e;
-    tail[src] = e;
-    indeg[sink] = indeg[sink] + 1;
+    EdgeG x; x.sink = sink; x.w = 1.0f; x.next = -1; x.base = sink_base;
+    S.stE(e, x);
+    if (src_tail >= 0) { S.stEnext(src_tail, e); S.stTail(src, e); } else { src_head = e; S.stList(src, e, e); }
+    if (src == cn_id) { cn_head = src_head; cn_tail = e; }
+    // the sink's in-degree is counted in one pass over the edge array before the sweep (no read-modify-write on this path)
   };
-  auto alt_step = [&](uint32_t prev, uint8_t tc) -> uint32_t {   // :162-186 / :206-233
-    for (int e = head[prev]; e >= 0; e = enext[e]) {
-      const uint32_t sk = esink[e];
-      if ((int)sk >= B && nbase[sk] == tc) { ew[e] = ew[e] + 1; return sk; }
+  auto insert_edge = [&](uint32_t src, int src_head, int src_tail, uint32_t sink) {     // src/anppoa.hpp:96-110
+    if ((int)src < B - 1 && sink == src + 1) { bbc[src] = bbc[src] + 1; return; }
+    for (int e = src_head; e >= 0;) {
+      const EdgeG x = S.ldE(e);
+      if (x.sink == sink) { S.stEw(e, x.w + 1.0f); return; }
+      e = x.next;
+    }
+    append_edge(src, src_head, src_tail, sink, (int)sink >= B ? (uint32_t)nbase[sink] : 0u);
+  };
+  auto alt_step = [&](uint32_t prev, int prev_head, int prev_tail, uint8_t tc) -> uint32_t {   // :162-186 / :206-233
+    for (int e = prev_head; e >= 0;) {
+      const EdgeG x = S.ldE(e);
+      if ((int)x.sink >= B && x.base == (uint32_t)tc) { S.stEw(e, x.w + 1.0f); return x.sink; }
+      e = x.next;
     }
     const uint32_t nn = new_node(tc);
-    if (!status) insert_edge(prev, nn);
+    if (!status) append_edge(prev, prev_head, prev_tail, nn, tc);     // a fresh node: no edge to it can exist yet
     return nn;
   };
 
@@ -364,8 +247,13 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
         bbc[ref_at - 1] = bbc[ref_at - 1] + 1;
         if (B - (ref_at + 1) <= 10 && spr && (uint32_t)ref_at < node_cap) isend[ref_at] = 1;
       }
-      // the target base of every op travels with it (one coalesced read instead of a dependent load per serial op)
+      // the target base of every op travels with it (one coalesced read instead of a dependent load per serial op), and so do
+      // the edge lists of the backbone node it starts from when the op before it is an 'M' (prev = ref-1).  Reading them ahead is
+      // safe: along one op string every node is left at most once, and an op that leaves ref-1 earlier in this chunk (an 'I'
+      // at the same ref) makes the op before this one a non-'M'.
       const int tb = (valid && (isX || isI) && tgt_at < slen) ? (int)seq[tgt_at] : 0;
+      int pf_head = -1, pf_tail = -1;
+      if (valid && !simple && pc == 'M' && ref_at >= 1 && ref_at <= B) { const NodeG n = S.ldN((uint32_t)(ref_at - 1)); pf_head = n.head; pf_tail = n.pred; }
       unsigned long long todo = __ballot(valid && !simple);
       while (todo && !status) {
         const int l = (int)__builtin_ctzll(todo);
@@ -373,12 +261,20 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
         const int op = __builtin_amdgcn_readlane(c, l), pop = __builtin_amdgcn_readlane(pc, l);
         const int r = __builtin_amdgcn_readlane(ref_at, l);
         const uint8_t tc = (uint8_t)__builtin_amdgcn_readlane(tb, l);
-        if (pop == 'M') { prev = r - 1; first = false; }
+        bool have_lists = false;
+        int ph = -1, pt = -1;
+        if (pop == 'M') {
+          prev = r - 1; first = false;
+          if (r >= 1 && r <= B) { ph = __builtin_amdgcn_readlane(pf_head, l); pt = __builtin_amdgcn_readlane(pf_tail, l); have_lists = true; }
+        }
         int ref_after = r;
         if (op == 'M') {
           if (first || prev == r) first = false;
-          else if ((uint32_t)prev >= n_nodes) { status = 3; break; }    // the reference indexes edges[] out of range here
-          else insert_edge((uint32_t)prev, (uint32_t)r);
+          else if ((uint32_t)prev >= n_nodes || (uint32_t)r >= n_nodes) { status = 3; break; }    // the reference indexes its vectors out of range here
+          else {
+            if (!((int)prev < B - 1 && r == prev + 1) && !have_lists) node_lists((uint32_t)prev, ph, pt);
+            insert_edge((uint32_t)prev, ph, pt, (uint32_t)r);
+          }
           prev = r; ref_after = r + 1;
         } else if (op == 'X') {
           if (first) {
@@ -387,7 +283,10 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
             if (need_new) { prev = (int)new_node(tc); starts[n_start++] = (uint32_t)prev; }
             first = false;
           } else if ((uint32_t)prev >= n_nodes) { status = 3; break; }
-          else prev = (int)alt_step((uint32_t)prev, tc);
+          else {
+            if (!have_lists) node_lists((uint32_t)prev, ph, pt);
+            prev = (int)alt_step((uint32_t)prev, ph, pt, tc);
+          }
           ref_after = r + 1;
         } else if (op == 'D') {
           ref_after = r + 1;
@@ -395,7 +294,10 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
         } else if (op == 'I') {
           if (first) { prev = (int)new_node(tc); starts[n_start++] = (uint32_t)prev; first = false; }
           else if ((uint32_t)prev >= n_nodes) { status = 3; break; }
-          else prev = (int)alt_step((uint32_t)prev, tc);
+          else {
+            if (!have_lists) node_lists((uint32_t)prev, ph, pt);
+            prev = (int)alt_step((uint32_t)prev, ph, pt, tc);
+          }
         }
         if (B - ref_after <= 10 && spr && (uint32_t)prev < node_cap) isend[prev] = 1;   // ids not yet created are remembered too
       }
@@ -406,48 +308,57 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
       ci += 64;
     }
   }
-  if (LDS) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
-  else __threadfence();
+  poa_phase_fence<LDS>();
   if (LDS && S.reduced && (status == 1 || status == 2)) return false;     // outgrew the optimistic LDS capacities
   const unsigned long long t1 = P.prof ? wall_clock64() : 0ull;
 
-  // ---- heaviest path: Kahn sweep pushing (weight, source) along out-edges (wave-uniform)
+  // ---- heaviest path: Kahn sweep pushing (weight, source) along out-edges (wave-uniform).  The result does not depend on the
+  // order in which ready nodes are taken (max weight, ties to the lowest source id), so the queue is only a work list.
   const float c_ = G.c, t_ = G.t;
   auto damp = [&](float w) -> float {                      // adjust_weights :243-252
     const float t_applied = t_ * w;
     const float final_weight = c_ > t_applied ? c_ : t_applied;
     return w - final_weight;
   };
-  auto relax = [&](uint32_t u, uint32_t v, float w) {
-    const float cand = hw[u] + w;
-    if (!hdef[v]) { hdef[v] = 1; hw[v] = cand; pred[v] = (int32_t)u; }
-    else if (cand > hw[v] || (cand == hw[v] && (int32_t)u < (int32_t)pred[v])) { hw[v] = cand; pred[v] = (int32_t)u; }
-  };
   uint32_t qh = 0, qt = 0;
   if (!status) {
+    for (uint32_t i = (uint32_t)lane; i < n_nodes; i += 64) S.stPred(i, -1);      // the list tails have done their job
+    poa_phase_fence<LDS>();
+    // in-degrees of the extra edges (the backbone in-edge was counted at init)
+    if (LDS) { for (uint32_t e = 0; e < n_edges; ++e) S.incIndeg(S.ldE((int)e).sink); }
+    else { for (uint32_t e = (uint32_t)lane; e < n_edges; e += 64) S.incIndegAtomic(S.ldE((int)e).sink); }
+    poa_phase_fence<LDS>();
     for (uint32_t b0 = 0; b0 < n_nodes; b0 += 64) {
       const uint32_t i = b0 + (uint32_t)lane;
-      const bool z = i < n_nodes && indeg[i] == 0;
+      const bool z = i < n_nodes && S.ldN(i).indeg == 0;
       const unsigned long long zm = __ballot(z);
       if (z) queue[qt + __builtin_popcountll(zm & lt)] = i;
       qt += (uint32_t)__builtin_popcountll(zm);
     }
-    if (LDS) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+    poa_phase_fence<LDS>();
+    uint32_t pushed_val = 0, pushed_at = 0xffffffffu;      // the latest push, so that a chain never reads the queue back
+    NodeG rv; rv.hw = 0.0f; rv.pred = -1; rv.indeg = 0; rv.head = -1;
+    uint32_t rv_id = 0xffffffffu;                          // rv = the record last written (node rv_id)
+    auto relax_into = [&](uint32_t u, float hw_u, uint32_t v, float w) {
+      NodeG nv = v == rv_id ? rv : S.ldN(v);
+      const float cand = hw_u + w;
+      if (nv.pred < 0) { nv.hw = cand; nv.pred = (int32_t)u; }
+      else if (cand > nv.hw || (cand == nv.hw && (int32_t)u < nv.pred)) { nv.hw = cand; nv.pred = (int32_t)u; }
+      nv.indeg = nv.indeg - 1u;
+      S.stN(v, nv);
+      rv = nv; rv_id = v;
+      if (nv.indeg == 0) { queue[qt] = v; pushed_val = v; pushed_at = qt; ++qt; }
+    };
     while (qh < qt) {
-      const uint32_t u = queue[qh++];
-      if ((int)u < B - 1) {
-        const uint32_t v = u + 1;
-        relax(u, v, damp(1.0f + (float)bbc[u]));
-        const uint32_t left = indeg[v] - 1;
-        indeg[v] = left;
-        if (left == 0) queue[qt++] = v;
-      }
-      for (int e = head[u]; e >= 0; e = enext[e]) {
-        const uint32_t v = esink[e];
-        relax(u, v, damp((float)ew[e]));
-        const uint32_t left = indeg[v] - 1;
-        indeg[v] = left;
-        if (left == 0) queue[qt++] = v;
+      const uint32_t u = qh == pushed_at ? pushed_val : (uint32_t)queue[qh];
+      ++qh;
+      const NodeG nu = u == rv_id ? rv : S.ldN(u);
+      // NOTE: pred < 0 doubles as "no weight yet" (hdef of the reference); start nodes keep hw = 0 and are never relaxed into
+      if ((int)u < B - 1) relax_into(u, nu.hw, u + 1, damp(1.0f + (float)bbc[u]));
+      for (int e = nu.head; e >= 0;) {
+        const EdgeG x = S.ldE(e);
+        relax_into(u, nu.hw, x.sink, damp(x.w));
+        e = x.next;
       }
     }
     if (qt != n_nodes) status = 4;    // cycle: the reference would never return
@@ -456,10 +367,10 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
   const unsigned long long t2 = P.prof ? wall_clock64() : 0ull;
   uint32_t len = 0, startpos = 0;
   if (!status && n_nodes > 0) {
-    if (LDS) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+    poa_phase_fence<LDS>();
     float bw = 0.0f; uint32_t bi = 0xffffffffu;
     for (uint32_t i = (uint32_t)lane; i < n_nodes; i += 64) {
-      if (isend[i]) { const float w = hw[i]; if (bi == 0xffffffffu || w > bw) { bw = w; bi = i; } }
+      if (isend[i]) { const float w = S.ldHw(i); if (bi == 0xffffffffu || w > bw) { bw = w; bi = i; } }
     }
     for (int off = 32; off > 0; off >>= 1) {
       const float ow = __shfl_xor(bw, off); const uint32_t oi = (uint32_t)__shfl_xor((int)bi, off);
@@ -475,9 +386,9 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
       while (cur >= 0 && k < cap && k < node_cap) {
         const uint8_t b = nbase[cur];
         if (b) queue[k++] = b;
-        cur = pred[cur];
+        cur = S.ldPred((uint32_t)cur);
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+      poa_phase_fence<LDS>();
       for (uint32_t j = (uint32_t)lane; j < k; j += 64) out[cap - 1 - j] = (uint8_t)queue[j];
       startpos = cap - k; len = k;
     } else {
@@ -485,7 +396,7 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
       while (cur >= 0 && pos > 0) {
         const uint8_t b = nbase[cur];
         if (b) out[--pos] = b;
-        cur = pred[cur];
+        cur = S.ldPred((uint32_t)cur);
       }
       startpos = pos; len = cap - pos;
     }
@@ -502,6 +413,7 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
 
 // LDS instantiation: one single-wave block per graph (the dispatcher refills the slot as soon as its graph is done); a graph
 // that does not fit, or outgrows its optimistic capacities, goes onto the list of the global-memory kernel below.
+constexpr uint32_t POA_LDS_NODE_B = 18, POA_LDS_EDGE_B = 8;      // NodeL 12 + bbc 2 + queue 2 + base 1 + end 1; EdgeL 8
 __global__ __launch_bounds__(64) void poa_graph_lds_kernel(PoaDev P, uint32_t lds_bytes)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t s_graph[];
@@ -519,10 +431,10 @@ __global__ __launch_bounds__(64) void poa_graph_lds_kernel(PoaDev P, uint32_t ld
   if (fits) {
     const uint32_t avail = lds_bytes - start_b - 32u;
     const float estN = (float)B + 0.5f * (float)(ncap_true - B) + 4.0f, estE = 0.5f * (float)ecap_true + 4.0f;
-    const float f = (float)avail / (19.0f * estN + 6.0f * estE);
+    const float f = (float)avail / ((float)POA_LDS_NODE_B * estN + (float)POA_LDS_EDGE_B * estE);
     N = (uint32_t)(estN * f) & ~3u; E = (uint32_t)(estE * f) & ~1u;
-    if (N >= ncap_true) { N = ncap_true; E = ((avail - 19u * N) / 6u) & ~1u; }     // node arrays at their bound: edges take the rest
-    if (E >= ecap_true) { E = ecap_true; const uint32_t n2 = ((avail - 6u * E) / 19u) & ~3u; N = n2 < ncap_true ? n2 : ncap_true; }
+    if (N >= ncap_true) { N = ncap_true; E = ((avail - POA_LDS_NODE_B * N) / POA_LDS_EDGE_B) & ~1u; }     // node arrays at their bound: edges take the rest
+    if (E >= ecap_true) { E = ecap_true; const uint32_t n2 = ((avail - POA_LDS_EDGE_B * E) / POA_LDS_NODE_B) & ~3u; N = n2 < ncap_true ? n2 : ncap_true; }
     reduced = N < ncap_true || E < ecap_true;
     fits = N >= B + 2u && f >= 1.0f;
   }
@@ -532,20 +444,13 @@ __global__ __launch_bounds__(64) void poa_graph_lds_kernel(PoaDev P, uint32_t ld
   }
   PoaStore<true> S;
   uint32_t o = 0;
-  S.hw = (OTG_LDS float*)(s_graph + o); o += 4u * N;
-  S.head = (OTG_LDS int16_t*)(s_graph + o); o += 2u * N;
-  S.tail = (OTG_LDS int16_t*)(s_graph + o); o += 2u * N;
-  S.pred = (OTG_LDS int16_t*)(s_graph + o); o += 2u * N;
-  S.indeg = (OTG_LDS uint16_t*)(s_graph + o); o += 2u * N;
+  S.nodes = (OTG_LDS NodeL*)(s_graph + o); o += 12u * N;
+  S.edges = (OTG_LDS EdgeL*)(s_graph + o); o += 8u * E;
   S.bbc = (OTG_LDS uint16_t*)(s_graph + o); o += 2u * N;
   S.queue = (OTG_LDS uint16_t*)(s_graph + o); o += 2u * N;
   S.nbase = (OTG_LDS uint8_t*)(s_graph + o); o += N;
   S.isend = (OTG_LDS uint8_t*)(s_graph + o); o += N;
-  S.hdef = (OTG_LDS uint8_t*)(s_graph + o); o += N;
   o = (o + 3u) & ~3u;
-  S.esink = (OTG_LDS uint16_t*)(s_graph + o); o += 2u * E;
-  S.ew = (OTG_LDS uint16_t*)(s_graph + o); o += 2u * E;
-  S.enext = (OTG_LDS int16_t*)(s_graph + o); o += 2u * E;
   S.starts = (OTG_LDS uint16_t*)(s_graph + o);
   S.node_cap = N; S.edge_cap = E; S.reduced = reduced;
   if (!poa_graph_body<true>(P, g, S, ncap_true)) {
@@ -563,10 +468,8 @@ __global__ __launch_bounds__(64, 8) void poa_graph_wave_kernel(PoaDev P, const u
     if (g >= P.n_graphs) continue;
     const uint64_t no = P.node_off[g], eo = P.edge_off[g];
     PoaStore<false> S;
-    S.nbase = P.node_base + no; S.isend = P.is_end + no; S.hdef = P.hdef + no;
-    S.head = P.head + no; S.tail = P.tail + no; S.indeg = P.indeg + no; S.bbc = P.bb_cnt + no;
-    S.hw = P.hw + no; S.pred = P.pred + no; S.queue = P.queue + no;
-    S.esink = P.e_sink + eo; S.ew = P.e_w + eo; S.enext = P.e_next + eo;
+    S.nodes = P.nodes + no; S.edges = P.edges + eo;
+    S.nbase = P.node_base + no; S.isend = P.is_end + no; S.bbc = P.bb_cnt + no; S.queue = P.queue + no;
     S.starts = P.start_list + P.start_off[g];
     S.node_cap = (uint32_t)(P.node_off[g + 1] - no); S.edge_cap = (uint32_t)(P.edge_off[g + 1] - eo); S.reduced = false;
     poa_graph_body<false>(P, g, S, S.node_cap);
@@ -613,24 +516,16 @@ int otg_launch_poa(otg_ctx* ctx, const uint8_t* d_seq_arena, const uint8_t* d_ci
   uint64_t* d_start_off = (uint64_t*)otg_slot(ctx, SLOT_P2, (size_t)(n_graphs + 1) * sizeof(uint64_t));
   P.node_base = (uint8_t*)otg_slot(ctx, SLOT_P3, NN);
   P.is_end = (uint8_t*)otg_slot(ctx, SLOT_P4, NN);
-  P.hdef = (uint8_t*)otg_slot(ctx, SLOT_P5, NN);
-  P.head = (int32_t*)otg_slot(ctx, SLOT_P6, NN * 4);
-  P.tail = (int32_t*)otg_slot(ctx, SLOT_P7, NN * 4);
-  P.indeg = (uint32_t*)otg_slot(ctx, SLOT_P8, NN * 4);
+  P.nodes = (NodeG*)otg_slot(ctx, SLOT_P6, NN * sizeof(NodeG));
   P.bb_cnt = (uint32_t*)otg_slot(ctx, SLOT_P9, NN * 4);
-  P.hw = (float*)otg_slot(ctx, SLOT_P10, NN * 4);
-  P.pred = (int32_t*)otg_slot(ctx, SLOT_P11, NN * 4);
   P.queue = (uint32_t*)otg_slot(ctx, SLOT_P12, NN * 4);
-  P.e_sink = (uint32_t*)otg_slot(ctx, SLOT_P13, NE * 4);
-  P.e_w = (float*)otg_slot(ctx, SLOT_P14, NE * 4);
-  P.e_next = (int32_t*)otg_slot(ctx, SLOT_P15, NE * 4);
+  P.edges = (EdgeG*)otg_slot(ctx, SLOT_P13, NE * sizeof(EdgeG));
   P.start_list = (uint32_t*)otg_slot(ctx, SLOT_P16, NS * 4);
   P.out_arena = (uint8_t*)otg_slot(ctx, SLOT_P17, NN);
   P.out_start = (uint32_t*)otg_slot(ctx, SLOT_P29, (size_t)n_graphs * 4);
   P.status = (int32_t*)otg_slot(ctx, SLOT_P28, (size_t)n_graphs * 4);
-  if (!d_node_off || !d_edge_off || !d_start_off || !P.node_base || !P.is_end || !P.hdef || !P.head || !P.tail || !P.indeg ||
-      !P.bb_cnt || !P.hw || !P.pred || !P.queue || !P.e_sink || !P.e_w || !P.e_next || !P.start_list || !P.out_arena ||
-      !P.out_start || !P.status)
+  if (!d_node_off || !d_edge_off || !d_start_off || !P.node_base || !P.is_end || !P.nodes || !P.bb_cnt || !P.queue ||
+      !P.edges || !P.start_list || !P.out_arena || !P.out_start || !P.status)
     return OTG_ERR_HIP;
   P.node_off = d_node_off; P.edge_off = d_edge_off; P.start_off = d_start_off;
   P.out_off = d_node_off;     // consensus g is written into [node_off[g], node_off[g+1]) of out_arena
@@ -647,7 +542,7 @@ int otg_launch_poa(otg_ctx* ctx, const uint8_t* d_seq_arena, const uint8_t* d_ci
     for (uint32_t g = 0; g < n_graphs; ++g) {
       if (h_graphs[g].backbone_len == 0 && h_graphs[g].n_members == 0) continue;
       const double B = (double)h_graphs[g].backbone_len, ncap = (double)(node_off[g + 1] - node_off[g]), ecap = (double)(edge_off[g + 1] - edge_off[g]);
-      const double need = 19.0 * (B + 0.5 * (ncap - B) + 4.0) + 6.0 * (0.5 * ecap + 4.0) + (double)((2u * (h_graphs[g].n_members + 2u) + 7u) & ~7u) + 32.0 + 64.0;
+      const double need = (double)POA_LDS_NODE_B * (B + 0.5 * (ncap - B) + 4.0) + (double)POA_LDS_EDGE_B * (0.5 * ecap + 4.0) + (double)((2u * (h_graphs[g].n_members + 2u) + 7u) & ~7u) + 32.0 + 64.0;
       est[g] = need > 4.0e9 ? 0xffffffffu : (uint32_t)need;
       live.push_back(g);
     }
@@ -694,12 +589,7 @@ int otg_launch_poa(otg_ctx* ctx, const uint8_t* d_seq_arena, const uint8_t* d_ci
   P.fb_list = (uint32_t*)otg_slot(ctx, SLOT_P22, (size_t)(n_graphs + 1) * sizeof(uint32_t));
   if (!P.fb_list) return OTG_ERR_HIP;
   P.fb_count = P.fb_list + n_graphs;
-  static const bool thread_per_graph = getenv("OTG_POA_THREAD") != nullptr;
-  if (thread_per_graph) {
-    uint32_t gi = n_graphs < (uint32_t)ctx->n_cu * 8 ? n_graphs : (uint32_t)ctx->n_cu * 8;
-    hipLaunchKernelGGL(poa_init_kernel, dim3(gi), dim3(256), 0, ctx->stream, P);
-    hipLaunchKernelGGL(poa_graph_kernel, dim3((n_graphs + 63) / 64), dim3(64), 0, ctx->stream, P);
-  } else {
+  {
     // one single-wave block per graph: the dispatcher refills a wave slot as soon as its graph is done
     if (n_glob) hipLaunchKernelGGL(poa_graph_wave_kernel, dim3(n_glob), dim3(64), 0, ctx->stream, P, P.order + n_lds, (const uint32_t*)nullptr, n_glob);
     if (n_lds) {

@@ -1,6 +1,6 @@
 """GPU parity of the alternative kernel paths.  The library picks its tier chains by itself; environment switches
 (read once per process) force the fallback chains — un-bounded affine pass, HBM-ring affine tiers, wavefront-only edit
-distance, un-routed / un-sorted bit-parallel tiers, thread-per-graph POA, POA graphs in global memory only.  Every chain must be bit-exact, so the
+distance, un-routed / un-sorted bit-parallel tiers, POA graphs in global memory only.  Every chain must be bit-exact, so the
 aligner / POA parity tests are re-run in a child process per switch."""
 import os
 import subprocess
@@ -19,7 +19,6 @@ CASES = [
     ("OTG_NO_EDIT_ROUTE", ["tests/test_gpu_edit.py"]),
     ("OTG_NO_EDIT_SORT", ["tests/test_gpu_edit.py"]),
     ("OTG_NO_EDIT_SAMPLE", ["tests/test_gpu_edit.py"]),
-    ("OTG_POA_THREAD", ["tests/test_gpu_poa.py"]),
     ("OTG_POA_NO_LDS", ["tests/test_gpu_poa.py"]),
 ]
 
