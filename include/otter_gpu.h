@@ -286,6 +286,38 @@ int  otg_emit_reads(const otg_bed* beds, const char* chr_arena, uint32_t n_regio
                     const char* read_group, int is_fasta, int32_t max_cov, char* out, uint64_t out_capacity, uint64_t* out_len);
 
 /* ---------------------------------------------------------------------------------------------
+ * `otter genotype` ingest: the allele BAM written by `otter assemble`.
+ * ------------------------------------------------------------------------------------------- */
+/* SampleIndex::init (src/anbamdb.cpp:10-63): sample names = the `@RG ID:` values in header order (everything after "ID:",
+ * as the reference takes it), offsets from `@PG ID:otter OF:l,r` (defaults 1, 0).  Errors as the reference's exit(1) cases. */
+int  otg_bam_sample_index(otg_bam* bam, uint32_t* n_samples, int32_t* offset_l, int32_t* offset_r);
+const char* otg_bam_sample(const otg_bam* bam, uint32_t i);      /* valid after otg_bam_sample_index */
+/* parse_analleles (src/anseqs.cpp:462-524) per BED region: the records whose `ta` tag equals "chr:start-end", in file order, as
+ * otg_allele records (seq, sc/ac/tc, se, ic, PS/HP; .region = region index, .label = SAMPLE index of the RG tag; an unknown
+ * read group is the reference's exit(1): OTG_ERR_ARG).  With a FASTA handle the reference allele of genotype_process
+ * (src/genotype.cpp:92-101: bases [start - offset_l, end + offset_r - 1], sample index = n_samples) is appended to every
+ * non-empty region.  first_allele has n_regions + 1 entries (in-out counter *n_alleles is the running total). */
+int  otg_ingest_alleles(otg_bam* bam, const otg_bed* beds, const char* chr_arena, uint32_t n_regions, int32_t threads,
+                        const struct otg_fasta* reference, uint8_t* arena, uint64_t arena_capacity, uint64_t* arena_used,
+                        otg_allele* alleles, uint32_t alleles_capacity, uint32_t* n_alleles, uint32_t* first_allele);
+
+/* `otter genotype` record emit.  The header: output_vcf_header (src/genotype.cpp:16-40; contigs = BAM targets,
+ * one column per sample of otg_bam_sample_index).  The lines: per region with alleles, genotype numbers re-centred on the reference
+ * allele (src/genotype.cpp:139-150) and output_vcf_line (:43-78) — alleles / first_allele as otg_ingest_alleles delivers them with a
+ * reference (reference allele last in every region, .label = sample index, n_samples = number of real samples); gt / hsd / n_gt /
+ * reps exactly as otg_genotype_cluster_batch returns them (per allele, per region, region-local representative indices at
+ * reps + first_allele[r]).  Without a reference `otter genotype` prints the shorter and longer allele length per sample instead
+ * (src/genotype.cpp:112-121): otg_emit_genotype_lengths.  Same buffer protocol as otg_emit_alleles. */
+int  otg_emit_vcf_header(const otg_bam* bam, char* out, uint64_t out_capacity, uint64_t* out_len);
+int  otg_emit_vcf_lines(const otg_bed* beds, const char* chr_arena, uint32_t n_regions, const uint32_t* first_allele,
+                        const otg_allele* alleles, const uint8_t* seqs, uint32_t n_samples, const int32_t* gt, const double* hsd,
+                        const int32_t* n_gt, const int32_t* reps, int32_t offset_l, int32_t offset_r,
+                        char* out, uint64_t out_capacity, uint64_t* out_len);
+int  otg_emit_genotype_lengths(const otg_bam* bam, const otg_bed* beds, const char* chr_arena, uint32_t n_regions,
+                               const uint32_t* first_allele, const otg_allele* alleles, uint32_t n_samples,
+                               char* out, uint64_t out_capacity, uint64_t* out_len);
+
+/* ---------------------------------------------------------------------------------------------
  * The two text inputs beside the BAM: the BED file of regions and the indexed FASTA the reference
  * flanks of local_realignment come from.  Host code.
  * ------------------------------------------------------------------------------------------- */

@@ -1498,4 +1498,82 @@ uint64_t oto_emit_sam_header(const char* name_arena, const uint64_t* name_off, c
   return t.size();
 }
 
+/* `otter genotype` text, restated from src/genotype.cpp:16-78,103-157 with the reference's own stream inserts.
+ * PARITY UNPINNED by a reference build: genotype.cpp includes the WFA2-lib bindings header, which /root/reference does not hold, so
+ * output_vcf_line cannot be compiled here; the genotype numbers it prints are pinned separately (G4 golden of anallele_cluster). */
+uint64_t oto_emit_vcf_header(const char* name_arena, const uint64_t* name_off, const uint32_t* name_len, const uint64_t* target_len, uint32_t n_targets,
+                             const char* sample_arena, const uint64_t* sample_off, const uint32_t* sample_len, uint32_t n_samples, char* out, uint64_t cap)
+{
+  std::ostringstream os;
+  os << "##fileformat=VCFv4.2\n";
+  for (uint32_t i = 0; i < n_targets; ++i) os << "##contig=<ID=" << std::string(name_arena + name_off[i], name_len[i]) << ",length=" << target_len[i] << ">\n";
+  os << "##INFO=<ID=HSD,Number=R,Type=Float,Description=\"Hill-Shannon Diversity Metric\">\n"
+     << "##ALT=<ID=DEL,Description=\"Deletion\">\n"
+     << "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n"
+     << "##FORMAT=<ID=PS,Number=1,Type=Integer,Description=\"Phase Set\">\n"
+     << "##FORMAT=<ID=HP,Number=1,Type=Integer,Description=\"Haplotype Identifier\">\n"
+     << "##FORMAT=<ID=TC,Number=1,Type=Integer,Description=\"Total Coverage of Region\">\n"
+     << "##FORMAT=<ID=AC,Number=2,Type=Integer,Description=\"Total Coverage For Each Allele\">\n"
+     << "##FORMAT=<ID=SC,Number=2,Type=Integer,Description=\"Total Coverage of Spanning Reads For Each Allele\">\n"
+     << "##FORMAT=<ID=SE,Number=2,Type=Float,Description=\"Standard Mean Error of Spanning Reads For Each Allele\">\n";
+  os << "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT";
+  for (uint32_t i = 0; i < n_samples; ++i) os << '\t' << std::string(sample_arena + sample_off[i], sample_len[i]);
+  os << '\n';
+  const std::string t = os.str();
+  if (out && cap) memcpy(out, t.data(), std::min<uint64_t>(cap, t.size()));
+  return t.size();
+}
+
+uint64_t oto_emit_vcf_lines(const otg_bed* beds, const char* chr_arena, uint32_t n_regions, const uint32_t* first_allele, const otg_allele* alleles,
+                            const uint8_t* seqs, uint32_t n_samples, const int32_t* gt, const double* hsd, const int32_t* n_gt, const int32_t* reps,
+                            int32_t offset_l, int32_t offset_r, char* out, uint64_t cap)
+{
+  (void)offset_r;
+  std::ostringstream os;
+  for (uint32_t r = 0; r < n_regions; ++r) {
+    const uint32_t a0 = first_allele[r], na = first_allele[r + 1] - a0;
+    if (na == 0) continue;
+    const int ref_allele_index = (int)na - 1;
+    /* sample2localindeces (:103-110); the last entry is the internal reference sample */
+    std::vector<std::pair<int, int>> local(n_samples + 1, std::make_pair(-1, -1));
+    for (int i = 0; i < (int)na; ++i) {
+      auto& p = local[(size_t)alleles[a0 + i].label];
+      if (p.first < 0) p = std::make_pair(i, i);
+      else { if (i < p.first) p.first = i; else if (i > p.second) p.second = i; }
+    }
+    std::vector<int> genotypes(gt + a0, gt + a0 + na);
+    std::vector<int> gt_reps(reps + a0, reps + a0 + n_gt[r]);
+    const int ref_gt = genotypes[(size_t)ref_allele_index];
+    std::vector<int> centered = gt_reps;                                            /* :139-143 */
+    for (int i = 0; i < (int)centered.size(); ++i) { if (i == 0) centered[0] = ref_allele_index; else if (i <= ref_gt) centered[(size_t)i] = gt_reps[(size_t)i - 1]; }
+    for (uint32_t i = 0; i < na; ++i) { if (genotypes[i] == ref_gt) genotypes[i] = 0; else if (genotypes[i] < ref_gt) ++genotypes[i]; }   /* :145-148 */
+    auto seq_of = [&](int i) { return std::string((const char*)seqs + alleles[a0 + i].seq_off, alleles[a0 + i].seq_len); };
+    const std::string chr(chr_arena + beds[r].chr_off, beds[r].chr_len);
+    const uint32_t start = (uint32_t)beds[r].start, end = (uint32_t)beds[r].end;
+    /* output_vcf_line :43-78 */
+    os << chr << '\t' << (1 + start - offset_l) << '\t' << (chr + ":" + std::to_string(start) + "-" + std::to_string(end)) << '\t' << seq_of(ref_allele_index) << '\t';
+    if (centered.size() == 1) os << '.';
+    else for (uint32_t i = 1; i < centered.size(); ++i) {
+      if (i > 1) os << ',';
+      if (seq_of(centered[i]) == "N") os << "<DEL>"; else os << seq_of(centered[i]);
+    }
+    os << "\t.\t.\tHSD=";
+    for (uint32_t i = 0; i < centered.size(); ++i) { if (i > 0) os << ','; os << hsd[a0 + (uint32_t)centered[i]]; }
+    os << "\tGT:PS:HP:TC:AC:SC:SE";
+    for (uint32_t i = 0; i < local.size() - 1; ++i) {
+      if (local[i].first < 0) os << "\t./.:.:.:.:.:.:.";
+      else {
+        const otg_allele& a1 = alleles[a0 + (uint32_t)local[i].first];
+        const otg_allele& a2 = alleles[a0 + (uint32_t)local[i].second];
+        os << '\t' << genotypes[(size_t)local[i].first] << '/' << genotypes[(size_t)local[i].second] << ':' << a1.ps << ':' << a1.hp << ':' << a1.tcov << ':' << a1.acov << ','
+           << a2.acov << ':' << a1.scov << ',' << a2.scov << ':' << a1.se << ',' << a2.se;
+      }
+    }
+    os << '\n';
+  }
+  const std::string t = os.str();
+  if (out && cap) memcpy(out, t.data(), std::min<uint64_t>(cap, t.size()));
+  return t.size();
+}
+
 } /* extern "C" */

@@ -11,6 +11,7 @@
 #include "anbed.hpp"
 #include "anbamfilehelper.hpp"
 #include "anfahelper.hpp"
+#include "anbamdb.hpp"
 #include "otter_opts.hpp"
 #include "sam.h"
 #include "faidx.h"
@@ -169,6 +170,53 @@ int64_t ref_parse_bed_file(const char* path, char* out, uint64_t cap)
   for (const BED& b : v) t += b.toString() + "\n";
   if (out && cap) memcpy(out, t.data(), t.size() < cap ? t.size() : cap);
   return (int64_t)t.size();
+}
+
+// SampleIndex::init (src/anbamdb.cpp:42-63) -> "offset_l\toffset_r\n" then one sample name per line
+int64_t ref_sample_index(const char* bam_path, char* out, uint64_t cap)
+{
+  SampleIndex si;
+  si.init(bam_path);
+  std::string t = std::to_string(si.offset_l) + "\t" + std::to_string(si.offset_r) + "\n";
+  for (const auto& nm : si.index2sample) t += nm + "\n";
+  if (out && cap) memcpy(out, t.data(), t.size() < cap ? t.size() : cap);
+  return (int64_t)t.size();
+}
+
+// parse_analleles (src/anseqs.cpp:513-524) for one region + the reference allele genotype_process appends (src/genotype.cpp:92-101),
+// in the layout of otg_ingest_alleles.  Returns the number of alleles, -1 / -2 on overflow.
+int64_t ref_ingest_alleles(void* hnd, const char* bam_path, const char* chr, uint32_t start, uint32_t end, uint32_t region_index, otg_allele* alleles,
+                           uint64_t alleles_cap, uint8_t* arena, uint64_t arena_cap, uint64_t* arena_used)
+{
+  RefIngest* r = (RefIngest*)hnd;
+  SampleIndex si;
+  si.init(bam_path);
+  OtterOpts params{};
+  BED region;
+  region.chr = chr; region.start = start; region.end = end;
+  std::vector<ANALLELE> block;
+  std::vector<int> samples;
+  parse_analleles(params, r->bam, region, si.sample2index, block, samples);
+  if (!block.empty() && r->has_fa) {
+    std::string refseq;
+    r->fa.fetch(region.chr, region.start - si.offset_l, region.end + si.offset_r - 1, refseq);
+    samples.emplace_back((int)si.index2sample.size());
+    block.emplace_back(refseq);
+  }
+  if (block.size() > alleles_cap) return -1;
+  uint64_t used = *arena_used;
+  for (size_t i = 0; i < block.size(); ++i) {
+    const ANALLELE& a = block[i];
+    if (used + a.seq.size() + 64 > arena_cap) return -2;
+    memset(&alleles[i], 0, sizeof(otg_allele));
+    alleles[i].seq_off = used; alleles[i].seq_len = (uint32_t)a.seq.size();
+    alleles[i].scov = a.scov; alleles[i].acov = a.acov; alleles[i].tcov = a.tcov; alleles[i].se = a.se; alleles[i].ic = a.ic;
+    alleles[i].ps = a.hpt.ps; alleles[i].hp = a.hpt.hp; alleles[i].region = region_index; alleles[i].label = samples[i];
+    memcpy(arena + used, a.seq.data(), a.seq.size());
+    used += a.seq.size();
+  }
+  *arena_used = used;
+  return (int64_t)block.size();
 }
 
 } // extern "C"

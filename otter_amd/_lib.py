@@ -18,6 +18,7 @@ EXPORTS = [
     "otg_bam_open", "otg_bam_close", "otg_bam_n_targets", "otg_bam_target", "otg_ingest_regions",
     "otg_ingest_regions_named", "otg_emit_reads", "otg_parse_bed_file", "otg_fasta_open", "otg_fasta_close", "otg_fasta_n_seqs",
     "otg_fasta_seq", "otg_fasta_fetch", "otg_fasta_region_flanks",
+    "otg_bam_sample_index", "otg_bam_sample", "otg_ingest_alleles", "otg_emit_vcf_header", "otg_emit_vcf_lines", "otg_emit_genotype_lengths",
 ]
 
 _lib = None
@@ -289,6 +290,36 @@ class Bam:
             out.append((nm.decode(), int(ln.value)))
         return out
 
+    def sample_index(self):
+        """SampleIndex of an allele BAM (otg_bam_sample_index): ([sample names in header order], offset_l, offset_r)."""
+        n, ol, orr = C.c_uint32(0), C.c_int32(0), C.c_int32(0)
+        rc = self._L.otg_bam_sample_index(self._h, C.byref(n), C.byref(ol), C.byref(orr))
+        if rc != 0:
+            raise OtterGpuError("otg_bam_sample_index failed (%d): %s" % (rc, (self._L.otg_last_error(None) or b"").decode()))
+        self._L.otg_bam_sample.restype = C.c_char_p
+        return [self._L.otg_bam_sample(self._h, C.c_uint32(i)).decode("latin-1") for i in range(n.value)], int(ol.value), int(orr.value)
+
+    def ingest_alleles(self, regions, reference=None, threads=1):
+        """The allele records of each region (otg_ingest_alleles) -> {"alleles", "first_allele", "arena"}; with reference (a Fasta)
+        the reference allele is appended to every non-empty region, as `otter genotype -r` does."""
+        beds, carena = regions if isinstance(regions, tuple) else abi.make_beds(regions)
+        fsz = os.path.getsize(self._path)
+        cap_n, cap_a = max(1024, fsz // 32), max(1 << 20, 8 * fsz)
+        first = np.zeros(len(beds) + 1, dtype=np.uint32)
+        while True:
+            alleles = np.zeros(cap_n, dtype=abi.allele_dt)
+            arena = np.zeros(cap_a, dtype=np.uint8)
+            used, na = C.c_uint64(0), C.c_uint32(0)
+            rc = self._L.otg_ingest_alleles(self._h, abi.ptr(beds), abi.ptr(carena, C.c_char_p), C.c_uint32(len(beds)), C.c_int32(threads),
+                                            reference._h if reference is not None else None, abi.ptr(arena), C.c_uint64(cap_a), C.byref(used),
+                                            abi.ptr(alleles), C.c_uint32(cap_n), C.byref(na), abi.ptr(first))
+            if rc == abi.OTG_ERR_CAPACITY:
+                cap_n, cap_a = max(cap_n, na.value + 16), max(cap_a, used.value + 4096)
+                continue
+            if rc != 0:
+                raise OtterGpuError("otg_ingest_alleles failed (%d): %s" % (rc, (self._L.otg_last_error(None) or b"").decode()))
+            return {"alleles": np.ascontiguousarray(alleles[:na.value]), "first_allele": first, "arena": np.ascontiguousarray(arena[:used.value + 64])}
+
     def ingest(self, regions, offset_l=0, offset_r=0, mapq=0, nonprimary=False, omit_nonspanning=False, read_quality=0.0, threads=1,
                names=False):
         """regions: list of (chr, start, end), or the (beds, chr_arena) pair of parse_bed_file -> batch dict {"arena", "reads",
@@ -433,3 +464,51 @@ class Fasta:
             raise OtterGpuError("otg_fasta_region_flanks failed (%d): %s" % (rc, _err(self._L)))
         batch["arena"] = np.ascontiguousarray(big[:used.value + 64])
         return batch
+
+
+def _emit(call, cap):
+    L = load()
+    while True:
+        out = np.empty(max(cap, 16), dtype=np.uint8)
+        n = C.c_uint64(0)
+        rc = call(abi.ptr(out, C.c_char_p), C.c_uint64(out.size), C.byref(n))
+        if rc == abi.OTG_ERR_CAPACITY:
+            cap = n.value
+            continue
+        if rc != 0:
+            raise OtterGpuError("emit failed (%d): %s" % (rc, _err(L)))
+        return out[:n.value].tobytes()
+
+
+def emit_vcf_header(bam):
+    """The VCF header of `otter genotype -r` for an allele BAM (after Bam.sample_index())."""
+    L = load()
+    return _emit(lambda o, c, n: L.otg_emit_vcf_header(bam._h, o, c, n), 4096)
+
+
+def emit_vcf_lines(beds, chr_arena, blk, n_samples, gt, hsd, n_gt, reps, offset_l, offset_r):
+    """One VCF line per region with alleles; blk = Bam.ingest_alleles(..., reference=...), gt / hsd / n_gt / reps from
+    Context.genotype_cluster_batch on the same blocks."""
+    L = load()
+    gt = np.ascontiguousarray(gt, dtype=np.int32); hsd = np.ascontiguousarray(hsd, dtype=np.float64)
+    n_gt = np.ascontiguousarray(n_gt, dtype=np.int32); reps = np.ascontiguousarray(reps, dtype=np.int32)
+    cap = int(blk["alleles"]["seq_len"].sum()) * 2 + 256 * (len(beds) + 1) * (n_samples + 2)
+    return _emit(lambda o, c, n: L.otg_emit_vcf_lines(abi.ptr(beds), abi.ptr(chr_arena, C.c_char_p), C.c_uint32(len(beds)), abi.ptr(blk["first_allele"]),
+                                                      abi.ptr(blk["alleles"]), abi.ptr(blk["arena"]), C.c_uint32(n_samples), abi.ptr(gt), abi.ptr(hsd),
+                                                      abi.ptr(n_gt), abi.ptr(reps), C.c_int32(offset_l), C.c_int32(offset_r), o, c, n), cap)
+
+
+def emit_genotype_lengths(bam, beds, chr_arena, blk, n_samples):
+    """`otter genotype` without a reference: region, sample, shorter and longer allele length per line."""
+    L = load()
+    return _emit(lambda o, c, n: L.otg_emit_genotype_lengths(bam._h, abi.ptr(beds), abi.ptr(chr_arena, C.c_char_p), C.c_uint32(len(beds)),
+                                                             abi.ptr(blk["first_allele"]), abi.ptr(blk["alleles"]), C.c_uint32(n_samples), o, c, n),
+                 128 * (len(beds) + 1) * (n_samples + 1))
+
+
+def genotype_blocks(blk):
+    """(seq_off, seq_len, first_allele, n_alleles) arrays of an ingested allele batch, the inputs of genotype_cluster_batch."""
+    a = blk["alleles"]
+    first = blk["first_allele"]
+    return (np.ascontiguousarray(a["seq_off"], dtype=np.uint64), np.ascontiguousarray(a["seq_len"], dtype=np.uint32),
+            np.ascontiguousarray(first[:-1], dtype=np.uint32), np.ascontiguousarray(np.diff(first.astype(np.int64)), dtype=np.uint32))

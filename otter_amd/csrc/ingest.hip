@@ -7,6 +7,7 @@
 // bin + linear-index region query, and a restatement of the reference's CIGAR walk with all of its quirks.
 // Output goes straight into the region batch of the L3 pipeline (otg_read / otg_region + byte arena).
 #include "otg_common.hpp"
+#include <cerrno>
 #include <zlib.h>
 #include <algorithm>
 #include <cstdio>
@@ -111,6 +112,11 @@ struct otg_bam {
   std::vector<uint8_t> rec;        // one decoded record
   std::string err;
   std::string path;
+  std::string text;                // SAM header text of the BAM
+  bool samples_parsed = false;     // SampleIndex (src/anbamdb.cpp): read groups in header order, offsets from `@PG ID:otter OF:`
+  std::vector<std::string> index2sample;
+  std::unordered_map<std::string, int> sample2index;
+  int offset_l = 1, offset_r = 0;
 };
 
 namespace {
@@ -343,6 +349,7 @@ int otg_bam_open(const char* bam_path, otg_bam** out)
   if (b->fp.read(&l_text, 4) != 4 || l_text < 0) { b->fp.close(); return bail("truncated header"); }
   std::vector<char> text((size_t)l_text + 1);
   if (l_text && b->fp.read(text.data(), (size_t)l_text) != (size_t)l_text) { b->fp.close(); return bail("truncated header text"); }
+  b->text.assign(text.data(), (size_t)l_text);
   if (b->fp.read(&n_ref, 4) != 4 || n_ref < 0) { b->fp.close(); return bail("truncated reference list"); }
   for (int32_t i = 0; i < n_ref; ++i) {
     int32_t l_name = 0; uint32_t l_ref = 0;
@@ -367,6 +374,44 @@ const char* otg_bam_target(const otg_bam* b, uint32_t i, uint64_t* length)
   if (!b || i >= b->names.size()) return nullptr;
   if (length) *length = b->lengths[i];
   return b->names[i].c_str();
+}
+
+} // extern "C"
+
+// Every record htslib's iterator would return for [qbeg, qend) on target tid (bins of the region, linear-index lower bound,
+// overlap filter; src/hts.c:690-870), in file order, on the private reader `local`.  fn(record) is called for each.
+template <class F>
+static int scan_region(const otg_bam* b, otg_bam& local, int tid, long long qbeg, long long qend, std::vector<uint32_t>& bins,
+                       std::vector<std::pair<uint64_t, uint64_t>>& chunks, std::string& err, F&& fn)
+{
+  const RefIndex& ri = b->idx[(size_t)tid];
+  uint64_t min_off = 0;
+  if (!ri.linear.empty()) { const size_t w = (size_t)(qbeg >> 14); min_off = ri.linear[w < ri.linear.size() ? w : ri.linear.size() - 1]; }
+  bins.clear(); chunks.clear();
+  reg2bins(qbeg, qend, bins);
+  for (uint32_t bn : bins) { auto f = ri.bins.find(bn); if (f != ri.bins.end()) for (auto& c : f->second) if (c.second > min_off) chunks.push_back(c); }
+  std::sort(chunks.begin(), chunks.end());
+  size_t m = 0;
+  for (size_t i = 0; i < chunks.size(); ++i) {              // merge overlapping / adjacent chunks
+    if (m && chunks[i].first <= chunks[m - 1].second) chunks[m - 1].second = std::max(chunks[m - 1].second, chunks[i].second);
+    else chunks[m++] = chunks[i];
+  }
+  chunks.resize(m);
+  bool finished = false;
+  for (size_t ci = 0; ci < chunks.size() && !finished; ++ci) {
+    if (!local.fp.seek(chunks[ci].first)) { err = "cannot seek in BAM"; return OTG_ERR_ARG; }
+    while (local.fp.tell() < chunks[ci].second) {
+      Rec r;
+      const int rc = read_record(&local, &r);
+      if (rc == 0) { finished = true; break; }
+      if (rc < 0) { err = "malformed BAM record"; return OTG_ERR_ARG; }
+      const long long rend = (long long)r.pos + (r.n_cigar ? cigar_rlen(r) : 1);
+      if (r.tid != tid || r.pos >= qend) { finished = true; break; }
+      if (!(rend > qbeg && qend > r.pos)) continue;
+      fn(r);
+    }
+  }
+  return OTG_OK;
 }
 
 // one contiguous slice of regions on its own file handle: reads + bytes into private vectors, regions[].first_read relative
@@ -395,73 +440,163 @@ static int ingest_slice(const otg_bam* b, const char* path, const otg_bed* beds,
     long long qbeg = (long long)start - 1; if (qbeg < 0) qbeg = 0;
     const long long qend = end;
     if (it == b->name2id.end() || end < 0 || qbeg > qend) { regions[g].n_reads = 0; continue; }
-    const int tid = it->second;
-    const RefIndex& ri = b->idx[(size_t)tid];
-    uint64_t min_off = 0;
-    if (!ri.linear.empty()) { const size_t w = (size_t)(qbeg >> 14); min_off = ri.linear[w < ri.linear.size() ? w : ri.linear.size() - 1]; }
-    bins.clear(); chunks.clear();
-    reg2bins(qbeg, qend, bins);
-    for (uint32_t bn : bins) { auto f = ri.bins.find(bn); if (f != ri.bins.end()) for (auto& c : f->second) if (c.second > min_off) chunks.push_back(c); }
-    std::sort(chunks.begin(), chunks.end());
-    size_t m = 0;
-    for (size_t i = 0; i < chunks.size(); ++i) {              // merge overlapping / adjacent chunks
-      if (m && chunks[i].first <= chunks[m - 1].second) chunks[m - 1].second = std::max(chunks[m - 1].second, chunks[i].second);
-      else chunks[m++] = chunks[i];
-    }
-    chunks.resize(m);
-    bool finished = false;
-    for (size_t ci = 0; ci < chunks.size() && !finished; ++ci) {
-      if (!local.fp.seek(chunks[ci].first)) { err = "cannot seek in BAM"; rc_out = OTG_ERR_ARG; break; }
-      while (local.fp.tell() < chunks[ci].second) {
-        Rec r;
-        const int rc = read_record(&local, &r);
-        if (rc == 0) { finished = true; break; }
-        if (rc < 0) { err = "malformed BAM record"; rc_out = OTG_ERR_ARG; finished = true; break; }
-        const long long rend = (long long)r.pos + (r.n_cigar ? cigar_rlen(r) : 1);
-        if (r.tid != tid || r.pos >= qend) { finished = true; break; }
-        if (!(rend > qbeg && qend > r.pos)) continue;
-        // ---- parse_anreads (src/anseqs.cpp:444-457)
-        if (!((int)r.mapq >= opts->mapq && (opts->nonprimary || !(r.flag & 0x100u || r.flag & 0x800u)))) continue;
-        ParseMsg msg; bool have = false; int q_first = 0, q_second = 0;
-        get_breakpoints(start, end, r, msg, have, q_first, q_second);
-        if (!msg.successful) continue;
-        seq.clear();
-        if (q_first == -1 || r.l_seq < (q_second - q_first)) seq = "N";          // parse_alignment :421-432
-        else {
-          const int l_sub = q_second - q_first, l_og = msg.c_second - msg.c_first;
-          msg.c_first = msg.c_first - q_first;
-          msg.c_second = msg.c_first + l_og;
-          seq.resize(l_sub > 0 ? (size_t)l_sub : 0);
-          for (int i = 0; i < l_sub; ++i) { const int qi = i + q_first; seq[(size_t)i] = nt16[(r.seq[qi >> 1] >> ((~qi & 1) << 2)) & 0xf]; }
-          if (seq.empty()) seq = "N";
-        }
-        if (opts->omit_nonspanning && !(msg.spanning_l && msg.spanning_r)) continue;
-        int32_t hp = -1, ps = -1; double rq = 0.0;
-        if (const uint8_t* a = aux_get(r, 'H', 'P')) hp = aux2i(a);
-        if (const uint8_t* a = aux_get(r, 'P', 'S')) ps = aux2i(a);
-        if (const uint8_t* a = aux_get(r, 'r', 'q')) rq = aux2f(a);
-        if (!(rq >= opts->read_quality)) continue;
-        otg_read o;
-        memset(&o, 0, sizeof(o));
-        o.seq_off = arena.size(); o.seq_len = (uint32_t)seq.size();
-        o.spanning_l = msg.spanning_l ? 1 : 0; o.spanning_r = msg.spanning_r ? 1 : 0;
-        o.ps = ps; o.hp = hp; o.ccoord_first = msg.c_first; o.ccoord_second = msg.c_second;
-        arena.insert(arena.end(), seq.begin(), seq.end());
-        reads.push_back(o);
-        if (meta) {                                                              // ANREAD::name / ANREAD::rq for the reads-only records
-          otg_read_meta mm;
-          memset(&mm, 0, sizeof(mm));
-          mm.name_off = names->size(); mm.name_len = r.l_name; mm.rq = rq;
-          names->append(r.name, r.l_name);
-          meta->push_back(mm);
-        }
+    rc_out = scan_region(b, local, it->second, qbeg, qend, bins, chunks, err, [&](const Rec& r) {
+      // ---- parse_anreads (src/anseqs.cpp:444-457)
+      if (!((int)r.mapq >= opts->mapq && (opts->nonprimary || !(r.flag & 0x100u || r.flag & 0x800u)))) return;
+      ParseMsg msg; bool have = false; int q_first = 0, q_second = 0;
+      get_breakpoints(start, end, r, msg, have, q_first, q_second);
+      if (!msg.successful) return;
+      seq.clear();
+      if (q_first == -1 || r.l_seq < (q_second - q_first)) seq = "N";          // parse_alignment :421-432
+      else {
+        const int l_sub = q_second - q_first, l_og = msg.c_second - msg.c_first;
+        msg.c_first = msg.c_first - q_first;
+        msg.c_second = msg.c_first + l_og;
+        seq.resize(l_sub > 0 ? (size_t)l_sub : 0);
+        for (int i = 0; i < l_sub; ++i) { const int qi = i + q_first; seq[(size_t)i] = nt16[(r.seq[qi >> 1] >> ((~qi & 1) << 2)) & 0xf]; }
+        if (seq.empty()) seq = "N";
       }
-    }
+      if (opts->omit_nonspanning && !(msg.spanning_l && msg.spanning_r)) return;
+      int32_t hp = -1, ps = -1; double rq = 0.0;
+      if (const uint8_t* a = aux_get(r, 'H', 'P')) hp = aux2i(a);
+      if (const uint8_t* a = aux_get(r, 'P', 'S')) ps = aux2i(a);
+      if (const uint8_t* a = aux_get(r, 'r', 'q')) rq = aux2f(a);
+      if (!(rq >= opts->read_quality)) return;
+      otg_read o;
+      memset(&o, 0, sizeof(o));
+      o.seq_off = arena.size(); o.seq_len = (uint32_t)seq.size();
+      o.spanning_l = msg.spanning_l ? 1 : 0; o.spanning_r = msg.spanning_r ? 1 : 0;
+      o.ps = ps; o.hp = hp; o.ccoord_first = msg.c_first; o.ccoord_second = msg.c_second;
+      arena.insert(arena.end(), seq.begin(), seq.end());
+      reads.push_back(o);
+      if (meta) {                                                              // ANREAD::name / ANREAD::rq for the reads-only records
+        otg_read_meta mm;
+        memset(&mm, 0, sizeof(mm));
+        mm.name_off = names->size(); mm.name_len = r.l_name; mm.rq = rq;
+        names->append(r.name, r.l_name);
+        meta->push_back(mm);
+      }
+    });
     regions[g].n_reads = (uint32_t)reads.size() - first;
   }
   local.fp.close();
   return rc_out;
 }
+
+// SampleIndex::init / _init (src/anbamdb.cpp:10-63) on the header text
+static int parse_sample_index(otg_bam* b, std::string& err)
+{
+  if (b->samples_parsed) return OTG_OK;
+  b->index2sample.clear(); b->sample2index.clear(); b->offset_l = 1; b->offset_r = 0;
+  bool bad = false;
+  auto one = [&](const std::string& line) {
+    if (line.substr(0, 2) == "RG") {
+      if (line.size() > 3 && line.substr(3, 2) == "ID") b->index2sample.emplace_back(line.size() >= 6 ? line.substr(6) : std::string());
+    } else if (line.substr(0, 2) == "PG") {
+      if (line.size() >= 15 && line.substr(0, 15) == "PG\tID:otter\tOF:") {
+        const std::string input = line.substr(15);
+        std::vector<std::string> columns;
+        size_t i = 0;
+        while (i < input.size()) { size_t j = input.find(',', i); if (j == std::string::npos) { columns.push_back(input.substr(i)); break; } columns.push_back(input.substr(i, j - i)); i = j + 1; }
+        auto to_i = [&](const std::string& v, int* o) { char* e = nullptr; errno = 0; const long x = strtol(v.c_str(), &e, 10); if (e == v.c_str() || errno == ERANGE || x > 2147483647L || x < -2147483648L) { bad = true; return; } *o = (int)x; };
+        if (columns.size() == 1) { to_i(columns[0], &b->offset_l); b->offset_r = b->offset_l; }
+        else if (columns.size() == 2) { to_i(columns[0], &b->offset_l); to_i(columns[1], &b->offset_r); }
+        else bad = true;
+      }
+    }
+  };
+  std::string tag;
+  for (char c : b->text) {
+    if (c != '@' && c != '\n') tag += c;
+    else if (!tag.empty()) { one(tag); tag.clear(); }
+  }
+  if (!tag.empty()) one(tag);
+  if (bad) { err = "cannot parse the offsets in the @PG ID:otter OF: header line"; return OTG_ERR_ARG; }
+  if (b->index2sample.empty()) { err = "no sample name (@RG ID:) in the BAM header"; return OTG_ERR_ARG; }
+  for (int i = 0; i < (int)b->index2sample.size(); ++i) b->sample2index[b->index2sample[i]] = i;
+  b->samples_parsed = true;
+  return OTG_OK;
+}
+
+// parse_analleles / parse_anallele (src/anseqs.cpp:462-524) for a slice of regions, plus the reference allele genotype_process appends
+// (src/genotype.cpp:92-101).  alleles[].region = region index, alleles[].label = sample index.
+static int alleles_slice(const otg_bam* b, const char* path, const otg_bed* beds, const char* chr_arena, uint32_t g0, uint32_t g1,
+                         const otg_fasta* fa, std::vector<otg_allele>& alleles, std::vector<uint8_t>& arena, uint32_t* n_per_region, std::string& err)
+{
+  static const char nt16[] = "=ACMGRSVTWYHKDBN";
+  otg_bam local;
+  if (!local.fp.open(path)) { err = "cannot reopen BAM"; return OTG_ERR_ARG; }
+  std::vector<uint32_t> bins;
+  std::vector<std::pair<uint64_t, uint64_t>> chunks;
+  int rc_out = OTG_OK;
+  const int refindex = (int)b->index2sample.size();
+  for (uint32_t g = g0; g < g1 && rc_out == OTG_OK; ++g) {
+    const size_t first = alleles.size();
+    n_per_region[g] = 0;
+    const std::string chr(chr_arena + beds[g].chr_off, beds[g].chr_len);
+    const std::string target = chr + ":" + std::to_string((uint32_t)beds[g].start) + "-" + std::to_string((uint32_t)beds[g].end);   // toScString
+    auto it = b->name2id.find(chr);
+    // the region string goes through hts_parse_reg: numbers are parsed into int (the unsigned spelling of a wrapped value overflows to garbage
+    // there; such regions are not supported here), the start is 1-based
+    const long long s0 = (long long)(uint32_t)beds[g].start, e0 = (long long)(uint32_t)beds[g].end;
+    long long qbeg = s0 - 1; if (qbeg < 0) qbeg = 0;
+    const long long qend = e0;
+    if (it == b->name2id.end() || s0 > 2147483647LL || e0 > 2147483647LL || qbeg > qend) continue;
+    int cb_rc = OTG_OK;
+    const int sc_rc = scan_region(b, local, it->second, qbeg, qend, bins, chunks, err, [&](const Rec& r) {
+      if (cb_rc != OTG_OK) return;
+      const uint8_t* a = aux_get(r, 't', 'a');
+      std::string parsed = a ? std::string((const char*)a + 1) : std::string();
+      if (parsed != target) return;
+      a = aux_get(r, 'R', 'G');
+      const std::string sample = a ? std::string((const char*)a + 1) : std::string();
+      auto si = b->sample2index.find(sample);
+      if (si == b->sample2index.end()) { err = "unrecognized sample name (read group): " + sample; cb_rc = OTG_ERR_ARG; return; }
+      otg_allele o;
+      memset(&o, 0, sizeof(o));
+      o.tcov = 1; o.acov = 1; o.scov = 1; o.ps = -1; o.hp = -1; o.se = 0.0f; o.ic = 1;
+      if ((a = aux_get(r, 't', 'c'))) o.tcov = aux2i(a);
+      if ((a = aux_get(r, 'a', 'c'))) o.acov = aux2i(a);
+      if ((a = aux_get(r, 's', 'c'))) o.scov = aux2i(a);
+      if ((a = aux_get(r, 'P', 'S'))) o.ps = aux2i(a);
+      if ((a = aux_get(r, 'H', 'P'))) o.hp = aux2i(a);
+      if ((a = aux_get(r, 's', 'e'))) o.se = (float)aux2f(a);
+      if ((a = aux_get(r, 'i', 'c'))) o.ic = aux2i(a);
+      const uint32_t l_qseq = r.l_seq > 0 ? (uint32_t)r.l_seq : 1u;
+      o.seq_off = arena.size(); o.seq_len = l_qseq; o.region = g; o.label = si->second;
+      const size_t at = arena.size();
+      arena.resize(at + l_qseq, (uint8_t)'N');
+      for (int i = 0; i < r.l_seq; ++i) arena[at + (size_t)i] = (uint8_t)nt16[(r.seq[i >> 1] >> ((~i & 1) << 2)) & 0xf];
+      alleles.push_back(o);
+    });
+    rc_out = sc_rc != OTG_OK ? sc_rc : cb_rc;
+    if (rc_out != OTG_OK) break;
+    if (fa && alleles.size() > first) {
+      // anallele_block.emplace_back(refseq): ANALLELE(seq) = coverage 1/1/1, se 0, ic 1, no haplotag; sample = the internal reference sample
+      const char* ref = nullptr; uint64_t ref_len = 0;
+      std::vector<char> buf;
+      const int fb = (int)(uint32_t)beds[g].start - b->offset_l, fe = (int)(uint32_t)beds[g].end + b->offset_r - 1;
+      uint64_t need = 0;
+      buf.resize((size_t)(fe >= fb ? (long long)fe - fb + 2 : 2) + 16);
+      if (otg_fasta_fetch(fa, chr.data(), (uint32_t)chr.size(), fb, fe, buf.data(), buf.size(), &need) != OTG_OK) {
+        buf.resize((size_t)need + 16);
+        if (otg_fasta_fetch(fa, chr.data(), (uint32_t)chr.size(), fb, fe, buf.data(), buf.size(), &need) != OTG_OK) { err = "cannot fetch the reference allele"; rc_out = OTG_ERR_ARG; break; }
+      }
+      ref = buf.data(); ref_len = need;
+      otg_allele o;
+      memset(&o, 0, sizeof(o));
+      o.tcov = 1; o.acov = 1; o.scov = 1; o.ps = -1; o.hp = -1; o.se = 0.0f; o.ic = 1;
+      o.seq_off = arena.size(); o.seq_len = (uint32_t)ref_len; o.region = g; o.label = refindex;
+      arena.insert(arena.end(), (const uint8_t*)ref, (const uint8_t*)ref + ref_len);
+      alleles.push_back(o);
+    }
+    n_per_region[g] = (uint32_t)(alleles.size() - first);
+  }
+  local.fp.close();
+  return rc_out;
+}
+
+extern "C" {
 
 int otg_ingest_regions_named(otg_bam* b, const otg_bed* beds, const char* chr_arena, uint32_t n_regions, const otg_ingest_opts* opts,
                              uint8_t* arena, uint64_t arena_capacity, uint64_t* arena_used, otg_read* reads, uint32_t reads_capacity,
@@ -522,6 +657,69 @@ int otg_ingest_regions(otg_bam* b, const otg_bed* beds, const char* chr_arena, u
 {
   return otg_ingest_regions_named(b, beds, chr_arena, n_regions, opts, arena, arena_capacity, arena_used, reads, reads_capacity,
                                   n_reads, regions, nullptr, nullptr, 0, nullptr);
+}
+
+int otg_bam_sample_index(otg_bam* b, uint32_t* n_samples, int32_t* offset_l, int32_t* offset_r)
+{
+  if (!b) return otg_fail(nullptr, OTG_ERR_ARG, "otg_bam_sample_index: null argument");
+  std::string err;
+  const int rc = parse_sample_index(b, err);
+  if (rc != OTG_OK) return otg_fail(nullptr, rc, "otg_bam_sample_index(%s): %s", b->path.c_str(), err.c_str());
+  if (n_samples) *n_samples = (uint32_t)b->index2sample.size();
+  if (offset_l) *offset_l = b->offset_l;
+  if (offset_r) *offset_r = b->offset_r;
+  return OTG_OK;
+}
+
+const char* otg_bam_sample(const otg_bam* b, uint32_t i)
+{
+  if (!b || !b->samples_parsed || i >= b->index2sample.size()) return nullptr;
+  return b->index2sample[i].c_str();
+}
+
+int otg_ingest_alleles(otg_bam* b, const otg_bed* beds, const char* chr_arena, uint32_t n_regions, int32_t threads, const otg_fasta* fa,
+                       uint8_t* arena, uint64_t arena_capacity, uint64_t* arena_used, otg_allele* alleles, uint32_t alleles_capacity,
+                       uint32_t* n_alleles, uint32_t* first_allele)
+{
+  if (!b || (n_regions && (!beds || !first_allele)) || !arena_used || !n_alleles) return otg_fail(nullptr, OTG_ERR_ARG, "otg_ingest_alleles: null argument");
+  {
+    std::string err;
+    const int rc = parse_sample_index(b, err);
+    if (rc != OTG_OK) return otg_fail(nullptr, rc, "otg_ingest_alleles(%s): %s", b->path.c_str(), err.c_str());
+  }
+  uint32_t T = threads > 1 ? (uint32_t)threads : 1u;
+  if (T > n_regions) T = n_regions ? n_regions : 1;
+  std::vector<std::vector<otg_allele>> R(T);
+  std::vector<std::vector<uint8_t>> A(T);
+  std::vector<uint32_t> per(n_regions, 0u);
+  std::vector<int> rcs(T, OTG_OK);
+  std::vector<std::string> errs(T);
+  auto work = [&](uint32_t t) {
+    const uint32_t g0 = (uint32_t)((uint64_t)n_regions * t / T), g1 = (uint32_t)((uint64_t)n_regions * (t + 1) / T);
+    rcs[t] = alleles_slice(b, b->path.c_str(), beds, chr_arena, g0, g1, fa, R[t], A[t], per.data(), errs[t]);
+  };
+  if (T == 1) work(0);
+  else {
+    std::vector<std::thread> th;
+    for (uint32_t t = 0; t < T; ++t) th.emplace_back(work, t);
+    for (auto& x : th) x.join();
+  }
+  for (uint32_t t = 0; t < T; ++t) if (rcs[t] != OTG_OK) return otg_fail(nullptr, rcs[t], "otg_ingest_alleles: %s", errs[t].c_str());
+  uint64_t used = *arena_used; uint32_t na = *n_alleles;
+  bool overflow = false;
+  for (uint32_t t = 0; t < T; ++t) {
+    const bool fits = (uint64_t)na + R[t].size() <= alleles_capacity && used + A[t].size() + 64 <= arena_capacity && alleles && arena;
+    if (fits && !overflow) {
+      for (size_t i = 0; i < R[t].size(); ++i) { alleles[na + i] = R[t][i]; alleles[na + i].seq_off += used; }
+      if (!A[t].empty()) memcpy(arena + used, A[t].data(), A[t].size());
+    } else overflow = true;
+    na += (uint32_t)R[t].size(); used += A[t].size();
+  }
+  uint32_t acc = *n_alleles;
+  for (uint32_t g = 0; g < n_regions; ++g) { first_allele[g] = acc; acc += per[g]; }
+  first_allele[n_regions] = acc;
+  *arena_used = used; *n_alleles = na;
+  return overflow ? OTG_ERR_CAPACITY : OTG_OK;
 }
 
 } // extern "C"

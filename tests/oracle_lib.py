@@ -264,3 +264,35 @@ def emit_sam_header(targets, read_group="", offset_l=0, offset_r=0):
     n = f(C.c_char_p(names), abi.ptr(off), abi.ptr(ln), abi.ptr(tl), C.c_uint32(len(targets)), C.c_char_p(read_group.encode()),
           C.c_int32(offset_l), C.c_int32(offset_r), abi.ptr(out, C.c_char_p), C.c_uint64(out.size))
     return out[:n].tobytes()
+
+
+def _names(items):
+    raw = [x.encode("latin-1") for x in items]
+    off = np.cumsum([0] + [len(x) for x in raw[:-1]]).astype(np.uint64) if raw else np.zeros(0, np.uint64)
+    ln = np.array([len(x) for x in raw], dtype=np.uint32)
+    return b"".join(raw) + b"\0", off, ln
+
+
+def emit_vcf_header(targets, samples):
+    f = lib().oto_emit_vcf_header
+    f.restype = C.c_uint64
+    tn, toff, tln = _names([t[0] for t in targets])
+    tl = np.array([t[1] for t in targets], dtype=np.uint64)
+    sn, soff, sln = _names(samples)
+    out = np.zeros(4096 + 64 * (len(targets) + len(samples)) + len(tn) + len(sn), dtype=np.uint8)
+    n = f(C.c_char_p(tn), abi.ptr(toff), abi.ptr(tln), abi.ptr(tl), C.c_uint32(len(targets)), C.c_char_p(sn), abi.ptr(soff), abi.ptr(sln),
+          C.c_uint32(len(samples)), abi.ptr(out, C.c_char_p), C.c_uint64(out.size))
+    return out[:n].tobytes()
+
+
+def emit_vcf_lines(beds, chr_arena, blk, n_samples, gt, hsd, n_gt, reps, offset_l, offset_r):
+    f = lib().oto_emit_vcf_lines
+    f.restype = C.c_uint64
+    gt = np.ascontiguousarray(gt, dtype=np.int32); hsd = np.ascontiguousarray(hsd, dtype=np.float64)
+    n_gt = np.ascontiguousarray(n_gt, dtype=np.int32); reps = np.ascontiguousarray(reps, dtype=np.int32)
+    out = np.zeros(int(blk["alleles"]["seq_len"].sum()) * 2 + 256 * (len(beds) + 1) * (n_samples + 2), dtype=np.uint8)
+    n = f(abi.ptr(beds), abi.ptr(chr_arena, C.c_char_p), C.c_uint32(len(beds)), abi.ptr(blk["first_allele"]), abi.ptr(blk["alleles"]), abi.ptr(blk["arena"]),
+          C.c_uint32(n_samples), abi.ptr(gt), abi.ptr(hsd), abi.ptr(n_gt), abi.ptr(reps), C.c_int32(offset_l), C.c_int32(offset_r),
+          abi.ptr(out, C.c_char_p), C.c_uint64(out.size))
+    assert n <= out.size
+    return out[:n].tobytes()
