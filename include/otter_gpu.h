@@ -368,6 +368,11 @@ int otg_assemble_submit(otg_ctx* ctx, const otg_params* params,
 /* Run the whole hot path on the resident batch: [local_realignment] -> fill_dist_matrix ->
  * otter_hclust -> invalid_reassignment -> rapid_consensus.  Results stay resident.             */
 int otg_assemble_run(otg_ctx* ctx);
+/* `otter assemble --reads-only -r`: run local_realignment alone on the resident batch (src/assemble.cpp:72-89 stops there), then read
+ * the read descriptors back: a rescued read has its seq_off / seq_len trimmed (src/analignments.cpp:53-54) and both spanning flags
+ * set; everything else is as submitted.  otg_emit_reads on them prints what the reference prints.  n_reads = the submitted count. */
+int otg_assemble_realign(otg_ctx* ctx);
+int otg_assemble_collect_reads(otg_ctx* ctx, otg_read* reads_out, uint32_t n_reads);
 /* Sizes needed by otg_assemble_collect for the last run.                                        */
 int otg_assemble_result_sizes(otg_ctx* ctx, uint32_t* n_alleles, uint64_t* seq_bytes);
 /* Device-resident results of the last run, for callers that forward them without a host round trip

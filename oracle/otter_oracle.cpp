@@ -1422,6 +1422,34 @@ oto_result* oto_assemble_batch(const otg_params* P, const uint8_t* arena, uint64
   return R;
 }
 
+/* local_realignment alone, as `otter assemble --reads-only -r` runs it (src/assemble.cpp:69-89: skipped for regions above max_cov):
+ * out[i] = the read descriptor after the flank rescue (a left rescue drops a prefix, a right rescue a suffix; both flags set). */
+void oto_realign_batch(const otg_params* P, const uint8_t* arena, uint64_t, const otg_read* reads, uint32_t n_reads,
+                       const otg_region* regions, uint32_t n_regions, otg_read* out)
+{
+  for (uint32_t i = 0; i < n_reads; ++i) out[i] = reads[i];
+  for (uint32_t r = 0; r < n_regions; ++r) {
+    const otg_region& G = regions[r];
+    if ((int)G.n_reads > P->max_cov || !P->realign) continue;
+    std::vector<oto::Read> rd(G.n_reads);
+    for (uint32_t i = 0; i < G.n_reads; ++i) {
+      const otg_read& q = reads[G.first_read + i];
+      rd[i].seq.assign((const char*)arena + q.seq_off, q.seq_len);
+      rd[i].spl = q.spanning_l; rd[i].spr = q.spanning_r; rd[i].ps = q.ps; rd[i].hp = q.hp; rd[i].cc1 = q.ccoord_first; rd[i].cc2 = q.ccoord_second;
+    }
+    std::string fl((const char*)arena + G.flank_l_off, G.flank_l_len), fr((const char*)arena + G.flank_r_off, G.flank_r_len);
+    oto::local_realignment(*P, rd, fl, fr, nullptr);
+    for (uint32_t i = 0; i < G.n_reads; ++i) {
+      const otg_read& q = reads[G.first_read + i];
+      otg_read& o = out[G.first_read + i];
+      const bool was_left = q.spanning_r && !q.spanning_l;           /* a left rescue trims the front of the read */
+      if (was_left) o.seq_off = q.seq_off + (q.seq_len - (uint32_t)rd[i].seq.size());
+      o.seq_len = (uint32_t)rd[i].seq.size();
+      o.spanning_l = rd[i].spl; o.spanning_r = rd[i].spr;
+    }
+  }
+}
+
 void oto_assemble_free(oto_result* R) { delete R; }
 uint32_t oto_result_n_alleles(oto_result* R) { return R->alleles.size(); }
 uint64_t oto_result_seq_bytes(oto_result* R) { return R->seqs.size(); }

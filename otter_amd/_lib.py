@@ -13,7 +13,7 @@ EXPORTS = [
     "otg_params_default", "otg_create", "otg_destroy", "otg_last_error", "otg_device_count", "otg_exp_variant",
     "otg_edit_distance_batch", "otg_affine_align_batch", "otg_cluster_batch", "otg_poa_consensus_batch",
     "otg_genotype_cluster_batch", "otg_assemble_submit", "otg_assemble_run", "otg_assemble_result_sizes",
-    "otg_assemble_collect", "otg_assemble_device_results", "otg_assemble_stats",
+    "otg_assemble_collect", "otg_assemble_device_results", "otg_assemble_stats", "otg_assemble_realign", "otg_assemble_collect_reads",
     "otg_emit_alleles", "otg_emit_sam_header",
     "otg_bam_open", "otg_bam_close", "otg_bam_n_targets", "otg_bam_target", "otg_ingest_regions",
     "otg_ingest_regions_named", "otg_emit_reads", "otg_parse_bed_file", "otg_fasta_open", "otg_fasta_close", "otg_fasta_n_seqs",
@@ -169,6 +169,14 @@ class Context:
 
     def assemble_run(self):
         self._check(self._L.otg_assemble_run(self._h), "otg_assemble_run")
+
+    def realign_reads(self, params, batch):
+        """local_realignment alone (`--reads-only -r`): the read descriptors after the flank rescue (otg_assemble_realign)."""
+        self.assemble_submit(params, batch)
+        self._check(self._L.otg_assemble_realign(self._h), "otg_assemble_realign")
+        out = np.zeros(len(batch["reads"]), dtype=abi.read_dt)
+        self._check(self._L.otg_assemble_collect_reads(self._h, abi.ptr(out), C.c_uint32(len(out))), "otg_assemble_collect_reads")
+        return out
 
     def assemble_collect(self):
         na = C.c_uint32(0)

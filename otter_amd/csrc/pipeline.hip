@@ -683,7 +683,27 @@ int otg_assemble_submit(otg_ctx* ctx, const otg_params* params, const uint8_t* s
   return OTG_OK;
 }
 
-int otg_assemble_run(otg_ctx* ctx)
+static int assemble_run_impl(otg_ctx* ctx, bool realign_only);
+
+int otg_assemble_run(otg_ctx* ctx) { return assemble_run_impl(ctx, false); }
+
+// `otter assemble --reads-only -r`: only local_realignment runs (src/assemble.cpp:72-89); the trimmed reads are read back with
+// otg_assemble_collect_reads
+int otg_assemble_realign(otg_ctx* ctx) { return assemble_run_impl(ctx, true); }
+
+int otg_assemble_collect_reads(otg_ctx* ctx, otg_read* reads_out, uint32_t n_reads)
+{
+  if (!ctx) return otg_fail(nullptr, OTG_ERR_NO_DEVICE, "otg_assemble_collect_reads: no context");
+  Pipeline* pl = ctx->pipe;
+  if (!pl) return otg_fail(ctx, OTG_ERR_ARG, "otg_assemble_collect_reads: nothing submitted");
+  if (n_reads != pl->n_reads || (n_reads && !reads_out)) return otg_fail(ctx, OTG_ERR_ARG, "otg_assemble_collect_reads: expected room for %u reads", pl->n_reads);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (n_reads) HIP_TRY(ctx, hipMemcpyAsync(reads_out, pl->buf[B_READS].p, (size_t)n_reads * sizeof(otg_read), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return OTG_OK;
+}
+
+static int assemble_run_impl(otg_ctx* ctx, bool realign_only)
 {
   if (!ctx) return otg_fail(nullptr, OTG_ERR_NO_DEVICE, "otg_assemble_run: no context");
   Pipeline* pl = ctx->pipe;
@@ -742,6 +762,11 @@ int otg_assemble_run(otg_ctx* ctx)
     pl->stats.ms_realign = t.ms();
   }
   dbg(ctx, "realign done");
+  if (realign_only) {
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    pl->stats.ms_total = total.ms();
+    return OTG_OK;             // pl->ran stays false: there are no allele results to collect
+  }
   // ------------------------------------------------------------------ partition + fill_dist_matrix
   {
     Timer t(ctx);

@@ -296,3 +296,11 @@ def emit_vcf_lines(beds, chr_arena, blk, n_samples, gt, hsd, n_gt, reps, offset_
           abi.ptr(out, C.c_char_p), C.c_uint64(out.size))
     assert n <= out.size
     return out[:n].tobytes()
+
+
+def realign_batch(params, batch):
+    """local_realignment alone (oto_realign_batch): the read descriptors after the flank rescue."""
+    out = np.zeros(len(batch["reads"]), dtype=abi.read_dt)
+    lib().oto_realign_batch(C.byref(params), abi.ptr(batch["arena"]), C.c_uint64(batch["arena"].size), abi.ptr(batch["reads"]),
+                            C.c_uint32(len(batch["reads"])), abi.ptr(batch["regions"]), C.c_uint32(len(batch["regions"])), abi.ptr(out))
+    return out

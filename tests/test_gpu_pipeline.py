@@ -140,3 +140,27 @@ def test_emitted_text_matches_oracle(gpu, oracle):
     beds, carena = abi.make_beds([("chr%d" % (1 + i % 5), 10_000 * i + 7, 10_000 * i + 507) for i in range(len(batch["regions"]))])
     for rg, fa in (("", False), ("s1", False), ("s1", True)):
         assert otter_amd.emit_alleles(beds, carena, res, rg, fa) == oracle.emit_alleles(beds, carena, ora, rg, fa)
+
+
+def test_realign_only_reads(gpu, oracle):
+    """`--reads-only -r`: local_realignment alone (otg_assemble_realign + otg_assemble_collect_reads) against the oracle's restatement:
+    rescued reads are trimmed at the rescued end and flagged spanning, every other descriptor is untouched; the emitted read records
+    (otg_emit_reads on the collected descriptors) are identical."""
+    import otter_amd
+    from otter_amd import synth
+    b = synth.make_batch(40, len_range=(300, 900), n_reads=16, err="hifi", realign=True, seed=8)
+    P = abi.default_params(realign=1)
+    got = gpu.realign_reads(P, b)
+    exp = oracle.realign_batch(P, b)
+    for f in ("seq_off", "seq_len", "spanning_l", "spanning_r", "ps", "hp", "ccoord_first", "ccoord_second"):
+        assert np.array_equal(got[f], exp[f]), f
+    changed = (got["seq_len"] != b["reads"]["seq_len"]) | (got["seq_off"] != b["reads"]["seq_off"])
+    assert changed.sum() > 10 and (got["spanning_l"][changed] == 1).all() and (got["spanning_r"][changed] == 1).all()
+    regions = [("chr1", 1000 * i, 1000 * i + 500) for i in range(len(b["regions"]))]
+    beds, carena = abi.make_beds(regions)
+    t_gpu = otter_amd.emit_reads(beds, carena, {**b, "reads": got}, read_group="rg", fasta=False, max_cov=200)
+    t_ora = otter_amd.emit_reads(beds, carena, {**b, "reads": exp}, read_group="rg", fasta=False, max_cov=200)
+    assert t_gpu == t_ora and t_gpu.count(b"\n") == len(got)
+    # without -r nothing moves
+    same = gpu.realign_reads(abi.default_params(), b)
+    assert np.array_equal(same["seq_len"], b["reads"]["seq_len"]) and np.array_equal(same["spanning_l"], b["reads"]["spanning_l"])
