@@ -97,7 +97,7 @@ typedef struct otg_align_task {
   int32_t  text_begin_free;
   int32_t  text_end_free;
   int32_t  endsfree;
-  int32_t  _pad;
+  int32_t  _pad;             /* reserved, 0 */
 } otg_align_task;
 
 /* Replaces WFAlignerEdit(Score, MemoryMed)::alignEnd2End/alignEndsFree + getAlignmentScore()

@@ -298,7 +298,11 @@ __global__ __launch_bounds__(WPB * 64) void myers_edit_kernel(
     for (int off = GL / 2; off > 0; off >>= 1) { const int o = __shfl_xor(best, off, GL); best = o < best ? o : best; }
     const bool ok = !unsupported && best <= K;
     u64 w = 0;
-    if (cells) w = wfa_cells<GL>(ok ? best : -1, (int)tsk.pattern_len, (int)tsk.text_len, ef ? tsk.pattern_begin_free : 0, ef ? tsk.text_begin_free : 0, gl);
+    // a mirrored task (_pad bit 0: both sequences reversed by the pipeline) reports the cells of the un-reversed alignment: its free
+    // prefixes are this task's free suffixes
+    const bool mirrored = (tsk._pad & 1) != 0;
+    if (cells) w = wfa_cells<GL>(ok ? best : -1, (int)tsk.pattern_len, (int)tsk.text_len, ef ? (mirrored ? tsk.pattern_end_free : tsk.pattern_begin_free) : 0,
+                                 ef ? (mirrored ? tsk.text_end_free : tsk.text_begin_free) : 0, gl);
     if (has_task && gl == 0) {
       if (ok) { scores[ti] = best; if (cells) cells[ti] = w; }
       else if (overflow_list) { const uint32_t q = atomicAdd(n_overflow, 1u); overflow_list[q] = ti; }

@@ -106,6 +106,19 @@ __device__ __forceinline__ void otg_myers_band(int K, int d, int pbf, int pef, i
   *KL = l < 0 ? 0 : l;
 }
 // Largest threshold K whose band fits R rows of lane schedule (KL + KU <= R, monotone in K).
+// W_p of SURVEY.md §8d in closed form: wavefront cells an edit-distance WFA evaluates up to score s when the wavefront of score t spans
+// the diagonals [max(-pbf - t, -m), min(tbf + t, n)] (pbf / tbf = free pattern / text prefix, 0 for a global alignment).
+__device__ __forceinline__ unsigned long long otg_edit_wfa_cells(int s, int m, int n, int pbf, int tbf)
+{
+  if (s < 0) return 0ull;
+  if (pbf > m) pbf = m;
+  if (tbf > n) tbf = n;
+  const long long kh = s < n - tbf ? s : n - tbf, kl = s < m - pbf ? s : m - pbf;
+  const long long sum_hi = (kh + 1) * tbf + kh * (kh + 1) / 2 + ((long long)s - kh) * n;
+  const long long sum_lo = (kl + 1) * pbf + kl * (kl + 1) / 2 + ((long long)s - kl) * m;
+  return (unsigned long long)(sum_hi + sum_lo + (long long)s + 1);
+}
+
 __device__ __forceinline__ int otg_myers_threshold(int R, int d, int pbf, int pef)
 {
   int lo = 0, hi = R;            // invariant: band(lo) fits (K = 0: KL + KU <= pbf + small), band(hi + 1) unknown

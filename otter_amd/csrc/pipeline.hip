@@ -34,6 +34,7 @@ struct Pipeline {
   otg_params P;
   uint32_t n_reads = 0, n_regions = 0;
   uint64_t arena_bytes = 0;
+  uint64_t rev_base = 0;         // the second half of the device arena: every read reversed in place (same offset + rev_base)
   std::vector<otg_read> h_reads;
   std::vector<otg_region> h_regions;
   std::vector<uint64_t> h_dist_off, h_re_off, h_cig_off;
@@ -97,7 +98,7 @@ __device__ __forceinline__ void make_task(otg_align_task& t, uint64_t po, uint32
 
 // align_anreads (src/analignments.cpp:62-101) as a task; returns 0: distance already known (*known),
 // 1: task written (denominator in *den).
-__device__ int anreads_task(const uint8_t* arena, const otg_read& x, const otg_read& y, otg_align_task& t, uint32_t* den, double* known)
+__device__ int anreads_task(const uint8_t* arena, const otg_read& x, const otg_read& y, otg_align_task& t, uint32_t* den, double* known, uint64_t rev_base = 0)
 {
   const bool xs = x.spanning_l && x.spanning_r, ys = y.spanning_l && y.spanning_r;
   if (x.seq_len == y.seq_len && seq_equal(arena + x.seq_off, arena + y.seq_off, x.seq_len)) { *known = 0.0; return 0; }
@@ -113,6 +114,12 @@ __device__ int anreads_task(const uint8_t* arena, const otg_read& x, const otg_r
     if (x.spanning_l) { pbf = 0; pef = length_diff; }
     else if (x.spanning_r) { pbf = length_diff; pef = 0; }
     else { pbf = length_diff / 2; pef = length_diff / 2; }
+    if (x.spanning_r && !x.spanning_l && rev_base) {
+      // a free BEGIN lets the alignment start on any of length_diff + 1 diagonals (wide band); the same distance read from the
+      // other end has a free END and a band of ~1.5 x the distance: align the reversed copies instead
+      make_task(t, rev_base + y.seq_off, y.seq_len, rev_base + x.seq_off, x.seq_len, 1, 0, length_diff, 0, 0);
+      t._pad = 1;             // mirrored: the wavefront-cell statistics are those of the un-reversed alignment
+    } else
     make_task(t, y.seq_off, y.seq_len, x.seq_off, x.seq_len, 1, pbf, pef, 0, 0);
     *den = x.seq_len;
     return 1;
@@ -298,12 +305,30 @@ __global__ void K_scatter_labels(const uint32_t* __restrict__ read_region, const
 }
 
 // ---- invalid_reassignment, task generation (src/analignments.cpp:129-157): slot(i,j) = re_off[r] + i*n + j
+// reversed copy (at + rev_base) of every read of a region that has reads to reassign: a non-spanning read that spans only the
+// right side is compared from the other end (see anreads_task)
+__global__ void K_reverse_reads(uint8_t* __restrict__ arena, const otg_read* __restrict__ reads, const otg_region* __restrict__ regions,
+                                const uint32_t* __restrict__ read_region, uint32_t n_reads, const int32_t* __restrict__ status,
+                                const uint32_t* __restrict__ n_valid, uint64_t rev_base)
+{
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t nw = gridDim.x * (blockDim.x >> 6);
+  for (uint32_t i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < n_reads; i += nw) {
+    const uint32_t r = read_region[i];
+    if (r == 0xffffffffu || status[r] != OTG_REGION_OK || n_valid[r] >= regions[r].n_reads) continue;
+    const otg_read rd = reads[i];
+    const uint8_t* src = arena + rd.seq_off;
+    uint8_t* dst = arena + rev_base + rd.seq_off;
+    for (uint32_t j = lane; j < rd.seq_len; j += 64) dst[j] = src[rd.seq_len - 1 - j];
+  }
+}
+
 __global__ void K_reassign_tasks(const uint8_t* __restrict__ arena, const otg_read* __restrict__ reads,
                                  const otg_region* __restrict__ regions, uint32_t n_regions, const int32_t* __restrict__ status,
                                  const uint32_t* __restrict__ n_valid, const int32_t* __restrict__ fc, const int32_t* __restrict__ labels,
                                  const uint64_t* __restrict__ re_off, otg_align_task* __restrict__ tasks,
                                  uint32_t* __restrict__ den, double* __restrict__ dist,
-                                 uint32_t* __restrict__ todo, uint32_t* __restrict__ n_todo)
+                                 uint32_t* __restrict__ todo, uint32_t* __restrict__ n_todo, uint64_t rev_base)
 {
   for (uint32_t r = blockIdx.x; r < n_regions; r += gridDim.x) {
     if (status[r] != OTG_REGION_OK || fc[r] <= 0) continue;                            // fc == 0: `-a 0` defect, reference UB
@@ -323,7 +348,7 @@ __global__ void K_reassign_tasks(const uint8_t* __restrict__ arena, const otg_re
         const uint64_t slot = re_off[r] + (uint64_t)i * n + j;
         double known = 0;
         uint32_t d = 1;
-        if (anreads_task(arena, x, y, tasks[slot], &d, &known)) { den[slot] = d; todo[atomicAdd(n_todo, 1u)] = (uint32_t)slot; }
+        if (anreads_task(arena, x, y, tasks[slot], &d, &known, rev_base)) { den[slot] = d; todo[atomicAdd(n_todo, 1u)] = (uint32_t)slot; }
         else dist[slot] = known;
       }
     }
@@ -645,7 +670,8 @@ int otg_assemble_submit(otg_ctx* ctx, const otg_params* params, const uint8_t* s
   ctx->max_seq_len = maxlen;
   std::vector<uint64_t> first64(n_regions);
   for (uint32_t r = 0; r < n_regions; ++r) first64[r] = regions[r].first_read;
-  uint8_t* d_arena = (uint8_t*)pbuf(ctx, pl, B_ARENA, arena_bytes + 64);
+  pl->rev_base = (arena_bytes + 64 + 255) & ~(uint64_t)255;
+  uint8_t* d_arena = (uint8_t*)pbuf(ctx, pl, B_ARENA, pl->rev_base + arena_bytes + 64);
   void* d_reads = pbuf(ctx, pl, B_READS, (size_t)n_reads * sizeof(otg_read));
   void* d_regions = pbuf(ctx, pl, B_REGIONS, (size_t)n_regions * sizeof(otg_region));
   void* d_rr = pbuf(ctx, pl, B_READ_REGION, (size_t)n_reads * 4);
@@ -655,6 +681,7 @@ int otg_assemble_submit(otg_ctx* ctx, const otg_params* params, const uint8_t* s
   void* d_f64 = pbuf(ctx, pl, B_FIRST_READ64, (size_t)n_regions * 8);
   if (!d_arena || !d_reads || !d_regions || !d_rr || !d_do || !d_ro || !d_co || !d_f64) return OTG_ERR_HIP;
   HIP_TRY(ctx, hipMemsetAsync(d_arena + arena_bytes, 0, 64, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(d_arena + pl->rev_base + arena_bytes, 0, 64, ctx->stream));
   if (arena_bytes) HIP_TRY(ctx, hipMemcpyAsync(d_arena, seq_arena, arena_bytes, hipMemcpyHostToDevice, ctx->stream));
   if (n_reads) HIP_TRY(ctx, hipMemcpyAsync(d_rr, read_region.data(), (size_t)n_reads * 4, hipMemcpyHostToDevice, ctx->stream));
   if (n_regions) HIP_TRY(ctx, hipMemcpyAsync(d_regions, regions, (size_t)n_regions * sizeof(otg_region), hipMemcpyHostToDevice, ctx->stream));
@@ -795,8 +822,12 @@ static int assemble_run_impl(otg_ctx* ctx, bool realign_only)
   // ------------------------------------------------------------------ invalid_reassignment
   {
     Timer t(ctx);
+    static const bool no_rev = getenv("OTG_NO_REASSIGN_REV") != nullptr;
+    const uint64_t rev_base = no_rev ? 0 : pl->rev_base;
+    if (rev_base) hipLaunchKernelGGL(K_reverse_reads, dim3(std::min<uint32_t>((NR + 3) / 4, (uint32_t)ctx->n_cu * 32)), dim3(256), 0, st, d_arena, d_reads, d_regions, d_rr, NR,
+                                     d_status, d_nvalid, rev_base);
     hipLaunchKernelGGL(K_reassign_tasks, dim3(gr_blocks), dim3(64), 0, st, d_arena, d_reads, d_regions, NG, d_status, d_nvalid, (const int32_t*)B(B_FC), d_labels,
-                       (const uint64_t*)B(B_RE_OFF), d_tasks, d_den, d_redist, d_todo, d_cnt + 24);
+                       (const uint64_t*)B(B_RE_OFF), d_tasks, d_den, d_redist, d_todo, d_cnt + 24, rev_base);
     float kms = 0; uint64_t kl = 0;
     rc = otg_launch_edit_todo(ctx, d_arena, d_tasks, d_todo, d_cnt + 24, (uint32_t)pl->n_re_slots, d_scores, d_cells, &kms, &kl);
     if (rc) return rc;

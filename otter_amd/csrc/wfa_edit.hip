@@ -125,7 +125,7 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_kernel(
     // wave-uniform tail: every lane stores the same value to the same address (one write after coalescing)
     if (done) {
       scores[ti] = s;
-      if (cells) cells[ti] = W;
+      if (cells) cells[ti] = (t._pad & 1) ? otg_edit_wfa_cells(s, pl, tl, ef ? (int)t.pattern_end_free : 0, ef ? (int)t.text_end_free : 0) : W;   // mirrored task: cells of the un-reversed form
     } else if (overflow && overflow_list) {
       const uint32_t q = otg_wave_atomic_add(n_overflow, 1u);
       overflow_list[q] = ti;
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_kernel_v2(
     }
     if (done) {
       scores[ti] = s;
-      if (cells) cells[ti] = W;
+      if (cells) cells[ti] = (t._pad & 1) ? otg_edit_wfa_cells(s, pl, tl, ef ? (int)t.pattern_end_free : 0, ef ? (int)t.text_end_free : 0) : W;   // mirrored task: cells of the un-reversed form
     } else if (overflow && route_cnt) {
       // Route to the bit-parallel tier whose band fits the ESTIMATED distance: score so far scaled by the share of
       // both sequences the furthest wavefront point has covered, plus the length difference.  Only a scheduling
