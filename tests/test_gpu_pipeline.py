@@ -164,3 +164,57 @@ def test_realign_only_reads(gpu, oracle):
     # without -r nothing moves
     same = gpu.realign_reads(abi.default_params(), b)
     assert np.array_equal(same["seq_len"], b["reads"]["seq_len"]) and np.array_equal(same["spanning_l"], b["reads"]["spanning_l"])
+
+
+def test_full_size_config1_properties(gpu, oracle):
+    """BASELINE configs[1] at full size (10 000 regions x 30 ONT reads of 1-5 kb, the bench workload), checked through what
+    does not need the oracle on every region: two runs agree bit for bit; a shard run alone equals the same regions inside the whole
+    batch; coverage / label / length invariants hold for every region; and three 16-region windows at the start, middle and end
+    equal the oracle record for record."""
+    import threading
+    N = 10000
+    b = synth.make_batch(N, len_range=(1000, 5000), n_reads=30, err="ont", seed=synth.SEED)
+    P = abi.default_params()
+    r1 = gpu.assemble(P, b)
+    r2 = gpu.assemble(P, b)
+    for k in ("regions", "alleles", "labels"):
+        assert r1[k].tobytes() == r2[k].tobytes(), k
+    nseq = int(r1["alleles"]["seq_len"].astype(np.int64).sum())
+    assert r1["seqs"][:nseq].tobytes() == r2["seqs"][:nseq].tobytes()
+
+    def alleles_of(res, lo, hi, base=0):
+        out = []
+        for r in range(lo, hi):
+            g = res["regions"][r - base]
+            for a in res["alleles"][int(g["first_allele"]):int(g["first_allele"]) + int(g["n_alleles"])]:
+                out.append((r, int(a["label"]), int(a["scov"]), int(a["acov"]), int(a["tcov"]), float(a["se"]), int(a["ic"]),
+                            res["seqs"][int(a["seq_off"]):int(a["seq_off"]) + int(a["seq_len"])].tobytes()))
+        return out
+    part = gpu.assemble(P, b, region_range=(4000, 4064))
+    assert alleles_of(part, 4000, 4064, base=4000) == alleles_of(r1, 4000, 4064)       # a shard's result arrays start at its first region
+
+    reg, al = r1["regions"], r1["alleles"]
+    ok = reg["status"] == 0
+    assert ok.sum() > 0.99 * N
+    assert ((reg["fc"][ok] >= 1) & (reg["fc"][ok] <= P.max_alleles) & (reg["n_alleles"][ok] == reg["fc"][ok])).all()
+    assert ((al["scov"] <= al["acov"]) & (al["acov"] <= al["tcov"]) & (al["tcov"] <= 30) & (al["scov"] >= 1)).all()
+    lens = b["reads"]["seq_len"].astype(np.int64)
+    first = b["regions"]["first_read"].astype(np.int64)
+    rmin = np.minimum.reduceat(lens, first); rmax = np.maximum.reduceat(lens, first)
+    ar = al["region"].astype(np.int64)
+    assert ((al["seq_len"] >= rmin[ar] // 2) & (al["seq_len"] <= rmax[ar] * 3 // 2)).all()
+    assert np.isin(r1["seqs"][:nseq], np.frombuffer(b"ACGTN", dtype=np.uint8)).all()
+    fc_per_read = np.repeat(reg["fc"], b["regions"]["n_reads"])
+    assert ((r1["labels"] >= -1) & (r1["labels"] < np.maximum(fc_per_read, 1))).all()
+
+    windows = [(0, 16), (5000, 5016), (N - 16, N)]
+    got = [None] * len(windows)
+
+    def work(i):
+        got[i] = oracle.assemble_batch(P, b, region_range=windows[i])
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(windows))]
+    [t.start() for t in th]; [t.join() for t in th]
+    for (lo, hi), ora in zip(windows, got):
+        assert alleles_of(ora, lo, hi) == alleles_of(r1, lo, hi), (lo, hi)
+        f0, f1 = int(first[lo]), int(first[hi - 1] + b["regions"]["n_reads"][hi - 1])
+        assert np.array_equal(ora["labels"][f0:f1], r1["labels"][f0:f1])
