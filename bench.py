@@ -86,7 +86,9 @@ def main():
     # static BED split: rank r owns the r-th contiguous shard of world*regions regions (seeded per shard)
     batch = synth.make_batch(args.regions, len_range=(args.len_min, args.len_max), n_reads=args.reads, err=args.err,
                              realign=args.realign, seed=synth.SEED + rank)
+    t_sub = time.perf_counter()
     ctx.assemble_submit(params, batch)       # H2D: inputs are resident in HBM from here on
+    submit_ms = (time.perf_counter() - t_sub) * 1000.0     # not part of `value`: reported so that the PCIe-inclusive rate can be derived
 
     def sync():
         torch.cuda.synchronize()
@@ -165,7 +167,8 @@ def main():
                    "stage_ms": {k: round(float(st[k]), 2) for k in ("ms_realign", "ms_edit", "ms_cluster", "ms_reassign", "ms_affine", "ms_poa", "ms_total")},
                    "edit_pairs": int(st["edit_tasks"]), "affine_alignments": int(st["affine_tasks"]),
                    "wavefront_cells": int(st["edit_cells"]) + int(st["affine_cells"]),
-                   "exp_variant": "glibc-fma" if ctx.exp_variant else "glibc-nofma"},
+                   "exp_variant": "glibc-fma" if ctx.exp_variant else "glibc-nofma",
+                   "h2d_submit_ms": round(submit_ms, 2), "input_bytes": int(batch["arena"].size + batch["reads"].nbytes + batch["regions"].nbytes)},
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "algorithmic_bytes_per_launch": kbytes // kl, "avg_launch_ms": round(kms / kl, 3),
