@@ -246,6 +246,7 @@ int otg_emit_sam_header(const char* name_arena, const uint64_t* name_off, const 
  * otg_assemble_submit.  Host code (zlib + stdio); the index is `<bam>.bai` (src/anbamfilehelper.cpp:20).
  * ------------------------------------------------------------------------------------------- */
 typedef struct otg_bam otg_bam;
+typedef struct otg_fasta otg_fasta;     /* indexed FASTA handle, see otg_fasta_open below */
 typedef struct otg_ingest_opts {
   int32_t offset_l, offset_r;   /* --offset: the query region is [start - offset_l, end + offset_r] (src/assemble.cpp:55-57) */
   int32_t mapq;                 /* --mapq                                                     */
@@ -298,7 +299,7 @@ const char* otg_bam_sample(const otg_bam* bam, uint32_t i);      /* valid after 
  * (src/genotype.cpp:92-101: bases [start - offset_l, end + offset_r - 1], sample index = n_samples) is appended to every
  * non-empty region.  first_allele has n_regions + 1 entries (in-out counter *n_alleles is the running total). */
 int  otg_ingest_alleles(otg_bam* bam, const otg_bed* beds, const char* chr_arena, uint32_t n_regions, int32_t threads,
-                        const struct otg_fasta* reference, uint8_t* arena, uint64_t arena_capacity, uint64_t* arena_used,
+                        const otg_fasta* reference, uint8_t* arena, uint64_t arena_capacity, uint64_t* arena_used,
                         otg_allele* alleles, uint32_t alleles_capacity, uint32_t* n_alleles, uint32_t* first_allele);
 
 /* `otter genotype` record emit.  The header: output_vcf_header (src/genotype.cpp:16-40; contigs = BAM targets,
@@ -330,7 +331,6 @@ int  otg_parse_bed_file(const char* path, otg_bed* beds, uint32_t beds_capacity,
 /* FaidxInstance (src/anfahelper.cpp:6-20) over an uncompressed FASTA with its `.fai` (read when present, otherwise built
  * as src/faidx.c:64-133 does and written beside the file when possible).  Handles are read-only after open: one may be
  * shared by threads. */
-typedef struct otg_fasta otg_fasta;
 int  otg_fasta_open(const char* fasta_path, otg_fasta** out);
 void otg_fasta_close(otg_fasta* fa);
 uint32_t otg_fasta_n_seqs(const otg_fasta* fa);

@@ -33,13 +33,16 @@ def test_struct_layouts_match_c(tmp_path):
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "otter_gpu.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    'sizeof(otg_params),sizeof(otg_align_task),sizeof(otg_read),sizeof(otg_region),sizeof(otg_allele),'
                    'sizeof(otg_region_result),sizeof(otg_poa_member),sizeof(otg_poa_graph),sizeof(otg_run_stats),'
-                   'offsetof(otg_allele,se),offsetof(otg_read,ccoord_second));return 0;}\n')
+                   'offsetof(otg_allele,se),offsetof(otg_read,ccoord_second));'
+                   'printf("%zu %zu %zu %zu\\n",sizeof(otg_bed),sizeof(otg_read_meta),sizeof(otg_ingest_opts),offsetof(otg_ingest_opts,read_quality));return 0;}\n')
     exe = tmp_path / "sz"
-    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    # the boundary is a plain C header: strict C99, no warnings (a type used before its declaration would only warn)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     exp = [C.sizeof(abi.otg_params), abi.align_task_dt.itemsize, abi.read_dt.itemsize, abi.region_dt.itemsize, abi.allele_dt.itemsize,
            abi.region_result_dt.itemsize, abi.poa_member_dt.itemsize, abi.poa_graph_dt.itemsize, abi.run_stats_dt.itemsize,
-           abi.allele_dt.fields["se"][1], abi.read_dt.fields["ccoord_second"][1]]
+           abi.allele_dt.fields["se"][1], abi.read_dt.fields["ccoord_second"][1],
+           abi.bed_dt.itemsize, abi.read_meta_dt.itemsize, abi.ingest_opts_dt.itemsize, abi.ingest_opts_dt.fields["read_quality"][1]]
     assert got == exp
 
 
