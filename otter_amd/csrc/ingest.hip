@@ -10,6 +10,7 @@
 #include <cerrno>
 #include <zlib.h>
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <string>
 #include <thread>
@@ -18,20 +19,41 @@
 
 namespace {
 
+static std::atomic<unsigned long long> g_blocks_inflated{0};      // OTG_DEBUG statistics
+
 struct Bgzf {
   FILE* fp = nullptr;
   uint64_t block_address = 0;      // file offset of the current (or next, when nothing is loaded) block
   uint32_t block_csize = 0;        // compressed size of the loaded block (0 = nothing loaded)
   uint32_t block_length = 0;       // its uncompressed size
   uint32_t block_offset = 0;
-  std::vector<uint8_t> cbuf, ubuf;
+  std::vector<uint8_t> cbuf;
+  // Inflated blocks are kept in a small LRU set: consecutive regions of a BED file query overlapping runs of blocks (a region's
+  // chunk starts at the 16 kb window of the linear index, i.e. inside the records of the regions before it), so without it every
+  // block is inflated about three times.
+  struct Slot { uint64_t address = ~0ull; uint32_t csize = 0, length = 0; uint64_t stamp = 0; std::vector<uint8_t> data; };
+  static constexpr int NSLOT = 32;
+  Slot slots[NSLOT];
+  int cur = 0;                     // slot of the loaded block
+  uint64_t clock_ = 0;
   bool eof = false;
+  z_stream zs;
+  bool zs_ready = false;
 
   bool open(const char* path) { fp = fopen(path, "rb"); return fp != nullptr; }
-  void close() { if (fp) fclose(fp); fp = nullptr; }
+  void close() { if (fp) fclose(fp); fp = nullptr; if (zs_ready) { inflateEnd(&zs); zs_ready = false; } }
   // loads the block at block_address; false on EOF / malformed data
   bool load() {
     block_csize = block_length = block_offset = 0;
+    for (int i = 0; i < NSLOT; ++i) if (slots[i].address == block_address && slots[i].csize) {
+      cur = i; slots[i].stamp = ++clock_; block_csize = slots[i].csize; block_length = slots[i].length;
+      return true;
+    }
+    int victim = 0;
+    for (int i = 1; i < NSLOT; ++i) if (slots[i].stamp < slots[victim].stamp) victim = i;
+    Slot& S = slots[victim];
+    S.address = ~0ull; S.csize = 0;
+    std::vector<uint8_t>& ubuf = S.data;
     if (fseeko(fp, (off_t)block_address, SEEK_SET) != 0) return false;
     uint8_t h[12];
     if (fread(h, 1, 12, fp) != 12) { eof = true; return false; }
@@ -56,14 +78,15 @@ struct Bgzf {
     const uint32_t isize = t[4] | (t[5] << 8) | (t[6] << 16) | ((uint32_t)t[7] << 24);
     ubuf.resize(isize ? isize : 1);
     if (isize) {
-      z_stream zs{};
+      if (!zs_ready) { memset(&zs, 0, sizeof zs); if (inflateInit2(&zs, -15) != Z_OK) return false; zs_ready = true; }
+      else if (inflateReset(&zs) != Z_OK) return false;            // one inflate state per reader, not one per block
       zs.next_in = cbuf.data(); zs.avail_in = clen; zs.next_out = ubuf.data(); zs.avail_out = isize;
-      if (inflateInit2(&zs, -15) != Z_OK) return false;
       const int rc = inflate(&zs, Z_FINISH);
-      inflateEnd(&zs);
       if (rc != Z_STREAM_END || zs.total_out != isize) return false;
     }
     block_csize = total; block_length = isize;
+    S.address = block_address; S.csize = total; S.length = isize; S.stamp = ++clock_; cur = victim;
+    g_blocks_inflated.fetch_add(1, std::memory_order_relaxed);
     return true;
   }
   // like bgzf_read: returns bytes read (< n at end of file)
@@ -77,7 +100,7 @@ struct Bgzf {
         if (block_length == 0) { if (eof) break; continue; }     // empty block (e.g. the EOF marker): try the next one
       }
       const size_t k = std::min<size_t>(n - got, block_length - block_offset);
-      memcpy(out + got, ubuf.data() + block_offset, k);
+      memcpy(out + got, slots[cur].data.data() + block_offset, k);
       got += k; block_offset += (uint32_t)k;
     }
     if (block_csize && block_offset == block_length) {           // bgzf_tell semantics: a fully consumed block points at the next one
@@ -272,7 +295,7 @@ struct ParseMsg { bool successful = true, spanning_l = true, spanning_r = true; 
 void get_breakpoints(int start, int end, const Rec& r, ParseMsg& msg, bool& have, int& q_first, int& q_second)
 {
   bool clipped_l = false, clipped_r = false;
-  int qstart_dist = -1, qend_dist = -1;
+  int qstart_dist = -1;
   int leftmost_q = -1, rightmost_q = -1, leftmost_r = -1, rightmost_r = -1;
   int qstart_q = -1, qend_q = -1;
   uint32_t qstart_cigar_i = 0, qend_cigar_i = 0;
@@ -285,13 +308,23 @@ void get_breakpoints(int start, int end, const Rec& r, ParseMsg& msg, bool& have
       if (i == r.n_cigar - 1) clipped_r = true;
       if (op == 4) qpos += ol;
     } else if (op == 0 || op == 7 || op == 8) {    // M, =, X
-      for (int j = 0; j < ol; ++j) {
+      // The reference visits every base of the op (:301-322).  Reference positions only grow along the CIGAR, so what its
+      // per-base updates leave behind is: leftmost = first aligned base, rightmost = last aligned base, the query start = the
+      // FIRST aligned base at or after `start` (later ones are farther), the query end = the LAST aligned base at or before
+      // `end` (every closer one overwrites) — computed per op here.
+      if (ol > 0) {
         if (leftmost_q == -1) { leftmost_q = qpos; leftmost_r = rpos; }
-        if (rightmost_q == -1 || rpos > rightmost_r) { rightmost_q = qpos; rightmost_r = rpos; }
-        const int cstart_dist = rpos - start, cend_dist = end - rpos;
-        if (cstart_dist >= 0 && (qstart_dist < 0 || cstart_dist < qstart_dist)) { qstart_dist = cstart_dist; qstart_q = qpos; qstart_cigar_i = i; }
-        if (cend_dist >= 0 && (qend_dist < 0 || cend_dist < qend_dist)) { qend_dist = cend_dist; qend_q = qpos; qend_cigar_i = i; }
-        ++rpos; ++qpos;
+        rightmost_q = qpos + ol - 1; rightmost_r = rpos + ol - 1;
+        if (qstart_dist < 0) {
+          long long j0 = (long long)start - rpos; if (j0 < 0) j0 = 0;
+          if (j0 < ol) { qstart_dist = (int)(rpos + j0 - start); qstart_q = qpos + (int)j0; qstart_cigar_i = i; }
+        }
+        long long j1 = (long long)end - rpos;
+        if (j1 >= 0) {
+          if (j1 > ol - 1) j1 = ol - 1;
+          qend_q = qpos + (int)j1; qend_cigar_i = i;
+        }
+        rpos += ol; qpos += ol;
       }
     } else if (op == 1) qpos += ol;                // I
     else if (op == 2) rpos += ol;                  // D   (N, P: ignored, as in the reference)
@@ -648,6 +681,7 @@ int otg_ingest_regions_named(otg_bam* b, const otg_bed* beds, const char* chr_ar
   }
   *arena_used = used; *n_reads = nr;
   if (want_meta) *name_used = nused;
+  if (getenv("OTG_DEBUG")) fprintf(stderr, "[otg] ingest: %llu BGZF blocks inflated so far, %u reads kept in this call\n", g_blocks_inflated.load(), nr);
   return overflow ? OTG_ERR_CAPACITY : OTG_OK;
 }
 
