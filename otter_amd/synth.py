@@ -2,6 +2,7 @@
 parse_anreads (src/anseqs.cpp:439-460) would hand to the region loop — per read the region
 sub-sequence, spanning flags and clip coordinates — laid out as the C-ABI region batch
 (include/otter_gpu.h: otg_read / otg_region + one byte arena).  Seed 20241008."""
+import os
 import numpy as np
 from . import abi
 
@@ -154,3 +155,101 @@ def shard_bounds(n_regions, world, rank):
     a = rank * block
     b = n_regions if rank == world - 1 else a + block
     return a, b
+
+
+# ---- large batches: fixed 250-region chunks, each with its own seed, generated by worker processes ------------------
+CHUNK = 250
+
+
+def _chunk_job(args):
+    c, n, seed, kw = args
+    return make_batch(n, seed=seed * 1000003 + c, **kw)
+
+
+def concat_batches(parts):
+    """Concatenates region batches (arena offsets, read indices rebased); the 64 slack bytes stay at the end only."""
+    arenas, reads, regions, truth = [], [], [], []
+    abase = rbase = 0
+    for p in parts:
+        a = p["arena"][:-64] if p["arena"].size >= 64 else p["arena"]
+        rd = p["reads"].copy(); rg = p["regions"].copy()
+        rd["seq_off"] += abase
+        rg["first_read"] += rbase
+        has_fl = (rg["flank_l_len"] > 0) | (rg["flank_r_len"] > 0)
+        rg["flank_l_off"][has_fl] += abase
+        rg["flank_r_off"][has_fl] += abase
+        arenas.append(a); reads.append(rd); regions.append(rg); truth.append(p["truth"])
+        abase += a.size; rbase += len(rd)
+    arenas.append(np.zeros(64, dtype=np.uint8))
+    return {"arena": np.concatenate(arenas), "reads": np.concatenate(reads) if reads else np.zeros(0, dtype=abi.read_dt),
+            "regions": np.concatenate(regions) if regions else np.zeros(0, dtype=abi.region_dt),
+            "truth": np.concatenate(truth) if truth else np.zeros((0, 3), dtype=np.int64)}
+
+
+def _worker_main(argv):
+    """Entry of a generator worker process: python -c '...' <out_dir> <json jobs>; writes one .npz per chunk."""
+    import json
+    out_dir, jobs = argv[0], json.loads(argv[1])
+    for c, n, seed, kw in jobs:
+        if "len_range" in kw:
+            kw["len_range"] = tuple(kw["len_range"])
+        p = make_batch(n, seed=seed * 1000003 + c, **kw)
+        np.savez(os.path.join(out_dir, "c%d.npz" % c), arena=p["arena"], reads=p["reads"], regions=p["regions"], truth=p["truth"])
+
+
+def make_batch_chunked(n_regions, seed=SEED, workers=None, first_chunk=0, **kw):
+    """Same distribution as make_batch, generated as independent 250-region chunks (chunk c is seeded by (seed, c), so the result
+    does not depend on the number of workers, and a rank's shard [a, b) of a larger job is chunks a/250 .. b/250 of it:
+    `first_chunk`).  workers > 1: chunks are generated by child processes started with subprocess (fresh interpreters that import
+    numpy only — nothing of a GPU-initialised parent is inherited) and handed back through files in a temporary directory."""
+    jobs = []
+    c, left = first_chunk, n_regions
+    while left > 0:
+        n = min(CHUNK, left)
+        jobs.append((c, n, seed, kw))
+        c += 1; left -= n
+    if workers is None:
+        workers = min(len(jobs), max(1, min(16, (os.cpu_count() or 1))))
+    if workers <= 1 or len(jobs) <= 1:
+        return concat_batches([_chunk_job(j) for j in jobs])
+    import json
+    import shutil
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tmp = tempfile.mkdtemp(prefix="otg_synth_")
+    try:
+        procs = []
+        for w in range(workers):
+            mine = jobs[w::workers]
+            if not mine:
+                continue
+            code = "import sys; sys.path.insert(0, %r); from otter_amd import synth; synth._worker_main(sys.argv[1:])" % root
+            procs.append(subprocess.Popen([sys.executable, "-c", code, tmp, json.dumps(mine)], stdin=subprocess.DEVNULL))
+        for p in procs:
+            if p.wait(timeout=1800) != 0:
+                raise RuntimeError("synthetic batch worker failed (exit %d)" % p.returncode)
+        parts = []
+        for c, n, _, _ in jobs:
+            with np.load(os.path.join(tmp, "c%d.npz" % c)) as z:
+                parts.append({k: z[k] for k in ("arena", "reads", "regions", "truth")})
+        return concat_batches(parts)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def config_batch(idx, n_regions=None, seed=SEED, workers=None, first_chunk=0):
+    """The synthetic workload of BASELINE.json configs[idx] (n_regions overrides the region count: a per-GPU shard or a test slice)."""
+    kw = dict(CONFIGS[idx])
+    n = kw.pop("n_regions")
+    return make_batch_chunked(n if n_regions is None else n_regions, seed=seed, workers=workers, first_chunk=first_chunk, **kw)
+
+
+def config_workload(idx, n_regions, world=1):
+    """Human-readable workload string for bench.py's config.workload, derived from CONFIGS (never hand-written)."""
+    kw = CONFIGS[idx]
+    lo, hi = kw["len_range"]
+    return "BASELINE configs[%d]: otter assemble%s hot path, %d regions%s x %d-%d bp TR, %dx %s-error reads" % (
+        idx, " -r (local re-alignment, divergent soft-clipped flanks)" if kw.get("realign") else "", n_regions,
+        "/GPU (static BED shard of %d)" % (n_regions * world) if world > 1 else "", lo, hi, kw["n_reads"], kw["err"].upper())

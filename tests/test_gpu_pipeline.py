@@ -218,3 +218,34 @@ def test_full_size_config1_properties(gpu, oracle):
         assert alleles_of(ora, lo, hi) == alleles_of(r1, lo, hi), (lo, hi)
         f0, f1 = int(first[lo]), int(first[hi - 1] + b["regions"]["n_reads"][hi - 1])
         assert np.array_equal(ora["labels"][f0:f1], r1["labels"][f0:f1])
+
+
+def test_stale_cigar_member(gpu, oracle):
+    """The case the reference handles by NOT aligning (src/analignments.cpp:267-273): a labelled member that is longer than the
+    representative and spans neither side reaches PPOA::insert_alignment with whatever op string the aligner object still holds.
+    Here (oracle and GPU alike, DESIGN.md §3 'waived') that is the op string of the previous member of the same allele, or the empty
+    string for the allele's first member.  The reference's aligner would instead still hold the op string of its last call — possibly
+    from the previous allele or the previous region of the worker thread, i.e. dependent on the thread split — so only the scoped form
+    is deterministic.  Both forms of the case are built (member first in its allele / not first) and must match the oracle."""
+    b = synth.make_batch(12, len_range=(300, 600), n_reads=12, err="hifi", seed=77, frac_partial=0.0)
+    reads, regions = b["reads"].copy(), b["regions"]
+    picked = []
+    for r in range(len(regions)):
+        f = int(regions[r]["first_read"])
+        i = f + (0 if r % 2 == 0 else 5)
+        # 12 more bases (they are the next read's first bases in the arena): longer than every other read of the region
+        reads["seq_len"][i] += 12
+        reads["spanning_l"][i] = 0
+        reads["spanning_r"][i] = 0
+        picked.append(i)
+    b2 = dict(b, reads=reads)
+    res, _ = run_both(gpu, oracle, b2)
+    lab = res["labels"][picked]
+    assert (lab >= 0).sum() >= 8                         # re-assigned by similarity, so they are members of an allele graph
+    # and the case is live: their allele is built by POA (more than two reads) and they are longer than the representative
+    for i, r in zip(picked, range(len(regions))):
+        if lab[picked.index(i)] < 0:
+            continue
+        g = res["regions"][r]
+        a = res["alleles"][int(g["first_allele"]) + int(lab[picked.index(i)])]
+        assert int(a["acov"]) > 2 and int(reads["seq_len"][i]) > int(a["seq_len"]) - 8
