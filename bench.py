@@ -2,74 +2,148 @@
 """bench.py — regions/sec of the otter assemble hot path on MI355X (contract in the task brief).
 
 A step = one pass of the whole hot path ([local_realignment] -> fill_dist_matrix -> otter_hclust ->
-invalid_reassignment -> rapid_consensus) over one resident batch of synthetic TR regions; inputs are
-uploaded (otg_assemble_submit) before the timed region.  N=1 workload: BASELINE.json configs[1]
-(10k regions x 1-5 kb TR, 30x ONT-error reads).  N>1: regions are sharded statically (each rank owns a
-contiguous shard of N x per-GPU regions, weak scaling) with no data-path collective; the per-rank allele
-records are gathered to rank 0 over RCCL at the end of every step, as north_star specifies.
+invalid_reassignment -> rapid_consensus) over one batch of synthetic TR regions that is already resident in HBM
+(otg_assemble_submit ran before the timed region), INCLUDING the hand-over of the allele records to the host:
+otg_assemble_collect at N=1, the RCCL gather to rank 0 + its one device-to-host copy at N>1.
+
+Workloads come from otter_amd.synth.CONFIGS (= BASELINE.json configs): --config 1 (default at N=1: 10 000 regions x 1-5 kb,
+30x ONT), --config 2 (the same with -r and soft-clipped divergent flanks), --config 4 (default at N>1: 1-10 kb regions,
+12 500 per GPU = the per-GPU shard of the 100 000-region 8-GPU job).  N>1: static contiguous BED split (rank r owns the
+r-th shard, weak scaling), no data-path collective, end-of-run gather of the records over RCCL as north_star specifies.
+
+`python bench.py --gpus N` without a launcher starts the N ranks itself: the parent never imports torch or touches the
+GPU, it starts N fresh child processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set before anything is imported) and
+relays rank 0's line; under torchrun (WORLD_SIZE set) it is simply one rank.
 
 Prints ONE JSON line on rank 0."""
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "pmc_summary.json")   # written by scripts/pmc_bench.sh + scripts/pmc_summarize.py
 
 
-def cpu_baseline(batch, params, n_sample, n_threads):
-    """Times the CPU oracle (a port of the reference algorithm, kind 'port') on the first n_sample regions
-    of the same workload, n_threads host threads (ctypes releases the GIL), static contiguous split."""
-    import oracle_lib
-    oracle_lib.lib()
-    n_sample = min(n_sample, len(batch["regions"]))
-    bounds = [(i * n_sample // n_threads, (i + 1) * n_sample // n_threads) for i in range(n_threads)]
-    done = [0] * n_threads
-
-    def work(i):
-        a, b = bounds[i]
-        if b > a:
-            r = oracle_lib.assemble_batch(params, batch, region_range=(a, b))
-            done[i] = int((r["regions"]["n_alleles"][a:b] > 0).sum())
-
-    t0 = time.perf_counter()
-    th = [threading.Thread(target=work, args=(i,)) for i in range(n_threads)]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    dt = time.perf_counter() - t0
-    return {"value": round(sum(done) / dt, 4), "unit": "regions/s", "cores": n_threads, "kind": "port",
-            "sample": "first %d regions of the same synthetic workload, oracle/libotter_oracle.so (scalar C++ WFA + O(N+E) "
-                      "consensus), %d threads, %.1f s" % (n_sample, n_threads, dt)}
-
-
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--regions", type=int, default=10000, help="regions per GPU (config 1: 10000)")
-    ap.add_argument("--len-min", type=int, default=1000)
-    ap.add_argument("--len-max", type=int, default=5000)
-    ap.add_argument("--reads", type=int, default=30)
-    ap.add_argument("--err", default="ont")
-    ap.add_argument("--realign", action="store_true", help="config 2: -r given, soft-clipped flanks")
-    ap.add_argument("--cpu-sample", type=int, default=192)
+    ap.add_argument("--config", type=int, default=None, choices=(1, 2, 4), help="BASELINE.json configs index (default: 1 at N=1, 4 at N>1)")
+    ap.add_argument("--regions", type=int, default=None, help="regions per GPU (default: the config's own count; config 4: 100000/8)")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU work per cpu_baseline run (3 runs per kind)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    return ap.parse_args()
 
+
+# ------------------------------------------------------------------------------------------------ N-rank launch
+def spawn_ranks(n):
+    """Parent of a self-launched N-rank run.  Imports nothing that touches the GPU."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stdin=subprocess.DEVNULL))
+    out0 = []
+    t = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()))
+    t.start()
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in list(pending):
+            c = procs[r].poll()
+            if c is None:
+                continue
+            pending.discard(r)
+            if c != 0 and rc == 0:
+                rc = c if c > 0 else 1
+                sys.stderr.write("bench.py: rank %d exited with %d; stopping the other ranks\n" % (r, c))
+                for q in pending:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    t.join()
+    sys.stdout.write((out0[0] or b"").decode(errors="replace"))
+    sys.stdout.flush()
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------ CPU baselines
+def cpu_baseline(batch, params, seconds, n_threads):
+    """The CPU oracle (oracle/libotter_oracle.so, a port of the reference algorithm) on a bounded sample of the same workload, all host
+    threads (ctypes releases the GIL; static contiguous split as the reference's thread pool).  Two kinds, three runs each, median:
+      port                 — the port as it is (O(N+E) consensus): BASELINE.md §3 baseline B
+      reference_consensus  — the same regions with every consensus computed by the REFERENCE'S OWN PPOA (src/anppoa.hpp, quadratic
+                             heaviest path :254-288) compiled into oracle/_ref/libotter_ref.so: baseline A.  Neither is the reference
+                             binary (WFA2-lib is absent); alignment and clustering are the port in both."""
+    import ctypes as C
+    import numpy as np
+    import oracle_lib
+    L = oracle_lib.lib()
+    n_regions = len(batch["regions"])
+
+    def run(n_sample):
+        bounds = [(i * n_sample // n_threads, (i + 1) * n_sample // n_threads) for i in range(n_threads)]
+        done = [0] * n_threads
+
+        def work(i):
+            a, b = bounds[i]
+            if b > a:
+                r = oracle_lib.assemble_batch(params, batch, region_range=(a, b))
+                done[i] = int((r["regions"]["n_alleles"][a:b] > 0).sum())
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=work, args=(i,)) for i in range(n_threads)]
+        [t.start() for t in th]; [t.join() for t in th]
+        return sum(done), time.perf_counter() - t0
+
+    def measure(label):
+        ok, dt = run(n_threads)                                   # pilot: one region per thread sizes the sample
+        n = int(min(n_regions, max(n_threads, n_threads * round(seconds / max(dt, 1e-3)))))
+        rates, times = [], []
+        for _ in range(3):
+            ok, dt = run(n)
+            rates.append(ok / dt); times.append(dt)
+        return {"value": round(float(np.median(rates)), 4), "unit": "regions/s", "cores": n_threads, "runs": [round(x, 4) for x in rates],
+                "sample": "first %d regions of the same synthetic workload, %d threads, %s; 3 runs of %.1f-%.1f s, median" % (
+                    n, n_threads, label, min(times), max(times))}
+
+    out = dict(measure("oracle/libotter_oracle.so: scalar C++ WFA + O(N+E) consensus (BASELINE.md baseline B)"), kind="port")
+    refp = os.path.join(ROOT, "oracle", "_ref", "libotter_ref.so")
+    if os.path.exists(refp):
+        R = C.CDLL(refp)
+        L.oto_set_poa_hook.argtypes = [C.c_void_p]
+        L.oto_set_poa_hook(C.cast(R.ref_poa_consensus_one, C.c_void_p))
+        try:
+            a = measure("the same port with every consensus through the reference's own PPOA (oracle/_ref/libotter_ref.so, quadratic "
+                        "heaviest path of src/anppoa.hpp:254-288; BASELINE.md baseline A)")
+            out["reference_consensus"] = dict(a, kind="port + reference PPOA")
+        finally:
+            L.oto_set_poa_hook(None)
+    else:
+        out["reference_consensus"] = None
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ one rank
+def run_rank(args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d — start it as `python bench.py --gpus N` (it launches the ranks itself) "
+                         "or under torchrun with --nproc-per-node equal to --gpus\n" % (args.gpus, world))
+        return 2
+    import numpy as np
     import torch
     dist = None
     if world > 1:
@@ -81,14 +155,20 @@ def main():
     import otter_amd
     from otter_amd import abi, synth, parallel
 
+    cfg = args.config if args.config is not None else (1 if world == 1 else 4)
+    n_regions = args.regions if args.regions is not None else (synth.CONFIGS[cfg]["n_regions"] // 8 if cfg == 4 else synth.CONFIGS[cfg]["n_regions"])
     ctx = otter_amd.Context(local_rank)
-    params = abi.default_params(realign=1 if args.realign else 0)
-    # static BED split: rank r owns the r-th contiguous shard of world*regions regions (seeded per shard)
-    batch = synth.make_batch(args.regions, len_range=(args.len_min, args.len_max), n_reads=args.reads, err=args.err,
-                             realign=args.realign, seed=synth.SEED + rank)
+    params = abi.default_params(realign=1 if synth.CONFIGS[cfg].get("realign") else 0)
+    # static BED split: rank r owns the r-th contiguous shard of world * n_regions regions (chunk-seeded generator: the shard is the
+    # same bytes whatever the world size)
+    if n_regions % synth.CHUNK and world > 1:
+        sys.stderr.write("bench.py: --regions must be a multiple of %d for N>1\n" % synth.CHUNK)
+        return 2
+    batch = synth.config_batch(cfg, n_regions, first_chunk=rank * (n_regions // synth.CHUNK) if world > 1 else 0,
+                               workers=max(1, min(16, (os.cpu_count() or 1) // max(1, world))))
     t_sub = time.perf_counter()
     ctx.assemble_submit(params, batch)       # H2D: inputs are resident in HBM from here on
-    submit_ms = (time.perf_counter() - t_sub) * 1000.0     # not part of `value`: reported so that the PCIe-inclusive rate can be derived
+    submit_ms = (time.perf_counter() - t_sub) * 1000.0
 
     def sync():
         torch.cuda.synchronize()
@@ -96,20 +176,25 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    gathered = {}
+    info = {}
 
     def step():
         ctx.assemble_run()
         if dist is not None:
-            # end-of-run gather of the per-region allele records to rank 0 (RCCL over xGMI), straight from the
-            # library's device-resident result buffers: GPU -> GPU, one device-to-host copy on rank 0
-            try:
-                res = ctx.assemble_device_results()
-            except Exception:                      # same records through the host (otg_assemble_collect) if wrapping fails
-                res = ctx.assemble_collect()
+            # end-of-run gather of the per-region allele records to rank 0 (RCCL over xGMI), straight from the library's
+            # device-resident result buffers: GPU -> GPU, one device-to-host copy on rank 0
+            t0 = time.perf_counter()
+            res = ctx.assemble_device_results()
             g = parallel.gather_records(res, dist, rank, world, torch.device("cuda", local_rank))
+            info["gather_ms"] = (time.perf_counter() - t0) * 1000.0
             if rank == 0:
-                gathered["records"] = len(g["alleles"])
+                info["records"] = len(g["alleles"])
+                info["gather_bytes"] = int(g["alleles"].nbytes + g["seqs"].nbytes + g["regions"].nbytes)
+        else:
+            t0 = time.perf_counter()
+            res = ctx.assemble_collect()       # allele records + sequences + region results to host memory
+            info["collect_ms"] = (time.perf_counter() - t0) * 1000.0
+            info["records"] = len(res["alleles"])
 
     for _ in range(args.warmup):
         step()
@@ -124,21 +209,28 @@ def main():
     st = kstats[-1]
     regions_ok = int(st["n_regions_ok"])
     tt = torch.tensor([dt, float(regions_ok)], dtype=torch.float64, device="cuda")
+    world_seen = 1
     if dist is not None:
         tmax = tt.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = tt.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt = float(tmax[0]); total_regions = float(tsum[1])
+        world_seen = dist.get_world_size()
     else:
         total_regions = float(regions_ok)
+    # host memory -> host memory (SURVEY §8d's kernel-path metric: upload + run + download), one extra untimed-for-`value` pass per rank
+    t1 = time.perf_counter()
+    ctx.assemble_submit(params, batch); ctx.assemble_run(); ctx.assemble_collect()
+    h2h_s = time.perf_counter() - t1
     if rank != 0:
         if dist is not None:
+            dist.barrier()
             dist.destroy_process_group()
-        return
+        return 0
 
     ms_per_step = dt * 1000.0 / args.steps
     value = total_regions * args.steps / dt
-    # dominant kernel: the WFA kernel group (edit or affine) with the larger HIP-event time; algorithmic bytes per launch
-    # = Σ(a+b) + 4·W (+ W/2 for the CIGAR-scope aligner), SURVEY.md §8d / DESIGN.md §6
+    # dominant kernel group: the WFA kernel chain (edit or affine) with the larger HIP-event time (events on the library's own stream);
+    # algorithmic bytes per launch = Σ(a+b) + 4·W (+ W/2 for the CIGAR-scope aligner), SURVEY.md §8d / DESIGN.md §6
     ek = float(np.mean([s["ms_edit_kernel"] for s in kstats])); el = max(1, int(st["edit_kernel_launches"]))
     ak = float(np.mean([s["ms_affine_kernel"] for s in kstats])); al = max(1, int(st["affine_kernel_launches"]))
     e_bytes = int(st["edit_seq_bytes"]) + 4 * int(st["edit_cells"])
@@ -148,43 +240,70 @@ def main():
     else:
         kname, kbytes, kms, kl = "wfa_affine_kernel", a_bytes, ak, al
     achieved = (kbytes / kl) / (kms / kl * 1e-3) / 1e9 if kms > 0 else 0.0
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(pmc):
+    workload = synth.config_workload(cfg, n_regions, world)
+    # PMC-derived figures are only attached when the committed summary was taken on exactly this workload
+    traffic, physical = None, None
+    if os.path.exists(PMC_SUMMARY):
         try:
-            traffic = json.load(open(pmc)).get(kname)
-        except Exception:
-            traffic = None
+            pm = json.load(open(PMC_SUMMARY)).get("config%d" % cfg)
+            if pm and int(pm.get("regions", -1)) == n_regions:
+                traffic = pm.get("traffic_bytes_per_launch", {}).get(kname)
+                physical = dict(pm.get("physical", {}).get(kname, {}), source=pm.get("source"), workload=pm.get("workload"))
+        except Exception as e:
+            physical = {"error": "profiles/pmc_summary.json unreadable: %r" % (e,)}
+    visited = int(st["affine_visited_cells"]) if "affine_visited_cells" in st.dtype.names else 0
     out = {
         "metric": "regions/sec (otter assemble hot path) on synthetic TR regions",
         "value": round(value, 3), "unit": "regions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "i32", "data": "synthetic",
-        "config": {"workload": "otter assemble hot path, %d regions/GPU x %d-%d bp TR, %dx %s-error reads%s (BASELINE configs[%d])" % (
-                       args.regions, args.len_min, args.len_max, args.reads, args.err.upper(), ", -r local re-alignment" if args.realign else "",
-                       2 if args.realign else 1),
-                   "regions_per_gpu": args.regions, "reads_per_region": args.reads, "parallelism": "static BED shard x%d + RCCL gather" % world,
+        "config": {"workload": workload, "baseline_config": cfg,
+                   "regions_per_gpu": n_regions, "reads_per_region": synth.CONFIGS[cfg]["n_reads"],
+                   "parallelism": "static BED shard x%d + RCCL gather" % world, "world_size_rccl": world_seen,
+                   "timed_region": "otg_assemble_run + " + ("RCCL gather of the records to rank 0 (device buffers) + one D2H" if world > 1 else "otg_assemble_collect (D2H of the records)") + "; inputs resident in HBM",
                    "stage_ms": {k: round(float(st[k]), 2) for k in ("ms_realign", "ms_edit", "ms_cluster", "ms_reassign", "ms_affine", "ms_poa", "ms_total")},
                    "edit_pairs": int(st["edit_tasks"]), "affine_alignments": int(st["affine_tasks"]),
                    "wavefront_cells": int(st["edit_cells"]) + int(st["affine_cells"]),
                    "exp_variant": "glibc-fma" if ctx.exp_variant else "glibc-nofma",
-                   "h2d_submit_ms": round(submit_ms, 2), "input_bytes": int(batch["arena"].size + batch["reads"].nbytes + batch["regions"].nbytes)},
+                   "h2d_submit_ms": round(submit_ms, 2), "input_bytes": int(batch["arena"].size + batch["reads"].nbytes + batch["regions"].nbytes),
+                   "allele_records": info.get("records"),
+                   "host_to_host": {"regions_per_s": round(regions_ok / h2h_s, 2), "ms": round(h2h_s * 1000.0, 2),
+                                    "what": "otg_assemble_submit (H2D) + otg_assemble_run + otg_assemble_collect (D2H), one pass on rank 0's shard"}},
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "algorithmic_bytes_per_launch": kbytes // kl, "avg_launch_ms": round(kms / kl, 3),
+                     "note": "achieved = SURVEY §8(d) algorithmic bytes (every cell of the reference's un-pruned, HBM-resident wavefronts) / "
+                             "HIP-event time of the kernel chain: a work-equivalent rate, NOT bytes moved — the kernels keep wavefronts in LDS "
+                             "and prune cells; the binding resource is in `physical` (PMC, profiles/)",
+                     "physical": physical,
                      "other_kernel": {"edit_ms": round(ek, 2), "affine_ms": round(ak, 2)}},
     }
-    if not args.no_cpu_baseline:
+    if visited:
+        out["roofline"]["affine_visited_cells_per_s"] = round(visited / (float(st["ms_affine_kernel"]) * 1e-3), 1) if float(st["ms_affine_kernel"]) > 0 else None
+        out["roofline"]["affine_visited_cells"] = visited
+    if world > 1:
+        out["config"]["gather"] = {"path": "device buffers (otg_assemble_device_results) -> RCCL gather -> one D2H on rank 0",
+                                   "bytes": info.get("gather_bytes"), "ms_last_step": round(info.get("gather_ms", 0.0), 2)}
+    else:
+        out["config"]["collect_ms_last_step"] = round(info.get("collect_ms", 0.0), 2)
+    if not args.no_cpu_baseline and world == 1:        # rank 0 at N=1 only
+        nth = max(1, min(32, os.cpu_count() or 1))       # the reference caps -t at 32 (src/otter_opts.cpp:93)
         try:
-            nth = max(1, min(16, os.cpu_count() or 1))
-            out["cpu_baseline"] = cpu_baseline(batch, params, max(args.cpu_sample, nth), nth)
+            out["cpu_baseline"] = cpu_baseline(batch, params, args.cpu_seconds, nth)
         except Exception as e:  # the oracle is only a reported baseline; never fail the bench line on it
             out["cpu_baseline"] = {"value": None, "unit": "regions/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
-    if gathered:
-        out["config"]["gathered_allele_records"] = gathered["records"]
     print(json.dumps(out), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+    sys.exit(run_rank(args))
 
 
 if __name__ == "__main__":

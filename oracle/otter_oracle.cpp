@@ -671,6 +671,13 @@ static int otter_hclust(const otg_params& P, const std::vector<uint32_t>& lens, 
  * :278; lowest-id ending node on equal weight :356-367).
  * ------------------------------------------------------------------------------------------ */
 struct PEdge { uint32_t source, sink; float weight; };
+/* Consensus hook (test infrastructure / bench.py only): when set, rapid_consensus hands each allele graph (backbone, members, op strings,
+ * flags, c, t) to this function instead of the PPOA restatement below — bench.py points it at ref_poa_consensus_one of oracle/_ref
+ * (the reference's own quadratic PPOA) to time BASELINE.md's baseline A. */
+typedef int (*oto_poa_hook_t)(const char*, int, int, const char* const*, const int*, const char* const*, const int*, const uint8_t*, const uint8_t*,
+                              float, float, char*, int);
+static oto_poa_hook_t g_poa_hook = nullptr;
+
 struct PPOA {
   std::string backbone;
   std::vector<char> nodes;      /* '\0' = empty string (uninitialised backbone node) */
@@ -1037,7 +1044,9 @@ static int assemble_region(const otg_params& P, std::vector<Read>& reads, const 
     if (all.size() + 1 <= 2) A.seq = reads[liv_reads.front()].seq;
     else {
       PPOA poa;
-      poa.init(rep_read.seq);
+      const bool hooked = g_poa_hook != nullptr;   /* bench.py baseline A: the consensus runs in the reference's own PPOA instead */
+      std::vector<std::string> hk_cig; std::vector<const char*> hk_seq, hk_cigp; std::vector<int> hk_sl, hk_cl; std::vector<uint8_t> hk_l, hk_r;
+      if (!hooked) poa.init(rep_read.seq);
       std::string cigar; /* persists across members: stale-CIGAR behaviour of :267-273 is reproduced */
       for (const auto& i : all) {
         const Read& read = reads[i];
@@ -1062,13 +1071,23 @@ static int assemble_region(const otg_params& P, std::vector<Read>& reads, const 
                      P.mismatch, P.gap_open, P.gap_ext, f, &cigar, &c);
           if (st) { st->aff_tasks++; st->aff_cells += c; st->aff_bytes += rep_read.seq.size() + read.seq.size(); }
         }
-        poa.insert_alignment(read.seq, cigar, read.spl, read.spr);
+        if (hooked) { hk_cig.push_back(cigar); hk_seq.push_back(read.seq.data()); hk_sl.push_back((int)read.seq.size()); hk_l.push_back(read.spl); hk_r.push_back(read.spr); }
+        else poa.insert_alignment(read.seq, cigar, read.spl, read.spr);
       }
       float c = (all.size() + 1) * 0.4;
       float t = 0.3;
       if (all.size() + 1 < 4) c = 1.0;
-      poa.adjust_weights(c, t);
-      poa.consensus(A.seq);
+      if (hooked) {
+        for (const auto& cg : hk_cig) { hk_cigp.push_back(cg.data()); hk_cl.push_back((int)cg.size()); }
+        std::string buf(4 * rep_read.seq.size() + 4096, '\0');
+        const int n = g_poa_hook(rep_read.seq.data(), (int)rep_read.seq.size(), (int)hk_seq.size(), hk_seq.data(), hk_sl.data(), hk_cigp.data(), hk_cl.data(),
+                                 hk_l.data(), hk_r.data(), c, t, &buf[0], (int)buf.size());
+        if (n < 0) return OTG_ERR_FATAL;
+        A.seq.assign(buf.data(), n);
+      } else {
+        poa.adjust_weights(c, t);
+        poa.consensus(A.seq);
+      }
       if (A.seq.empty()) A.seq = "N";
     }
   }
@@ -1451,6 +1470,7 @@ void oto_realign_batch(const otg_params* P, const uint8_t* arena, uint64_t, cons
 }
 
 void oto_assemble_free(oto_result* R) { delete R; }
+void oto_set_poa_hook(void* fn) { oto::g_poa_hook = (oto::oto_poa_hook_t)fn; }
 uint32_t oto_result_n_alleles(oto_result* R) { return R->alleles.size(); }
 uint64_t oto_result_seq_bytes(oto_result* R) { return R->seqs.size(); }
 uint64_t oto_result_dist_len(oto_result* R) { return R->dist.size(); }

@@ -91,4 +91,28 @@ int ref_poa_consensus_batch(const uint8_t* seq_arena, uint64_t, const uint8_t* c
   return rc;
 }
 
+/* One allele graph through the reference's own PPOA (quadratic heaviest path, src/anppoa.hpp:254-288): the consensus hook of the
+ * oracle pipeline (oto_set_poa_hook) — bench.py's cpu_baseline "reference_consensus" (BASELINE.md §3 baseline A).  Thread-safe: the
+ * PPOA instance is local.  Returns the consensus length (the caller maps an empty string to "N" as rapid_consensus does). */
+int ref_poa_consensus_one(const char* backbone, int backbone_len, int n_members, const char* const* seqs, const int* seq_lens,
+                          const char* const* cigars, const int* cig_lens, const uint8_t* spl, const uint8_t* spr, float c, float t,
+                          char* out, int out_cap)
+{
+  PPOA poa;
+  std::string bb(backbone, backbone_len);
+  poa.init(bb);
+  for (int m = 0; m < n_members; ++m) {
+    std::string seq(seqs[m], seq_lens[m]);
+    std::string cig(cigars[m], cig_lens[m]);
+    bool l = spl[m], r = spr[m];
+    poa.insert_alignment(seq, cig, l, r);
+  }
+  poa.adjust_weights(c, t);
+  std::string cons;
+  poa.consensus(cons);
+  if ((int)cons.size() > out_cap) return -1;
+  memcpy(out, cons.data(), cons.size());
+  return (int)cons.size();
+}
+
 } /* extern "C" */

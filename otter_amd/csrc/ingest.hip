@@ -39,6 +39,7 @@ struct Bgzf {
   bool eof = false;
   z_stream zs;
   bool zs_ready = false;
+  bool failed = false;           // the last load() met a malformed / truncated / non-inflatable block (as opposed to the end of the file)
 
   bool open(const char* path) { fp = fopen(path, "rb"); return fp != nullptr; }
   void close() { if (fp) fclose(fp); fp = nullptr; if (zs_ready) { inflateEnd(&zs); zs_ready = false; } }
@@ -56,7 +57,9 @@ struct Bgzf {
     std::vector<uint8_t>& ubuf = S.data;
     if (fseeko(fp, (off_t)block_address, SEEK_SET) != 0) return false;
     uint8_t h[12];
-    if (fread(h, 1, 12, fp) != 12) { eof = true; return false; }
+    const size_t hg = fread(h, 1, 12, fp);
+    if (hg != 12) { eof = true; if (hg != 0) failed = true; return false; }      // 0 bytes: clean end of file; 1-11: truncated block header
+    failed = true;                                                                 // cleared once the block has been inflated
     if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) return false;
     const uint32_t xlen = h[10] | (h[11] << 8);
     uint8_t extra[256];
@@ -84,6 +87,7 @@ struct Bgzf {
       const int rc = inflate(&zs, Z_FINISH);
       if (rc != Z_STREAM_END || zs.total_out != isize) return false;
     }
+    failed = false;
     block_csize = total; block_length = isize;
     S.address = block_address; S.csize = total; S.length = isize; S.stamp = ++clock_; cur = victim;
     g_blocks_inflated.fetch_add(1, std::memory_order_relaxed);
@@ -207,13 +211,15 @@ struct Rec {
 inline int cig_op(const uint8_t* c, uint32_t i) { return (int)(rd32(c + 4 * i) & 0xf); }
 inline int cig_len(const uint8_t* c, uint32_t i) { return (int)(rd32(c + 4 * i) >> 4); }
 
+const uint8_t* aux_get(const Rec& r, char t0, char t1);
+
 // returns 1 record decoded, 0 end of file, -1 error
 int read_record(otg_bam* b, Rec* r)
 {
   int32_t block_len = 0;
   const size_t g = b->fp.read(&block_len, 4);
-  if (g == 0) return 0;
-  if (g != 4 || block_len < 32) return -1;
+  if (g == 0) return b->fp.failed ? -1 : 0;                    // a block that does not inflate is an error, not the end of the file
+  if (g != 4 || block_len < 32 || block_len > (1 << 29)) return -1;
   b->rec.resize((size_t)block_len);
   if (b->fp.read(b->rec.data(), (size_t)block_len) != (size_t)block_len) return -1;
   const uint8_t* p = b->rec.data();
@@ -231,6 +237,15 @@ int read_record(otg_bam* b, Rec* r)
   r->seq = q + 4 * (size_t)r->n_cigar;
   r->aux = r->seq + ((size_t)r->l_seq + 1) / 2 + (size_t)r->l_seq;
   r->aux_end = p + block_len;
+  // Alignments with more than 65535 CIGAR operations (ultra-long reads) carry a placeholder `<l_seq>S<rlen>N` and the real CIGAR in the
+  // tag CG:B,I; the reference's bam_read1 moves it into place (bam_tag2cigar, src/sam.c:243-285).  Same test, the ops are read in place.
+  if (r->n_cigar != 0 && r->tid >= 0 && r->pos >= 0 && cig_op((const uint8_t*)r->cigar, 0) == 4 && cig_len((const uint8_t*)r->cigar, 0) == r->l_seq) {
+    const uint8_t* cg = aux_get(*r, 'C', 'G');
+    if (cg && cg[0] == 'B' && cg[1] == 'I') {
+      const uint32_t n = rd32(cg + 2);
+      if (n != 0) { r->cigar = (const uint32_t*)(cg + 6); r->n_cigar = n; }      // bounds were checked by aux_get
+    }
+  }
   return 1;
 }
 
@@ -243,14 +258,16 @@ int cigar_rlen(const Rec& r)
   return l;
 }
 
-// pointer to the value (type byte first) of an aux tag, or null (bam_aux_get)
+// pointer to the value (type byte first) of an aux tag, or null (bam_aux_get).  Every value is checked to lie inside the record
+// (a string needs its terminator there), so the readers below never look past aux_end; a malformed tail ends the scan.
 const uint8_t* aux_get(const Rec& r, char t0, char t1)
 {
   const uint8_t* s = r.aux;
-  while (s + 3 <= r.aux_end) {
+  const uint8_t* const end = r.aux_end;
+  while (s + 3 <= end) {
     const bool hit = s[0] == (uint8_t)t0 && s[1] == (uint8_t)t1;
+    const uint8_t* val = s + 2;
     s += 2;
-    if (hit) return s;
     const int type = *s++;
     size_t sz = 0;
     switch (type) {
@@ -258,19 +275,23 @@ const uint8_t* aux_get(const Rec& r, char t0, char t1)
       case 's': case 'S': sz = 2; break;
       case 'i': case 'I': case 'f': sz = 4; break;
       case 'd': sz = 8; break;
-      case 'Z': case 'H': while (s < r.aux_end && *s) ++s; sz = 1; break;
+      case 'Z': case 'H': { const uint8_t* z = (const uint8_t*)memchr(s, 0, (size_t)(end - s)); if (!z) return nullptr; sz = (size_t)(z - s) + 1; break; }
       case 'B': {
-        if (s + 5 > r.aux_end) return nullptr;
+        if (s + 5 > end) return nullptr;
         const int sub = *s; const uint32_t n = rd32(s + 1);
         const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
-        s += 5; sz = es * (size_t)n; break;
+        sz = 5 + es * (size_t)n; break;
       }
       default: return nullptr;
     }
+    if (sz > (size_t)(end - s)) return nullptr;
+    if (hit) return val;
     s += sz;
   }
   return nullptr;
 }
+// bam_aux2Z: the string of a Z / H value (empty for any other type; the terminator is inside the record, see aux_get)
+std::string aux2str(const uint8_t* a) { return (a && (a[0] == 'Z' || a[0] == 'H')) ? std::string((const char*)a + 1) : std::string(); }
 int32_t aux2i(const uint8_t* s)
 {
   const int type = *s++;
@@ -579,10 +600,10 @@ static int alleles_slice(const otg_bam* b, const char* path, const otg_bed* beds
     const int sc_rc = scan_region(b, local, it->second, qbeg, qend, bins, chunks, err, [&](const Rec& r) {
       if (cb_rc != OTG_OK) return;
       const uint8_t* a = aux_get(r, 't', 'a');
-      std::string parsed = a ? std::string((const char*)a + 1) : std::string();
+      std::string parsed = aux2str(a);
       if (parsed != target) return;
       a = aux_get(r, 'R', 'G');
-      const std::string sample = a ? std::string((const char*)a + 1) : std::string();
+      const std::string sample = aux2str(a);
       auto si = b->sample2index.find(sample);
       if (si == b->sample2index.end()) { err = "unrecognized sample name (read group): " + sample; cb_rc = OTG_ERR_ARG; return; }
       otg_allele o;
@@ -651,8 +672,10 @@ int otg_ingest_regions_named(otg_bam* b, const otg_bed* beds, const char* chr_ar
   std::vector<std::string> errs(T);
   auto work = [&](uint32_t t) {
     const uint32_t g0 = (uint32_t)((uint64_t)n_regions * t / T), g1 = (uint32_t)((uint64_t)n_regions * (t + 1) / T);
-    rcs[t] = ingest_slice(b, b->path.c_str(), beds, chr_arena, g0, g1, opts, R[t], A[t], regions, errs[t],
-                          want_meta ? &M[t] : nullptr, want_meta ? &N[t] : nullptr);
+    try {
+      rcs[t] = ingest_slice(b, b->path.c_str(), beds, chr_arena, g0, g1, opts, R[t], A[t], regions, errs[t],
+                            want_meta ? &M[t] : nullptr, want_meta ? &N[t] : nullptr);
+    } catch (const std::exception& e) { rcs[t] = OTG_ERR_ARG; errs[t] = std::string("exception while reading the BAM: ") + e.what(); }   // nothing may unwind through the C ABI / a std::thread
   };
   if (T == 1) work(0);
   else {
@@ -730,7 +753,8 @@ int otg_ingest_alleles(otg_bam* b, const otg_bed* beds, const char* chr_arena, u
   std::vector<std::string> errs(T);
   auto work = [&](uint32_t t) {
     const uint32_t g0 = (uint32_t)((uint64_t)n_regions * t / T), g1 = (uint32_t)((uint64_t)n_regions * (t + 1) / T);
-    rcs[t] = alleles_slice(b, b->path.c_str(), beds, chr_arena, g0, g1, fa, R[t], A[t], per.data(), errs[t]);
+    try { rcs[t] = alleles_slice(b, b->path.c_str(), beds, chr_arena, g0, g1, fa, R[t], A[t], per.data(), errs[t]); }
+    catch (const std::exception& e) { rcs[t] = OTG_ERR_ARG; errs[t] = std::string("exception while reading the BAM: ") + e.what(); }
   };
   if (T == 1) work(0);
   else {

@@ -764,6 +764,7 @@ static int assemble_run_impl(otg_ctx* ctx, bool realign_only)
   uint32_t* d_cig_len = (uint32_t*)B(B_CIGLEN);
   uint8_t* d_cig = (uint8_t*)B(B_CIG);
   memset(&pl->stats, 0, sizeof(pl->stats));
+  pl->ran = false;               // a run that fails below must not leave the previous run's results collectable
   pl->out_alleles = 0; pl->out_seq_bytes = 0;
   if (NG == 0 || NR == 0) { pl->ran = true; return OTG_OK; }
   Timer total(ctx);
@@ -792,6 +793,9 @@ static int assemble_run_impl(otg_ctx* ctx, bool realign_only)
   if (realign_only) {
     HIP_TRY(ctx, hipStreamSynchronize(st));
     pl->stats.ms_total = total.ms();
+    uint32_t hf = 0;
+    HIP_TRY(ctx, hipMemcpy(&hf, d_cnt + 41, sizeof(hf), hipMemcpyDeviceToHost));
+    if (hf) return otg_fail(ctx, OTG_ERR_CAPACITY, "a gap-affine alignment exhausted its backtrace storage on the device");
     return OTG_OK;             // pl->ran stays false: there are no allele results to collect
   }
   // ------------------------------------------------------------------ partition + fill_dist_matrix

@@ -1549,10 +1549,10 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
                        d_cig_arena, d_cells, cnt + 10, cnt + 11, listB, wsB, (const int32_t*)d_bound);
     cur = listB; cur_n = cnt + 11; cur_imm = 0;
   }
-  if (kernel_ms) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   hipLaunchKernelGGL((wfa_affine_kernel<WPB>), dim3(gridC), dim3(WPB * 64), 0, ctx->stream, d_arena, d_tasks,
                      cur, cur_n, cur_imm, xs, oes, es, g, d_scores, d_cig_off, d_cig_len,
                      d_cig_arena, d_cells, cnt + 12, cnt + 13, (uint32_t*)nullptr, wsC);
+  if (kernel_ms) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));      // after the LAST tier of the chain
   HIP_TRY(ctx, hipGetLastError());
   if (getenv("OTG_DEBUG")) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

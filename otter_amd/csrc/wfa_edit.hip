@@ -647,7 +647,6 @@ int otg_launch_edit_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_t
     }
   }
   const uint32_t* cur = lists + 6 * (size_t)n_tasks; const uint32_t* cur_n = rc + 6;
-  if (kernel_ms) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   {
     constexpr int CAP = 8192, WPB = 1;                         // 32 KB per wave -> 5 waves / CU, scores up to ~4000
     const size_t lds = (size_t)CAP * 2 * WPB * sizeof(uint16_t);
@@ -666,6 +665,7 @@ int otg_launch_edit_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_t
                        (const uint32_t*)listG, (const uint32_t*)(cnt + 17), 0u, d_scores, d_cells, cnt + 18, cnt + 19,
                        (uint32_t*)nullptr, ws, gcap);
   }
+  if (kernel_ms) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));      // after the LAST tier of the chain
   HIP_TRY(ctx, hipGetLastError());
   if (getenv("OTG_DEBUG")) {
     hipError_t er = hipStreamSynchronize(ctx->stream);

@@ -49,6 +49,10 @@ def gather_records(res, dist, rank, world, device):
         lst = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
         dist.gather(pad, lst, dst=0)
         out.append(lst)
+    if device.type == "cuda":
+        # the collectives above run on torch's stream; the library rewrites (or frees) the forwarded result buffers on ITS stream at the
+        # next submit / run, so every rank waits here until its sends have left the buffers
+        torch.cuda.current_stream(device).synchronize()
     if rank != 0:
         return None
     # rank 0: trim + concatenate on the device, ONE device-to-host copy per array, then rebase on the host

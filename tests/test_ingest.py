@@ -163,3 +163,62 @@ def test_bam_open_errors(tmp_path):
     p.write_bytes(b"not a bam")
     with pytest.raises(otter_amd.OtterGpuError):
         otter_amd.Bam(str(p))
+
+
+@needs_ref
+def test_ingest_long_cigar_in_cg_tag(tmp_path):
+    """An alignment with more than 65535 CIGAR operations: BAM stores `<l_seq>S<rlen>N` in the record and the real CIGAR in tag
+    CG:B,I (the reference's writer, src/sam.c:323-352); the reference's reader moves it back (bam_tag2cigar, src/sam.c:243-285).  The
+    product reads the ops from the tag in place; dropped silently it would mark the read unsuccessful."""
+    rng = np.random.default_rng(5)
+    n_pairs = 34000                                   # 1M1D x 34000 + tails = 68003 ops
+    ops = "5S" + "1M1D" * n_pairs + "40M" + "3S"
+    qlen = 5 + n_pairs + 40 + 3
+    seq = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, qlen))
+    short = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, 300))
+    sam, bam = str(tmp_path / "cg.sam"), str(tmp_path / "cg.bam")
+    with open(sam, "w") as f:
+        f.write("@HD\tVN:1.4\tSO:coordinate\n@SQ\tSN:chr1\tLN:1000000\n")
+        f.write("long\t0\tchr1\t1000\t60\t%s\t*\t0\t0\t%s\t*\tHP:i:2\tPS:i:77\n" % (ops, seq))
+        f.write("short\t0\tchr1\t30000\t60\t300M\t*\t0\t0\t%s\t*\n" % short)
+    assert oracle_lib.ref_io().ref_sam_to_bam(sam.encode(), bam.encode()) == 2
+    regions = [("chr1", 1500, 1600), ("chr1", 29990, 30100), ("chr1", 68000, 69050), ("chr1", 900, 1010), ("chr1", 69030, 69100)]
+    bamh = otter_amd.Bam(bam)
+    for kw in (dict(), dict(offset_l=1, offset_r=1)):
+        ref = _ref_ingest(bam, regions, **kw)
+        assert ref["regions"]["n_reads"][0] == 1 and ref["reads"]["seq_len"][0] > 40     # the long read is used, with its real CIGAR
+        _same(bamh.ingest(regions, **kw), ref)
+        _same(bamh.ingest(regions, threads=3, **kw), ref)
+    bamh.close()
+
+
+def test_ingest_rejects_corrupt_and_truncated_bam(tmp_path):
+    """Malformed input must come back as an error code through the C-ABI — never a crash, never a silent short read: a BGZF block that
+    does not inflate, a truncated file, aux fields that run past the record."""
+    import shutil
+    src = os.path.join(GOLD, "ingest_small.bam")
+    g = np.load(os.path.join(GOLD, "ingest_ref.npz"))
+    regions = [(str(c), int(s), int(e)) for c, s, e in zip(g["regions_chr"], g["regions_start"], g["regions_end"])]
+    raw = bytearray(open(src, "rb").read())
+    rng = np.random.default_rng(9)
+    n_err = 0
+    for trial in range(12):
+        bad = bytearray(raw)
+        if trial < 6:
+            for _ in range(40):                                   # flip bytes in the compressed payload (past the header block)
+                p = int(rng.integers(len(bad) // 3, len(bad) - 40))
+                bad[p] ^= 0x5a
+        else:
+            bad = bad[:int(rng.integers(len(bad) // 2, len(bad) - 30))]   # truncated inside a block
+        p = tmp_path / ("bad%d.bam" % trial)
+        p.write_bytes(bytes(bad))
+        shutil.copy(src + ".bai", str(p) + ".bai")
+        try:
+            b = otter_amd.Bam(str(p))
+            try:
+                b.ingest(regions, threads=1 + trial % 3)
+            finally:
+                b.close()
+        except otter_amd.OtterGpuError:
+            n_err += 1
+    assert n_err >= 6          # most corruptions are detected (a flipped byte may by chance leave a decodable stream); none crashed
