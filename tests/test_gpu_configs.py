@@ -87,7 +87,7 @@ def test_full_size_config2_realign_properties(gpu, oracle):
     # reads that local_realignment rescues, per region: windows are taken where most of them are
     trimmed = gpu.realign_reads(P, b)
     changed = (trimmed["seq_len"] != b["reads"]["seq_len"]) | (trimmed["seq_off"] != b["reads"]["seq_off"])
-    assert changed.sum() > 0.08 * len(changed)                     # ~25 % clipped x 60 % rescuable
+    assert changed.sum() > 0.05 * len(changed)                     # 25 % clipped, 60 % of those rescuable, min_sim 0.9 over the flank
     assert (trimmed["spanning_l"][changed] == 1).all() and (trimmed["spanning_r"][changed] == 1).all()
     first = b["regions"]["first_read"].astype(np.int64)
     per_region = np.add.reduceat(changed.astype(np.int64), first)
