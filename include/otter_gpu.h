@@ -358,6 +358,7 @@ typedef struct otg_run_stats {
   uint64_t edit_kernel_launches;
   double   ms_affine_kernel;          /* HIP-event time of the gap-affine WFA kernel launches (tier 1)     */
   uint64_t affine_kernel_launches;
+  uint64_t affine_visited_cells;      /* (score, diagonal) cells the exact gap-affine kernels actually evaluated (pruned wavefronts) */
 } otg_run_stats;
 
 /* Upload a batch (H2D).  After it returns the inputs are resident in HBM.                       */

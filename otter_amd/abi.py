@@ -77,7 +77,7 @@ run_stats_dt = np.dtype([
     ("allele_bytes", "<u8"), ("algorithmic_bytes", "<u8"),
     ("ms_edit", "<f8"), ("ms_cluster", "<f8"), ("ms_reassign", "<f8"), ("ms_affine", "<f8"), ("ms_poa", "<f8"),
     ("ms_realign", "<f8"), ("ms_total", "<f8"), ("ms_edit_kernel", "<f8"), ("edit_kernel_launches", "<u8"),
-    ("ms_affine_kernel", "<f8"), ("affine_kernel_launches", "<u8")], align=True)
+    ("ms_affine_kernel", "<f8"), ("affine_kernel_launches", "<u8"), ("affine_visited_cells", "<u8")], align=True)
 
 assert align_task_dt.itemsize == 48
 assert read_dt.itemsize == 32

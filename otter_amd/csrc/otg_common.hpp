@@ -28,6 +28,7 @@ struct otg_ctx {
   // resident batch of the L3 pipeline
   struct Pipeline* pipe = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  unsigned long long* affine_visited = nullptr;   // device counter: (score, diagonal) cells the exact gap-affine tiers visited (wfa_affine.hip)
 };
 
 extern thread_local std::string g_otg_err;

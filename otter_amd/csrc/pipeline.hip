@@ -772,6 +772,7 @@ static int assemble_run_impl(otg_ctx* ctx, bool realign_only)
   HIP_TRY(ctx, hipMemcpyAsync(d_reads, pl->h_reads.data(), (size_t)NR * sizeof(otg_read), hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, 64 * 8, st));
   HIP_TRY(ctx, hipMemsetAsync(d_stats, 0, 64 * 8, st));
+  if (ctx->affine_visited) HIP_TRY(ctx, hipMemsetAsync(ctx->affine_visited, 0, 8, st));
   const int TB = 256;
   const uint32_t gr_reads = (NR + TB - 1) / TB, gr_regions = (NG + TB - 1) / TB;
   const uint32_t gr_blocks = std::min<uint32_t>(NG, (uint32_t)ctx->n_cu * 16);
@@ -912,6 +913,7 @@ static int assemble_run_impl(otg_ctx* ctx, bool realign_only)
   pl->stats.edit_cells = hs[0]; pl->stats.edit_seq_bytes = hs[1]; pl->stats.edit_tasks = hs[2];
   pl->stats.affine_cells = hs[4]; pl->stats.affine_seq_bytes = hs[5]; pl->stats.affine_tasks = hs[6];
   pl->stats.n_regions = NG;
+  if (ctx->affine_visited) { unsigned long long v = 0; HIP_TRY(ctx, hipMemcpy(&v, ctx->affine_visited, 8, hipMemcpyDeviceToHost)); pl->stats.affine_visited_cells = v; }
   pl->stats.allele_bytes = pl->out_seq_bytes + 40ull * pl->out_alleles;
   pl->stats.algorithmic_bytes = pl->stats.edit_seq_bytes + 4 * pl->stats.edit_cells + pl->stats.affine_seq_bytes + 4 * pl->stats.affine_cells +
                                 (pl->stats.affine_cells + 1) / 2 + pl->stats.allele_bytes;

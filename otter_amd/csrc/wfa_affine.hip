@@ -20,6 +20,7 @@
 #include "otg_common.hpp"
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -35,6 +36,7 @@ struct AffWs {
   int nrows;            // row-table entries
   size_t rev_cap;
   int dbg;              // OTG_DEBUG: count visited cells
+  unsigned long long* visited;   // device counter of visited (score, diagonal) cells, all exact tiers (nullable)
 };
 
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
@@ -964,6 +966,7 @@ __global__ __launch_bounds__(NW * 64) void wfa_affine_kernel_v3(
     }
     if (!backtrace_unpack(P, pl, T, tl, s_end, k_end, xs, oes, es, rowtab, slab, rev, ws.rev_cap, cig_arena + cig_off[ti], lane, &scores[ti], &cig_len[ti], g)) continue;
     if (cells) cells[ti] = affine_cells(t, xs, oes, s_end);
+    if (ws.visited && lane == 0) atomicAdd(ws.visited, (unsigned long long)slab_top);
   }
 }
 
@@ -1322,6 +1325,427 @@ __global__ __launch_bounds__(NW * 64, WPEU) void wfa_affine_kernel_v4(
     if (!backtrace_unpack(P, pl, T, tl, s_end, k_end, xs, oes, es, rowtab, slab, rev, ws.rev_cap, cig_arena + cig_off[ti], lane, &scores[ti], &cig_len[ti], g)) continue;
     if (cells) cells[ti] = affine_cells(t, xs, oes, s_end);
     if (ws.dbg && threadIdx.x == 0) { atomicAdd(&otg_dbg_v4_cells[0], (unsigned long long)slab_top); atomicAdd(&otg_dbg_v4_cells[1], 1ull); }
+    if (ws.visited && threadIdx.x == 0) atomicAdd(ws.visited, (unsigned long long)slab_top);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// v5 forward kernel: REGISTER-RESIDENT wavefronts, one wave per alignment, no barriers (penalties (2,4,1) after gcd
+// reduction, score-bounded alignments whose diamond fits a window of CAP = 128 * S2 diagonals).
+//   * Window index x = k - kbase; lane l of pair-slot i owns the two ADJACENT diagonals x = 128 i + 2 l (+1).  Per diagonal three
+//     32-bit words live in VGPRs for the whole alignment: two M words — one per score parity, {lo16: M[s-4], hi16: M[s-2]}, a score
+//     only reads M rows of its own parity — and one {lo16: I[s-1], hi16: D[s-1]} word.  The slot loop is fully unrolled, so every
+//     register index is static; which pair-slots a score touches is a wave-uniform branch per slot.  After a score the two parity
+//     arrays trade places (v_swap per register).
+//   * Of the four neighbours a pair of cells needs, two sit in the lane itself (the even cell's right neighbour is the lane's odd
+//     cell and vice versa); the other two come with ONE DPP wave shift each of a packed export word (lane 0 / 63 take the value of
+//     the adjacent pair-slot through readlane).  M[s] replaces M[s-4] by a 16-bit rotate of the word, I and D are updated in place
+//     (ascending sweep: the left neighbour's old value travels in an SGPR, the right neighbour's is still old).
+//   * Cells outside the score's range [lo, hi] but inside an active pair-slot are computed like any other: every value a cell ever
+//     holds is the offset of a real alignment prefix of at most that score, so such cells can only matter if they lie on an alignment
+//     of score <= U — and then they are inside the diamond by its definition.  (Same argument as for the pruned cells of v3/v4.)
+//   * Sequences: 2 bits per base in LDS (as v4), a probe covers 32 bases.  A cell whose match run outlives the probe (1.2 % at ONT
+//     divergence) is pushed {x, h} to a per-wave LDS queue; the queue is drained in full 64-lane batches at the end of the score and
+//     the final offsets come back through a 16-bit patch table that one packed max per cell folds into the M words.
+//   * Provenance: one byte per cell of the touched pair-slots (row = 128 * (j1 - j0 + 1) bytes), the lane's two bytes in one
+//     16-bit store.  Same row table, backtrace and unpack as every other tier.
+typedef short otg_short2 __attribute__((ext_vector_type(2)));
+// compile-time loop: the body sees its index as a constant expression, so register arrays are only ever indexed statically
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f)
+{
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b)
+{
+  otg_short2 x, y;
+  __builtin_memcpy(&x, &a, 4); __builtin_memcpy(&y, &b, 4);
+  const otg_short2 r = __builtin_elementwise_max(x, y);
+  uint32_t o; __builtin_memcpy(&o, &r, 4); return o;
+}
+__device__ __forceinline__ int lo16s(uint32_t w) { return (int)(int16_t)(w & 0xffffu); }
+__device__ __forceinline__ int hi16s(uint32_t w) { return (int)w >> 16; }
+__device__ __forceinline__ uint32_t pack16(int lo, int hi) { return __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u); }   // {lo16: lo, hi16: hi}
+
+template <int S2, int SEQB, int WPEU>
+__global__ __launch_bounds__(256, WPEU) void wfa_affine_kernel_v5(
+    const uint8_t* __restrict__ arena, const otg_align_task* __restrict__ tasks,
+    const uint32_t* __restrict__ todo, const uint32_t* __restrict__ seg, int g,
+    int32_t* __restrict__ scores, const uint64_t* __restrict__ cig_off, uint32_t* __restrict__ cig_len,
+    uint8_t* __restrict__ cig_arena, uint64_t* __restrict__ cells,
+    uint32_t* __restrict__ ticket, uint32_t* __restrict__ n_overflow, uint32_t* __restrict__ overflow_list,
+    AffWs ws, const int32_t* __restrict__ bound, unsigned long long* __restrict__ visited)
+{
+  constexpr int xs = 2, oes = 4, es = 1;
+  constexpr int CAP = S2 * 128;
+  constexpr int QCAP = 512;
+  constexpr uint32_t NN = 0x80008000u;
+  constexpr int NUL16 = -32768;
+  __shared__ uint32_t s_seq[4][SEQB / 4];
+  __shared__ uint32_t s_patch[4][CAP / 2];
+  __shared__ uint32_t s_queue[4][QCAP];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  uint32_t* SQ = &s_seq[wv][0];
+  volatile lds_u32* PT = (volatile lds_u32*)&s_patch[wv][0];
+  volatile lds_u32* QU = (volatile lds_u32*)&s_queue[wv][0];
+  volatile lds_u16* PT16 = (volatile lds_u16*)&s_patch[wv][0];
+  uint8_t* my = ws.base + (size_t)(blockIdx.x * 4 + wv) * ws.stride;
+  int64_t* rowtab = (int64_t*)(my + ws.off_rowtab);
+  uint8_t* rev = my + ws.off_rev;
+  uint8_t* slab = my + ws.off_slab;
+  const uint32_t seg0 = seg[0], n_todo = seg[1] - seg[0];
+
+  for (;;) {
+    const uint32_t tk = otg_wave_atomic_add(ticket, 1u);
+    if (tk >= n_todo) break;
+    const uint32_t ti = todo[seg0 + tk];
+    const otg_align_task t = tasks[ti];
+    const uint8_t* P = arena + t.pattern_off;
+    const uint8_t* T = arena + t.text_off;
+    const int pl = (int)t.pattern_len, tl = (int)t.text_len;
+    const bool ef = t.endsfree != 0;
+    const int pef = t.pattern_end_free, tef = t.text_end_free;
+    const int kend = tl - pl;
+    const int U = __builtin_amdgcn_readfirstlane(bound[ti]);
+    const int elo = kend - (ef ? tef : 0), ehi = kend + (ef ? pef : 0);
+    int lo0 = ef ? imax(-t.pattern_begin_free, -pl) : 0, hi0 = ef ? imin(t.text_begin_free, tl) : 0;
+    bool fail = U >= 0x40000000 || pl >= 32766 || tl >= 32766;
+    const int offT = (pl + 15) / 16 + 3;
+    if ((offT + (tl + 15) / 16 + 3) * 4 > SEQB) fail = true;
+    int kbase = 0;
+    if (!fail) {
+      lo0 = imax(lo0, elo - U); hi0 = imin(hi0, ehi + U);
+      const int wlo = imax((lo0 + elo - U) >> 1, -pl) - 1, whi = imin((hi0 + ehi + U + 1) >> 1, tl) + 1;
+      kbase = wlo - 2;
+      if (hi0 < lo0 || whi - kbase + 4 >= CAP) fail = true;
+    }
+    uint32_t MC[2][S2 + 1][2];          // [parity slot][pair-slot][even / odd diagonal]: {lo16: M[s-4], hi16: M[s-2]}; [0] = the parity of the current score
+    uint32_t ID[S2 + 1][2];           // {lo16: I[s-1], hi16: D[s-1]}
+    static_for<0, S2 + 1>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value;
+      MC[0][i][0] = NN; MC[0][i][1] = NN; MC[1][i][0] = NN; MC[1][i][1] = NN; ID[i][0] = NN; ID[i][1] = NN; });
+    if (!fail) {
+      for (int q = lane; q < CAP / 2; q += 64) PT[q] = NN;
+      bool bad = false;
+      auto pack = [&](const uint8_t* S, int len, int woff) {
+        for (int q = lane; q < (len + 15) / 16; q += 64) {
+          uint32_t w = 0;
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int b0 = 16 * q + 8 * j;
+            const uint64_t x = b0 < len + 8 ? otg_load8(S + (b0 < len ? b0 : len)) : 0ull;
+#pragma unroll
+            for (int t2 = 0; t2 < 8; ++t2) {
+              const uint32_t c = (uint32_t)(x >> (8 * t2)) & 0xffu;
+              const uint32_t code = (c >> 1) & 3u;
+              if (b0 + t2 < len && c != ((0x47544341u >> (8 * code)) & 0xffu)) bad = true;
+              w |= code << (2 * (8 * j + t2));
+            }
+          }
+          SQ[woff + q] = w;
+        }
+      };
+      pack(P, pl, 0);
+      pack(T, tl, offT);
+      // slack words a probe may read past the packed ends
+      if (lane < 3) { SQ[(pl + 15) / 16 + lane] = 0; SQ[offT + (tl + 15) / 16 + lane] = 0; }
+      fail = __ballot(bad) != 0ull;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    auto ld32b = [&](int woff, int pos) -> uint64_t {
+      const int w = woff + (pos >> 4);
+      const uint32_t sh = (uint32_t)(pos & 15) * 2u;
+      const uint32_t d0 = SQ[w], d1 = SQ[w + 1], d2 = SQ[w + 2];
+      return (uint64_t)__builtin_amdgcn_alignbit(d1, d0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32);
+    };
+    // equal leading bases looking at most 32 * nb bases ahead (and at most rem); a rolled loop: the register arrays of the sweep stay live
+    // across the drain, so this must not turn into nb independent probes in flight
+    auto match_n = [&](int v, int h, int rem, int nb) -> int {
+      int m = 0;
+#pragma nounroll
+      for (int i = 0; i < nb; ++i) {
+        if (m >= rem) break;
+        const uint64_t x = ld32b(0, v + m) ^ ld32b(offT, h + m);
+        if (x) { m += (int)(__builtin_ctzll(x) >> 1); break; }
+        m += 32;
+      }
+      return m < rem ? m : rem;
+    };
+    auto wave_match = [&](int v, int h, int rem) -> int {
+      int total = 0;
+      while (total < rem) {
+        const int off = total + lane * 32;
+        uint64_t x = ~0ull;
+        if (off < rem) x = ld32b(0, v + off) ^ ld32b(offT, h + off);
+        const int m = x ? (int)(__builtin_ctzll(x) >> 1) : 32;
+        const unsigned long long stop = __ballot(m < 32);
+        if (stop) { const int f = (int)__builtin_ctzll(stop); total += f * 32 + __builtin_amdgcn_readlane(m, f); break; }
+        total += 2048;
+      }
+      return total < rem ? total : rem;
+    };
+
+    size_t slab_top = 0;
+    int s_end = -1, k_end = 0;
+    int r1lo = 1, r1hi = 0, r2lo = 1, r2hi = 0, r3lo = 1, r3hi = 0, r4lo = 1, r4hi = 0, idlo = 1, idhi = 0;
+    const int xe = kend - kbase;                 // window index of the end diagonal (end-to-end termination)
+
+    int lane2 = 2 * lane, kb = __builtin_amdgcn_readfirstlane(kbase);
+    for (int s = 0; !fail; ++s) {
+      if (s >= ws.nrows) { fail = true; break; }
+      // opaque to the optimiser: per-slot expressions built on these are recomputed where they are used instead of being hoisted out of
+      // the score loop into S2 live registers each (loop-invariant code motion knows nothing about register pressure)
+      asm volatile("" : "+v"(lane2));
+      asm volatile("" : "+s"(kb));
+      int lo, hi;
+      if (s == 0) { lo = lo0; hi = hi0; }
+      else {
+        lo = 1 << 30; hi = -(1 << 30);
+        if (r2hi >= r2lo) { lo = imin(lo, r2lo); hi = imax(hi, r2hi); }
+        if (r4hi >= r4lo) { lo = imin(lo, r4lo - 1); hi = imax(hi, r4hi + 1); }
+        if (idhi >= idlo) { lo = imin(lo, idlo - 1); hi = imax(hi, idhi + 1); }
+        if (lo < -pl) lo = -pl;
+        if (hi > tl) hi = tl;
+        if (hi >= lo) {
+          const int room = U - s;
+          lo = imax(lo, elo - room); hi = imin(hi, ehi + room);
+          if (room < 0 || hi < lo) { fail = true; break; }
+        }
+      }
+      lo = __builtin_amdgcn_readfirstlane(lo); hi = __builtin_amdgcn_readfirstlane(hi);     // wave-uniform by construction: say so, the whole score loop stays scalar
+      r4lo = r3lo; r4hi = r3hi; r3lo = r2lo; r3hi = r2hi; r2lo = r1lo; r2hi = r1hi;
+      if (hi < lo) {   // unreachable score: nothing is written, the parity arrays still trade places
+        r1lo = 1; r1hi = 0; idlo = 1; idhi = 0;
+        rowtab[s] = -1;
+        if (s > 2 * (oes + es * (pl + tl)) + 8) fail = true;
+        static_for<0, S2>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value;
+          { const uint32_t t_ = MC[0][i][0]; MC[0][i][0] = MC[1][i][0]; MC[1][i][0] = t_; }
+          { const uint32_t t_ = MC[0][i][1]; MC[0][i][1] = MC[1][i][1]; MC[1][i][1] = t_; } });
+        continue;
+      }
+      r1lo = lo; r1hi = hi;
+      const int xlo = lo - kbase, xhi = hi - kbase;
+      if (xlo < 2 || xhi + 3 >= CAP) { fail = true; break; }
+      const int j0 = xlo >> 7, j1 = xhi >> 7;
+      const int width = (j1 - j0 + 1) * 128;
+      if (slab_top + (size_t)width > ws.slab_bytes) { fail = true; break; }
+      uint8_t* brow = slab + slab_top - 128 * j0;                  // provenance byte of window index x: brow[x]
+      rowtab[s] = (int64_t)slab_top - (int64_t)(kbase + 128 * j0);  // wave-uniform store (same value from every lane)
+      slab_top += (size_t)width;
+      int qn = 0;
+      int cand = 0x7fffffff;
+      // ---- drain: queued cells {x | h << 16} are extended to the end of their match run in 64-lane batches; final offsets go to the patch table
+      auto drain = [&]() {
+        int pass = 0;
+        while (qn > 0) {
+          if (qn <= 4 && pass > 0) {
+            for (int e = 0; e < qn; ++e) {
+              const uint32_t ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)QU[e]);      // same address in every lane: keep it (and all that follows from it) scalar
+              const int x = (int)(ent & 0xffffu), h = (int)(ent >> 16), kk = kbase + x, v = h - kk;
+              const int m = wave_match(v, h, imin(pl - v, tl - h));
+              const int hf = h + m, vf = v + m;
+              PT16[x] = (uint16_t)hf;
+              if (ef ? ((hf >= tl && pl - vf <= pef) || (vf >= pl && tl - hf <= tef)) : (x == xe && hf >= tl)) cand = imin(cand, kk);
+            }
+            qn = 0;
+            break;
+          }
+          int wq = 0;
+          for (int q0 = 0; q0 < qn; q0 += 64) {
+            const bool act = q0 + lane < qn;
+            int x = 0, kk = 0, h = 0, v = 0;
+            bool more = false, fin = false;
+            if (act) {
+              const uint32_t ent = QU[q0 + lane];
+              x = (int)(ent & 0xffffu); h = (int)(ent >> 16); kk = kbase + x; v = h - kk;
+              const int rem = imin(pl - v, tl - h);
+              int m, full;
+              if (pass == 0) { m = match_n(v, h, rem, 2); full = 64; }
+              else { m = match_n(v, h, rem, 8); full = 256; }
+              v += m; h += m;
+              more = (m == full) && v < pl && h < tl;
+              if (!more) {
+                PT16[x] = (uint16_t)h;
+                fin = ef ? ((h >= tl && pl - v <= pef) || (v >= pl && tl - h <= tef)) : (x == xe && h >= tl);
+              }
+            }
+            const unsigned long long fm = __ballot(fin);
+            if (fm) {                                            // lowest diagonal among this batch's finishing cells
+              int kc = fin ? kk : 0x7fffffff;
+              kc = -otg_wave_max_i32(-kc);
+              cand = imin(cand, kc);
+            }
+            const unsigned long long mm = __ballot(more);
+            if (more) {
+              const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+              QU[wq + rank] = (uint32_t)x | ((uint32_t)h << 16);
+            }
+            wq += __builtin_popcountll(mm);
+          }
+          qn = wq; ++pass;
+        }
+      };
+      bool pushed = false, qfull = false;
+      auto push2 = [&](bool moreE, bool moreO, int xE, int hE, int hO) {
+        const unsigned long long mE = __ballot(moreE), mO = __ballot(moreO);
+        if (mE | mO) {
+          if (qn + 128 > QCAP) { qfull = true; return; }          // more unfinished match runs in one score than the queue holds: the next tier takes the alignment
+          const int nE = __builtin_popcountll(mE);
+          if (moreE) {
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mE >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mE, 0u));
+            QU[qn + rank] = (uint32_t)xE | ((uint32_t)hE << 16);
+          }
+          if (moreO) {
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mO >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mO, 0u));
+            QU[qn + nE + rank] = (uint32_t)(xE + 1) | ((uint32_t)hO << 16);
+          }
+          qn += nE + __builtin_popcountll(mO);
+          pushed = true;
+        }
+      };
+      // end condition of a fully extended cell (ends-free form; the end-to-end form is checked on the one end diagonal)
+      auto fin_ef = [&](int h, int v) -> bool { return h >= 0 && ((h >= tl && pl - v <= pef) || (v >= pl && tl - h <= tef)); };
+
+      if (s == 0) {
+        // score 0: offset max(k, 0) on every start diagonal, no I / D wavefronts; everything is extended through the queue
+        static_for<0, S2>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value;
+          if (i < j0 || i > j1) return;
+          const int xE = 128 * i + lane2, kE = kb + xE, kO = kE + 1;
+          const int hE = kE > 0 ? kE : 0, vE = hE - kE, hO = kO > 0 ? kO : 0, vO = hO - kO;
+          const bool validE = kE >= lo && kE <= hi && hE <= tl && vE <= pl, validO = kO >= lo && kO <= hi && hO <= tl && vO <= pl;
+          MC[0][i][0] = pack16(NUL16, validE ? hE : NUL16);
+          MC[0][i][1] = pack16(NUL16, validO ? hO : NUL16);
+          const bool moreE = validE && vE < pl && hE < tl, moreO = validO && vO < pl && hO < tl;
+          if (ef) {
+            const bool fE = validE && !moreE && fin_ef(hE, vE), fO = validO && !moreO && fin_ef(hO, vO);
+            const unsigned long long fm = __ballot(fE || fO);
+            if (fm) { int kc = fE ? kE : (fO ? kO : 0x7fffffff); kc = -otg_wave_max_i32(-kc); cand = imin(cand, kc); }
+          } else if (xe >= 128 * i && xe < 128 * i + 128) {
+            const int hx = __builtin_amdgcn_readlane((xe & 1) ? (validO && !moreO ? hO : -1) : (validE && !moreE ? hE : -1), (xe & 127) >> 1);
+            if (hx >= tl) cand = kend;
+          }
+          push2(moreE, moreO, xE, hE, hO);
+        });
+      } else {
+        // ---- the sweep over the touched pair-slots, ascending
+        uint32_t carryL = NN;                     // {M[s-4], I[s-1]} of the diagonal left of the current pair-slot
+        static_for<0, S2>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value;
+          if (i + 1 == j0) {                       // the slot left of the first touched one: its lane 63 is the left neighbour of the sweep
+            carryL = (uint32_t)__builtin_amdgcn_readlane((int)pack16(lo16s(MC[0][i][1]), lo16s(ID[i][1])), 63);
+          }
+          if (i < j0 || i > j1) return;
+          const uint32_t mE = MC[0][i][0], mO = MC[0][i][1], dE = ID[i][0], dO = ID[i][1];
+          const uint32_t Lx = pack16(lo16s(mO), lo16s(dO));                               // what the lane to the right needs: {M[s-4][odd], I[s-1][odd]}
+          const uint32_t Rx = pack16(lo16s(mE), hi16s(dE));                               // what the lane to the left needs: {M[s-4][even], D[s-1][even]}
+          uint32_t rcar = NN;
+          if (i + 1 < S2) rcar = (uint32_t)__builtin_amdgcn_readlane((int)pack16(lo16s(MC[0][i + 1][0]), hi16s(ID[i + 1][0])), 0);   // the next pair-slot's lane 0, still old
+          const uint32_t lnb = (uint32_t)__builtin_amdgcn_update_dpp((int)carryL, (int)Lx, 0x138, 0xf, 0xf, false);   // lane l <- lane l-1, lane 0 <- carryL
+          const uint32_t rnb = (uint32_t)__builtin_amdgcn_update_dpp((int)rcar, (int)Rx, 0x130, 0xf, 0xf, false);     // lane l <- lane l+1, lane 63 <- rcar
+          carryL = (uint32_t)__builtin_amdgcn_readlane((int)Lx, 63);
+          const int xE = 128 * i + lane2, kE = kb + xE;
+          int insE, delE, mxE, insO, delO, mxO;
+          uint32_t bitsE, bitsO;
+          {   // even diagonal: left neighbour from lane l-1, right neighbour is the lane's own odd diagonal
+            const int io = lo16s(lnb), ix = hi16s(lnb), dop = lo16s(mO), dx = hi16s(dO), mm = hi16s(mE);
+            bitsE = 0;
+            if (ix >= io) { insE = ix; bitsE |= 4u; } else insE = io;
+            insE += 1;
+            if (dx >= dop) { delE = dx; bitsE |= 8u; } else delE = dop;
+            const int mis = mm + 1;
+            mxE = imax(delE, imax(mis, insE));
+            uint32_t org = 0;
+            if (mxE == insE) org = 2;
+            if (mxE == delE) org = 1;
+            if (mxE == mis) org = 0;
+            bitsE |= org;
+          }
+          {   // odd diagonal: left neighbour is the lane's own even diagonal (old values), right neighbour from lane l+1
+            const int io = lo16s(mE), ix = lo16s(dE), dop = lo16s(rnb), dx = hi16s(rnb), mm = hi16s(mO);
+            bitsO = 0;
+            if (ix >= io) { insO = ix; bitsO |= 4u; } else insO = io;
+            insO += 1;
+            if (dx >= dop) { delO = dx; bitsO |= 8u; } else delO = dop;
+            const int mis = mm + 1;
+            mxO = imax(delO, imax(mis, insO));
+            uint32_t org = 0;
+            if (mxO == insO) org = 2;
+            if (mxO == delO) org = 1;
+            if (mxO == mis) org = 0;
+            bitsO |= org;
+          }
+          ID[i][0] = pack16(insE, delE);
+          ID[i][1] = pack16(insO, delO);
+          int hE = mxE, hO = mxO;
+          const int vE = mxE - kE, vO = mxO - kE - 1;
+          const bool validE = (uint32_t)hE <= (uint32_t)tl && (uint32_t)vE <= (uint32_t)pl;
+          const bool validO = (uint32_t)hO <= (uint32_t)tl && (uint32_t)vO <= (uint32_t)pl;
+          const bool probeE = validE && vE < pl && hE < tl, probeO = validO && vO < pl && hO < tl;
+          const uint64_t aE = ld32b(0, validE ? vE : 0), bE = ld32b(offT, validE ? hE : 0);
+          const uint64_t aO = ld32b(0, validO ? vO : 0), bO = ld32b(offT, validO ? hO : 0);
+          const uint16_t b2 = (uint16_t)(bitsE | (bitsO << 8));
+          __builtin_memcpy(brow + xE, &b2, 2);
+          bool moreE, moreO;
+          {
+            const uint64_t xx = aE ^ bE;
+            int m = xx ? (int)(__builtin_ctzll(xx) >> 1) : 32;
+            m = imin(m, imin(pl - vE, tl - hE));
+            m = probeE ? m : 0;
+            hE += m;
+            moreE = probeE && m == 32 && vE + m < pl && hE < tl;
+          }
+          {
+            const uint64_t xx = aO ^ bO;
+            int m = xx ? (int)(__builtin_ctzll(xx) >> 1) : 32;
+            m = imin(m, imin(pl - vO, tl - hO));
+            m = probeO ? m : 0;
+            hO += m;
+            moreO = probeO && m == 32 && vO + m < pl && hO < tl;
+          }
+          const int sE = validE ? hE : NUL16, sO = validO ? hO : NUL16;
+          MC[0][i][0] = (mE >> 16) | ((uint32_t)sE << 16);
+          MC[0][i][1] = (mO >> 16) | ((uint32_t)sO << 16);
+          if (ef) {
+            const bool fE = validE && !moreE && fin_ef(hE, hE - kE), fO = validO && !moreO && fin_ef(hO, hO - kE - 1);
+            const unsigned long long fm = __ballot(fE || fO);
+            if (fm) { int kc = fE ? kE : (fO ? kE + 1 : 0x7fffffff); kc = -otg_wave_max_i32(-kc); cand = imin(cand, kc); }
+          } else if (xe >= 128 * i && xe < 128 * i + 128) {
+            const int hx = __builtin_amdgcn_readlane((xe & 1) ? (validO && !moreO ? hO : -1) : (validE && !moreE ? hE : -1), (xe & 127) >> 1);
+            if (hx >= tl) cand = kend;
+          }
+          push2(moreE, moreO, xE, hE, hO);
+        });
+      }
+      if (qfull) { fail = true; break; }
+      if (pushed) {
+        drain();
+        // fold the final offsets of the queued cells into the M words (partial offset <= final offset: a packed max)
+        static_for<0, S2>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value;
+          if (i < j0 || i > j1) return;
+          const uint32_t pw = PT[64 * i + lane];
+          if (__ballot(pw != NN)) {
+            MC[0][i][0] = pk_max_i16(MC[0][i][0], pack16(NUL16, lo16s(pw)));
+            MC[0][i][1] = pk_max_i16(MC[0][i][1], pack16(NUL16, hi16s(pw)));
+            PT[64 * i + lane] = NN;
+          }
+        });
+      }
+      idlo = s == 0 ? 1 : lo; idhi = s == 0 ? 0 : hi;
+      cand = __builtin_amdgcn_readfirstlane(cand);
+      if (cand != 0x7fffffff) { s_end = s; k_end = cand; break; }
+      // the other parity is next
+      static_for<0, S2>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value;
+        { const uint32_t t_ = MC[0][i][0]; MC[0][i][0] = MC[1][i][0]; MC[1][i][0] = t_; }
+        { const uint32_t t_ = MC[0][i][1]; MC[0][i][1] = MC[1][i][1]; MC[1][i][1] = t_; } });
+    }
+
+    if (fail || s_end < 0) {
+      const uint32_t q = otg_wave_atomic_add(n_overflow, 1u);
+      overflow_list[q] = ti;                                   // wave-uniform store
+      continue;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    if (!backtrace_unpack(P, pl, T, tl, s_end, k_end, xs, oes, es, rowtab, slab, rev, ws.rev_cap, cig_arena + cig_off[ti], lane, &scores[ti], &cig_len[ti], g)) continue;
+    if (cells) cells[ti] = affine_cells(t, xs, oes, s_end);
+    if (visited && lane == 0) atomicAdd(visited, (unsigned long long)slab_top);
   }
 }
 
@@ -1384,6 +1808,95 @@ __global__ __launch_bounds__(256) void K_asort_scatter(const uint32_t* __restric
   }
 }
 
+
+// ---- register-resident tiers (v5): which tier takes an alignment follows from its score bound and shape alone — the same window
+// arithmetic as the kernel — so one counting sort on (tier, bound) hands every tier its own list, longest alignments first
+constexpr int V5_TIERS = 3;                                         // pair-slots 8 / 12 / 16: windows of 1024 / 1536 / 2048 diagonals
+constexpr int TSORT_BUCKETS = (V5_TIERS + 1) * ASORT_BUCKETS;       // last tier = everything else (LDS / HBM tiers)
+__device__ __forceinline__ int v5_tier(const otg_align_task& t, int U)
+{
+  const int pl = (int)t.pattern_len, tl = (int)t.text_len;
+  if (U < 0 || U >= 0x40000000 || pl >= 32766 || tl >= 32766) return V5_TIERS;
+  const bool ef = t.endsfree != 0;
+  const int kend = tl - pl;
+  const int elo = kend - (ef ? t.text_end_free : 0), ehi = kend + (ef ? t.pattern_end_free : 0);
+  int lo0 = ef ? imax(-t.pattern_begin_free, -pl) : 0, hi0 = ef ? imin(t.text_begin_free, tl) : 0;
+  lo0 = imax(lo0, elo - U); hi0 = imin(hi0, ehi + U);
+  if (hi0 < lo0) return V5_TIERS;
+  const int wlo = imax((lo0 + elo - U) >> 1, -pl) - 1, whi = imin((hi0 + ehi + U + 1) >> 1, tl) + 1;
+  const int need = whi - (wlo - 2) + 4;                             // the kernel wants need < CAP
+  const int seqb = ((pl + 15) / 16 + 3 + (tl + 15) / 16 + 3) * 4;
+  if (need < 1024 && seqb <= 4096) return 0;
+  if (need < 1536 && seqb <= 4608) return 1;
+  if (need < 2048 && seqb <= 6144) return 2;
+  return V5_TIERS;
+}
+__device__ __forceinline__ int tsort_bucket(const otg_align_task& t, int U) { return v5_tier(t, U) * ASORT_BUCKETS + asort_bucket(U); }
+__global__ __launch_bounds__(256) void K_tsort_hist(const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_ptr, uint32_t n_imm,
+                                                    const otg_align_task* __restrict__ tasks, const int32_t* __restrict__ bound, uint32_t* __restrict__ hist)
+{
+  __shared__ uint32_t h[TSORT_BUCKETS];
+  for (int b = (int)threadIdx.x; b < TSORT_BUCKETS; b += 256) h[b] = 0;
+  __syncthreads();
+  const uint32_t n = n_ptr ? *n_ptr : n_imm;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { const uint32_t ti = list ? list[i] : i; atomicAdd(&h[tsort_bucket(tasks[ti], bound[ti])], 1u); }
+  __syncthreads();
+  for (int b = (int)threadIdx.x; b < TSORT_BUCKETS; b += 256) if (h[b]) atomicAdd(&hist[b], h[b]);
+}
+// exclusive scan of the bucket counts (one block) + the tier segment bounds seg[0 .. V5_TIERS + 1]
+__global__ __launch_bounds__(1024) void K_tsort_scan(uint32_t* __restrict__ hist, uint32_t* __restrict__ seg)
+{
+  __shared__ uint32_t part[1024];
+  constexpr int PER = (TSORT_BUCKETS + 1023) / 1024;
+  const int t = (int)threadIdx.x;
+  uint32_t v[PER], s = 0;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) { const int b = t * PER + j; v[j] = b < TSORT_BUCKETS ? hist[b] : 0u; s += v[j]; }
+  part[t] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const uint32_t x = t >= off ? part[t - off] : 0u;
+    __syncthreads();
+    part[t] += x;
+    __syncthreads();
+  }
+  uint32_t acc = part[t] - s;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int b = t * PER + j;
+    if (b < TSORT_BUCKETS) { hist[b] = acc; if (b % ASORT_BUCKETS == 0) seg[b / ASORT_BUCKETS] = acc; }
+    acc += v[j];
+  }
+  if (t == 1023) seg[V5_TIERS + 1] = part[1023];
+}
+__global__ __launch_bounds__(256) void K_tsort_scatter(const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_ptr, uint32_t n_imm,
+                                                       const otg_align_task* __restrict__ tasks, const int32_t* __restrict__ bound,
+                                                       uint32_t* __restrict__ pos, uint32_t* __restrict__ out)
+{
+  __shared__ uint32_t cnt[TSORT_BUCKETS], basep[TSORT_BUCKETS];
+  const uint32_t n = n_ptr ? *n_ptr : n_imm;
+  const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
+  const uint32_t lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+  for (int b = (int)threadIdx.x; b < TSORT_BUCKETS; b += 256) cnt[b] = 0;
+  __syncthreads();
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) { const uint32_t ti = list ? list[i] : i; atomicAdd(&cnt[tsort_bucket(tasks[ti], bound[ti])], 1u); }
+  __syncthreads();
+  for (int b = (int)threadIdx.x; b < TSORT_BUCKETS; b += 256) { basep[b] = cnt[b] ? atomicAdd(&pos[b], cnt[b]) : 0u; cnt[b] = 0; }
+  __syncthreads();
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
+    const uint32_t ti = list ? list[i] : i;
+    const int b = tsort_bucket(tasks[ti], bound[ti]);
+    out[basep[b] + atomicAdd(&cnt[b], 1u)] = ti;
+  }
+}
+// the last segment (alignments no register tier takes) opens the list the LDS / HBM tiers work on; the register tiers append what they give up
+__global__ void K_seg_copy(const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ seg, uint32_t* __restrict__ out, uint32_t* __restrict__ n_out)
+{
+  const uint32_t a = seg[0], n = seg[1] - seg[0];
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = sorted[a + i];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *n_out = n;
+}
+
 } // namespace
 
 int otg_launch_affine(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_task* d_tasks, uint32_t n_tasks,
@@ -1403,11 +1916,15 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
   const int g = gcd3(x, o + e, e);
   const int xs = x / g, oes = (o + e) / g, es = e / g;
   if (std::max(xs, oes) + 1 > 64 || es + 1 > 64) return otg_fail(ctx, OTG_ERR_ARG, "affine penalties too large after gcd reduction");
-  uint32_t* cnt = (uint32_t*)otg_slot(ctx, SLOT_COUNTERS, 64 * sizeof(uint32_t));
-  uint32_t* todo = (uint32_t*)otg_slot(ctx, SLOT_TODO, 7 * (size_t)n_tasks * sizeof(uint32_t));
+  const bool fresh_cnt = ctx->pool[SLOT_COUNTERS].cap < 128 * sizeof(uint32_t);
+  uint32_t* cnt = (uint32_t*)otg_slot(ctx, SLOT_COUNTERS, 128 * sizeof(uint32_t));
+  uint32_t* todo = (uint32_t*)otg_slot(ctx, SLOT_TODO, 8 * (size_t)n_tasks * sizeof(uint32_t));
   if (!cnt || !todo) return OTG_ERR_HIP;
   HIP_TRY(ctx, hipMemsetAsync(cnt + 8, 0, 8 * sizeof(uint32_t), ctx->stream));   // tickets / overflow counters of the tiers
   HIP_TRY(ctx, hipMemsetAsync(cnt + 24, 0, 8 * sizeof(uint32_t), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(cnt + 64, 0, 16 * sizeof(uint32_t), ctx->stream));      // register tiers: segment bounds, overflow count, tickets
+  // visited-cell counter of the exact tiers (accumulates over the launches of a run; otg_assemble_run zeroes it)
+  if (fresh_cnt || !ctx->affine_visited) { ctx->affine_visited = (unsigned long long*)(cnt + 96); HIP_TRY(ctx, hipMemsetAsync(cnt + 96, 0, 8, ctx->stream)); }
 
   const size_t maxlen = ctx->max_seq_len;
   AffWs ws;
@@ -1417,6 +1934,7 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
   ws.nrows = (int)(2 * (size_t)oes + (size_t)es * 2 * maxlen + 16);
   ws.rev_cap = 4 * maxlen + 64;
   ws.dbg = getenv("OTG_DEBUG") != nullptr;
+  ws.visited = ctx->affine_visited;
   if (ws.dbg) { const unsigned long long z[2] = {0, 0}; HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(otg_dbg_v4_cells), z, sizeof(z))); }
   size_t ring_bytes = (size_t)(ws.rm + 2 * ws.ri) * ws.capa * sizeof(int32_t);
   ws.off_rowtab = (ring_bytes + 255) & ~(size_t)255;
@@ -1504,9 +2022,52 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
       static const int nws = getenv("OTG_V4_NWS") ? atoi(getenv("OTG_V4_NWS")) : 2;
       static const int nwm = getenv("OTG_V4_NWM") ? atoi(getenv("OTG_V4_NWM")) : 4;
       // alignments in decreasing order of their bound (work ~ bound^2): short tails in every tier kernel
-      const uint32_t* inS = d_todo;
+      const uint32_t* inS = d_todo; const uint32_t* inS_n = d_n_todo; uint32_t inS_imm = n_tasks;
       static const bool no_asort = getenv("OTG_NO_AFFINE_SORT") != nullptr;
-      if (!no_asort) {
+      static const bool no_v5 = getenv("OTG_NO_AFFINE_V5") != nullptr;
+      if (!no_v5) {
+        // register-resident tiers: one counting sort on (tier, bound) gives each tier its list; what no tier takes (or a tier gives up)
+        // is the input of the LDS / HBM tiers below
+        uint32_t* hist = (uint32_t*)otg_slot(ctx, SLOT_ROWTAB, TSORT_BUCKETS * sizeof(uint32_t));
+        uint32_t* sorted = todo + 6 * (size_t)n_tasks;
+        uint32_t* ovf5 = todo + 7 * (size_t)n_tasks;
+        uint32_t* seg = cnt + 64;               // seg[0 .. V5_TIERS + 1]
+        uint32_t* n_ovf5 = cnt + 70;
+        if (!hist) return OTG_ERR_HIP;
+        HIP_TRY(ctx, hipMemsetAsync(hist, 0, TSORT_BUCKETS * sizeof(uint32_t), ctx->stream));
+        const uint32_t sg = std::min<uint32_t>((n_tasks + 2047) / 2048, (uint32_t)ctx->n_cu * 2);
+        hipLaunchKernelGGL(K_tsort_hist, dim3(sg), dim3(256), 0, ctx->stream, d_todo, d_n_todo, n_tasks, d_tasks, (const int32_t*)d_bound, hist);
+        hipLaunchKernelGGL(K_tsort_scan, dim3(1), dim3(1024), 0, ctx->stream, hist, seg);
+        hipLaunchKernelGGL(K_tsort_scatter, dim3(sg), dim3(256), 0, ctx->stream, d_todo, d_n_todo, n_tasks, d_tasks, (const int32_t*)d_bound, hist, sorted);
+        hipLaunchKernelGGL(K_seg_copy, dim3(std::min<uint32_t>((n_tasks + 255) / 256, 1024u)), dim3(256), 0, ctx->stream, (const uint32_t*)sorted,
+                           (const uint32_t*)(seg + V5_TIERS), ovf5, n_ovf5);
+        // per-wave workspaces of the three tiers side by side (they may run concurrently); row table sized by the window (a score is a row)
+        auto v5_ws = [&](int cap, uint32_t blocks_per_cu, uint32_t& blocks) {
+          AffWs w = ws;
+          w.nrows = cap + 64;
+          w.off_rowtab = 0;
+          w.off_rev = ((size_t)w.nrows * sizeof(int64_t) + 255) & ~(size_t)255;
+          w.off_slab = (w.off_rev + ws.rev_cap + 255) & ~(size_t)255;
+          w.slab_bytes = ((size_t)cap * (size_t)cap * 7 / 8 + (1 << 16)) & ~(size_t)255;
+          w.stride = w.off_slab + w.slab_bytes;
+          blocks = std::min<uint32_t>((uint32_t)ctx->n_cu * blocks_per_cu, (n_tasks + 3) / 4);
+          return w;
+        };
+        uint32_t b0, b1, b2;
+        AffWs w0 = v5_ws(1024, 4, b0), w1 = v5_ws(1536, 3, b1), w2 = v5_ws(2048, 2, b2);
+        const size_t need5 = w0.stride * b0 * 4 + w1.stride * b1 * 4 + w2.stride * b2 * 4;
+        uint8_t* ws5 = (uint8_t*)otg_slot(ctx, SLOT_REVOPS, need5);
+        if (!ws5) return OTG_ERR_HIP;
+        w0.base = ws5; w1.base = ws5 + w0.stride * b0 * 4; w2.base = w1.base + w1.stride * b1 * 4;
+        unsigned long long* vis = ctx->affine_visited;
+        hipLaunchKernelGGL((wfa_affine_kernel_v5<8, 4096, 4>), dim3(b0), dim3(256), 0, ctx->stream, d_arena, d_tasks, (const uint32_t*)sorted, (const uint32_t*)(seg + 0), g,
+                           d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, cnt + 72, n_ovf5, ovf5, w0, (const int32_t*)d_bound, vis);
+        hipLaunchKernelGGL((wfa_affine_kernel_v5<12, 4608, 3>), dim3(b1), dim3(256), 0, ctx->stream, d_arena, d_tasks, (const uint32_t*)sorted, (const uint32_t*)(seg + 1), g,
+                           d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, cnt + 73, n_ovf5, ovf5, w1, (const int32_t*)d_bound, vis);
+        hipLaunchKernelGGL((wfa_affine_kernel_v5<16, 6144, 2>), dim3(b2), dim3(256), 0, ctx->stream, d_arena, d_tasks, (const uint32_t*)sorted, (const uint32_t*)(seg + 2), g,
+                           d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, cnt + 74, n_ovf5, ovf5, w2, (const int32_t*)d_bound, vis);
+        inS = ovf5; inS_n = n_ovf5; inS_imm = 0;
+      } else if (!no_asort) {
         uint32_t* hist = (uint32_t*)otg_slot(ctx, SLOT_ROWTAB, ASORT_BUCKETS * sizeof(uint32_t));
         uint32_t* sortedU = todo + 6 * (size_t)n_tasks;
         if (!hist) return OTG_ERR_HIP;
@@ -1522,8 +2083,8 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
                          TODO, NTODO, IMM, g, d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, TICK, OVF, LIST, WS,       \
                          (const int32_t*)d_bound)
       static const bool no_mid = getenv("OTG_V4_NO_MID") != nullptr;
-      if (nws == 1) OTG_V4_LAUNCH(1024, 1, 2304, 3, blocksS, inS, d_n_todo, n_tasks, cnt + 24, cnt + 25, listS, wsS);
-      else OTG_V4_LAUNCH(1024, 2, 2304, 5, blocksS, inS, d_n_todo, n_tasks, cnt + 24, cnt + 25, listS, wsS);
+      if (nws == 1) OTG_V4_LAUNCH(1024, 1, 2304, 3, blocksS, inS, inS_n, inS_imm, cnt + 24, cnt + 25, listS, wsS);
+      else OTG_V4_LAUNCH(1024, 2, 2304, 5, blocksS, inS, inS_n, inS_imm, cnt + 24, cnt + 25, listS, wsS);
       const uint32_t* inM = listS; const uint32_t* inM_n = cnt + 25;
       if (!no_mid) {
         OTG_V4_LAUNCH(1472, 4, 2688, 7, blocksX, (const uint32_t*)listS, (const uint32_t*)(cnt + 25), 0u, cnt + 28, cnt + 29, listX, wsX);
@@ -1559,6 +2120,9 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
     uint32_t h[32];
     HIP_TRY(ctx, hipMemcpy(h, cnt, sizeof(h), hipMemcpyDeviceToHost));
     fprintf(stderr, "[otg] affine: LDS tiers overflow %u / %u, tier A overflow %u, tier B overflow %u\n", h[25], h[27], h[9], h[11]);
+    { uint32_t h5[8]; HIP_TRY(ctx, hipMemcpy(h5, cnt + 64, sizeof(h5), hipMemcpyDeviceToHost));
+      fprintf(stderr, "[otg] affine: register tiers take %u / %u / %u alignments, %u go to the LDS tiers (of which given up by a register tier: %u)\n",
+              h5[1] - h5[0], h5[2] - h5[1], h5[3] - h5[2], h5[6], h5[6] - (h5[4] - h5[3])); }
     {
       unsigned long long vc[2] = {0, 0};
       HIP_TRY(ctx, hipMemcpyFromSymbol(vc, HIP_SYMBOL(otg_dbg_v4_cells), sizeof(vc)));
