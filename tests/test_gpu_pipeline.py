@@ -242,10 +242,13 @@ def test_stale_cigar_member(gpu, oracle):
     res, _ = run_both(gpu, oracle, b2)
     lab = res["labels"][picked]
     assert (lab >= 0).sum() >= 8                         # re-assigned by similarity, so they are members of an allele graph
-    # and the case is live: their allele is built by POA (more than two reads) and they are longer than the representative
-    for i, r in zip(picked, range(len(regions))):
-        if lab[picked.index(i)] < 0:
+    # and the case is live: some of them sit in alleles built by POA (more than two reads) and are longer than the representative
+    live = 0
+    for j, i in enumerate(picked):
+        if lab[j] < 0:
             continue
-        g = res["regions"][r]
-        a = res["alleles"][int(g["first_allele"]) + int(lab[picked.index(i)])]
-        assert int(a["acov"]) > 2 and int(reads["seq_len"][i]) > int(a["seq_len"]) - 8
+        g = res["regions"][j]
+        a = res["alleles"][int(g["first_allele"]) + int(lab[j])]
+        if int(a["acov"]) > 2 and int(reads["seq_len"][i]) > int(a["seq_len"]) - 8:
+            live += 1
+    assert live >= 4
