@@ -1982,18 +1982,20 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
   uint32_t blocksS = std::min<uint32_t>((uint32_t)ctx->n_cu * 10, n_tasks), blocksM = std::min<uint32_t>((uint32_t)ctx->n_cu * 5, n_tasks);   // resident blocks per CU (LDS / VGPR limits)
   uint32_t blocksX = std::min<uint32_t>((uint32_t)ctx->n_cu * 7, n_tasks);
   uint32_t blocksL = std::min<uint32_t>((uint32_t)ctx->n_cu * 2, n_tasks);
-  AffWs wsS = lds_ws(1024, blocksS), wsM = lds_ws(2048, blocksM), wsX = lds_ws(1472, blocksX), wsL = lds_ws(4096, blocksL);
+  uint32_t blocksH = std::min<uint32_t>((uint32_t)ctx->n_cu * 3, n_tasks);
+  AffWs wsS = lds_ws(1024, blocksS), wsM = lds_ws(2048, blocksM), wsX = lds_ws(1472, blocksX), wsL = lds_ws(4096, blocksL), wsH = lds_ws(3072, blocksH);
   const size_t need = std::max(std::max(std::max(wsA.stride * wavesA, wsB.stride * wavesB), wsC.stride * (size_t)gridC * WPB),
-                               std::max(std::max(wsS.stride * blocksS, wsM.stride * blocksM), std::max(wsX.stride * blocksX, wsL.stride * blocksL)));
+                               std::max(std::max(wsS.stride * blocksS, wsM.stride * blocksM), std::max(std::max(wsX.stride * blocksX, wsH.stride * blocksH), wsL.stride * blocksL)));
   uint8_t* wsp = (uint8_t*)otg_slot(ctx, SLOT_WF_WS, need);
   if (!wsp) return OTG_ERR_HIP;
-  wsA.base = wsB.base = wsC.base = wsS.base = wsM.base = wsX.base = wsL.base = wsp;
+  wsA.base = wsB.base = wsC.base = wsS.base = wsM.base = wsX.base = wsL.base = wsH.base = wsp;
   uint32_t* listA = todo;                  // overflow of tier A
   uint32_t* listB = todo + n_tasks;        // overflow of tier B
   uint32_t* listS = todo + 2 * (size_t)n_tasks;   // overflow of the LDS tier with 1024 diagonals
   uint32_t* listM = todo + 3 * (size_t)n_tasks;   // ... 2048 diagonals
   uint32_t* listX = todo + 4 * (size_t)n_tasks;   // ... 1472 diagonals
   uint32_t* listL = todo + 5 * (size_t)n_tasks;   // ... 4096 diagonals
+  uint32_t* listH = todo + 7 * (size_t)n_tasks;   // ... 3072 diagonals (shares its slot with the register tiers' overflow list, which is consumed by then)
   static const bool no_v3 = getenv("OTG_NO_AFFINE_V3") != nullptr;
   if (kernel_ms) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   const uint32_t* cur = d_todo; const uint32_t* cur_n = d_n_todo; uint32_t cur_imm = n_tasks;
@@ -2024,7 +2026,7 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
       // alignments in decreasing order of their bound (work ~ bound^2): short tails in every tier kernel
       const uint32_t* inS = d_todo; const uint32_t* inS_n = d_n_todo; uint32_t inS_imm = n_tasks;
       static const bool no_asort = getenv("OTG_NO_AFFINE_SORT") != nullptr;
-      static const bool no_v5 = getenv("OTG_NO_AFFINE_V5") != nullptr;
+      static const bool no_v5 = getenv("OTG_AFFINE_V5") == nullptr;      // register-resident tiers: opt-in (measured on par with the LDS tiers)
       if (!no_v5) {
         // register-resident tiers: one counting sort on (tier, bound) gives each tier its list; what no tier takes (or a tier gives up)
         // is the input of the LDS / HBM tiers below
@@ -2092,11 +2094,17 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
       }
       if (nwm == 4) OTG_V4_LAUNCH(2048, 4, 3072, 5, blocksM, inM, inM_n, 0u, cnt + 26, cnt + 27, listM, wsM);
       else OTG_V4_LAUNCH(2048, 2, 3072, 3, blocksM, inM, inM_n, 0u, cnt + 26, cnt + 27, listM, wsM);
-      // diamonds of up to 4096 diagonals (reads beyond ~6 kb at ONT divergence): eight waves per alignment, two alignments per CU
-      static const bool no_l = getenv("OTG_V4_NO_L") != nullptr;
+      // diamonds of up to 3072 diagonals (reads of ~6-9 kb at ONT divergence): six waves per alignment, three alignments per CU
+      static const bool no_h = getenv("OTG_V4_NO_H") != nullptr;
       const uint32_t* outM = listM; const uint32_t* outM_n = cnt + 27;
+      if (!no_h) {
+        OTG_V4_LAUNCH(3072, 6, 5632, 3, blocksH, (const uint32_t*)listM, (const uint32_t*)(cnt + 27), 0u, cnt + 76, cnt + 77, listH, wsH);
+        outM = listH; outM_n = cnt + 77;
+      }
+      // diamonds of up to 4096 diagonals: eight waves per alignment, two alignments per CU
+      static const bool no_l = getenv("OTG_V4_NO_L") != nullptr;
       if (!no_l) {
-        OTG_V4_LAUNCH(4096, 8, 6144, 2, blocksL, (const uint32_t*)listM, (const uint32_t*)(cnt + 27), 0u, cnt + 30, cnt + 31, listL, wsL);
+        OTG_V4_LAUNCH(4096, 8, 6144, 2, blocksL, outM, outM_n, 0u, cnt + 30, cnt + 31, listL, wsL);
         outM = listL; outM_n = cnt + 31;
       }
 #undef OTG_V4_LAUNCH
