@@ -1322,9 +1322,10 @@ __global__ __launch_bounds__(NW * 64, WPEU) void wfa_affine_kernel_v4(
       continue;
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");      // provenance bytes of the other waves (same CU, through L2)
+    if (ws.dbg & 2) { scores[ti] = s_end * g; cig_len[ti] = 0; continue; }
     if (!backtrace_unpack(P, pl, T, tl, s_end, k_end, xs, oes, es, rowtab, slab, rev, ws.rev_cap, cig_arena + cig_off[ti], lane, &scores[ti], &cig_len[ti], g)) continue;
     if (cells) cells[ti] = affine_cells(t, xs, oes, s_end);
-    if (ws.dbg && threadIdx.x == 0) { atomicAdd(&otg_dbg_v4_cells[0], (unsigned long long)slab_top); atomicAdd(&otg_dbg_v4_cells[1], 1ull); }
+    if ((ws.dbg & 1) && threadIdx.x == 0) { atomicAdd(&otg_dbg_v4_cells[0], (unsigned long long)slab_top); atomicAdd(&otg_dbg_v4_cells[1], 1ull); }
     if (ws.visited && threadIdx.x == 0) atomicAdd(ws.visited, (unsigned long long)slab_top);
   }
 }
@@ -1933,9 +1934,9 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
   ws.ri = es + 1;
   ws.nrows = (int)(2 * (size_t)oes + (size_t)es * 2 * maxlen + 16);
   ws.rev_cap = 4 * maxlen + 64;
-  ws.dbg = getenv("OTG_DEBUG") != nullptr;
+  ws.dbg = (getenv("OTG_DEBUG") != nullptr ? 1 : 0) | (getenv("OTG_DBG_NO_BT") != nullptr ? 2 : 0);
   ws.visited = ctx->affine_visited;
-  if (ws.dbg) { const unsigned long long z[2] = {0, 0}; HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(otg_dbg_v4_cells), z, sizeof(z))); }
+  if (ws.dbg & 1) { const unsigned long long z[2] = {0, 0}; HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(otg_dbg_v4_cells), z, sizeof(z))); }
   size_t ring_bytes = (size_t)(ws.rm + 2 * ws.ri) * ws.capa * sizeof(int32_t);
   ws.off_rowtab = (ring_bytes + 255) & ~(size_t)255;
   ws.off_rev = (ws.off_rowtab + (size_t)ws.nrows * sizeof(int64_t) + 255) & ~(size_t)255;

@@ -86,7 +86,15 @@ for k, c in agg.items():
     kernels[k] = derive(c, n)
     for name, v in c.items():
         groups[g][name] += v
-chain_launches = {"wfa_edit_kernel": 2, "wfa_affine_kernel": 2 if synth.CONFIGS[cfg].get("realign") else 1, "poa": 1, "cluster": 1}
+# launches of each chain inside the profiled process (bench.py --steps 1 --warmup 0 = the timed step + the host-to-host pass): counted on a kernel
+# that runs exactly once per chain launch
+def n_of(name, default):
+    for k in kernels:
+        if k.startswith(name):
+            return max(1, kernels[k]["launches"])
+    return default
+chain_launches = {"wfa_edit_kernel": n_of("edit_route_kernel", 2), "wfa_affine_kernel": n_of("wfa_affine_bound1_kernel", 1), "poa": n_of("poa_count_kernel", 1),
+                  "cluster": n_of("cluster_kernel", 1)}
 physical, traffic = {}, {}
 for g, c in groups.items():
     d = derive(c, chain_launches[g])
