@@ -391,6 +391,37 @@ int otg_assemble_collect(otg_ctx* ctx,
                          int32_t* labels_out);
 int otg_assemble_stats(otg_ctx* ctx, otg_run_stats* out);
 
+/* ---------------------------------------------------------------------------------------------
+ * The dispatcher: `otter assemble` from files to record text in one call — the role of assemble() /
+ * assemble_process() (src/assemble.cpp:39-179) over BS::thread_pool::parallelize_loop (src/BS_thread_pool.hpp:175-200).
+ * The BED list is split into one contiguous shard per device (the reference's static split, GPUs for threads); every shard is cut
+ * into bounded batches of `batch_regions` regions that are ingested on host threads, run through the hot path on the device (two
+ * contexts per device: the upload of a batch overlaps the kernels of the previous one) and emitted, the three stages concurrently.
+ * Text reaches `write` strictly in BED order (SAM header first unless is_fasta), whatever the batch size or the number of devices.
+ * Host memory is bounded by the batch size.  A non-zero return of `write` aborts the job.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct otg_assemble_job {
+  const char* bam_path;          /* <BAM> (its index is <BAM>.bai)                                   */
+  const char* bed_path;          /* -b                                                               */
+  const char* fasta_path;        /* -r (NULL or "": no local re-alignment)                           */
+  const char* read_group;        /* -R sample name                                                   */
+  int32_t     is_fasta;          /* --fasta                                                          */
+  int32_t     reads_only;        /* --reads-only                                                     */
+  otg_params  params;            /* heuristics (realign is set from fasta_path)                      */
+  otg_ingest_opts ingest;        /* --offset, --mapq, --non-primary, --omit-nonspanning, --read-quality; .threads = -t (host ingest threads) */
+  uint32_t    batch_regions;     /* regions per batch, 0 = 2048                                      */
+  int32_t     n_devices;         /* 0: device 0 only                                                 */
+  const int32_t* devices;        /* HIP device ordinals, one shard each                              */
+} otg_assemble_job;
+typedef struct otg_job_stats {
+  uint64_t n_regions, n_regions_ok, n_regions_skipped, n_reads, n_alleles, input_bytes, output_bytes;
+  uint32_t n_devices, reserved;
+  double   ms_total;             /* wall                                                             */
+  double   ms_ingest, ms_hot_path, ms_emit;   /* busy time of the three stages, summed over their threads (they overlap) */
+} otg_job_stats;
+typedef int (*otg_write_fn)(void* user, const char* data, uint64_t len);
+int otg_assemble_files(const otg_assemble_job* job, otg_write_fn write, void* user, otg_job_stats* stats);
+
 #ifdef __cplusplus
 }
 #endif

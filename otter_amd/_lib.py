@@ -18,7 +18,7 @@ EXPORTS = [
     "otg_bam_open", "otg_bam_close", "otg_bam_n_targets", "otg_bam_target", "otg_ingest_regions",
     "otg_ingest_regions_named", "otg_emit_reads", "otg_parse_bed_file", "otg_fasta_open", "otg_fasta_close", "otg_fasta_n_seqs",
     "otg_fasta_seq", "otg_fasta_fetch", "otg_fasta_region_flanks",
-    "otg_bam_sample_index", "otg_bam_sample", "otg_ingest_alleles", "otg_emit_vcf_header", "otg_emit_vcf_lines", "otg_emit_genotype_lengths",
+    "otg_bam_sample_index", "otg_bam_sample", "otg_ingest_alleles", "otg_emit_vcf_header", "otg_emit_vcf_lines", "otg_emit_genotype_lengths", "otg_assemble_files",
 ]
 
 _lib = None
@@ -520,3 +520,31 @@ def genotype_blocks(blk):
     first = blk["first_allele"]
     return (np.ascontiguousarray(a["seq_off"], dtype=np.uint64), np.ascontiguousarray(a["seq_len"], dtype=np.uint32),
             np.ascontiguousarray(first[:-1], dtype=np.uint32), np.ascontiguousarray(np.diff(first.astype(np.int64)), dtype=np.uint32))
+
+
+def assemble_files(bam, bed, fasta=None, read_group="", is_fasta=False, reads_only=False, params=None, batch_regions=0, devices=None,
+                   offset_l=1, offset_r=0, mapq=0, nonprimary=False, omit_nonspanning=False, read_quality=0.0, threads=1):
+    """otg_assemble_files: `otter assemble` from files to record text (the library's dispatcher, include/otter_gpu.h).
+    Returns (text bytes, stats dict)."""
+    L = load()
+    job = abi.AssembleJob()
+    job.bam_path = bam.encode(); job.bed_path = bed.encode(); job.fasta_path = fasta.encode() if fasta else None
+    job.read_group = read_group.encode(); job.is_fasta = int(is_fasta); job.reads_only = int(reads_only)
+    job.params = params if params is not None else abi.default_params()
+    job.ingest = abi.IngestOpts(offset_l, offset_r, mapq, int(nonprimary), int(omit_nonspanning), threads, read_quality)
+    job.batch_regions = batch_regions
+    devs = (C.c_int32 * len(devices))(*devices) if devices else None
+    job.n_devices = len(devices) if devices else 0
+    job.devices = devs
+    chunks = []
+
+    def sink(_user, data, n):
+        chunks.append(C.string_at(data, n))
+        return 0
+    cb = abi.WRITE_FN(sink)
+    st = abi.JobStats()
+    L.otg_assemble_files.argtypes = [C.POINTER(abi.AssembleJob), abi.WRITE_FN, C.c_void_p, C.POINTER(abi.JobStats)]
+    rc = L.otg_assemble_files(C.byref(job), cb, None, C.byref(st))
+    if rc != 0:
+        raise OtterGpuError("otg_assemble_files failed (%d): %s" % (rc, (L.otg_last_error(None) or b"").decode()))
+    return b"".join(chunks), {k: getattr(st, k) for k, _ in abi.JobStats._fields_}

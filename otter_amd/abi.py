@@ -142,3 +142,23 @@ def pack_seqs(seqs, pad=64):
         arena[pos:pos + len(s)] = np.frombuffer(s if isinstance(s, (bytes, bytearray)) else s.encode(), dtype=np.uint8)
         pos += len(s)
     return arena, np.asarray(offs, dtype=np.uint64), np.asarray(lens, dtype=np.uint32)
+
+
+class IngestOpts(C.Structure):
+    _fields_ = [("offset_l", C.c_int32), ("offset_r", C.c_int32), ("mapq", C.c_int32), ("nonprimary", C.c_int32), ("omit_nonspanning", C.c_int32),
+                ("threads", C.c_int32), ("read_quality", C.c_double)]
+
+
+class AssembleJob(C.Structure):
+    """otg_assemble_job (include/otter_gpu.h)."""
+    _fields_ = [("bam_path", C.c_char_p), ("bed_path", C.c_char_p), ("fasta_path", C.c_char_p), ("read_group", C.c_char_p),
+                ("is_fasta", C.c_int32), ("reads_only", C.c_int32), ("params", otg_params), ("ingest", IngestOpts),
+                ("batch_regions", C.c_uint32), ("n_devices", C.c_int32), ("devices", C.POINTER(C.c_int32))]
+
+
+class JobStats(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("n_regions", "n_regions_ok", "n_regions_skipped", "n_reads", "n_alleles", "input_bytes", "output_bytes")] + \
+               [("n_devices", C.c_uint32), ("reserved", C.c_uint32)] + [(k, C.c_double) for k in ("ms_total", "ms_ingest", "ms_hot_path", "ms_emit")]
+
+
+WRITE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_char), C.c_uint64)

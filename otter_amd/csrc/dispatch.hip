@@ -1,0 +1,326 @@
+// dispatch.hip — the per-region dispatcher of `otter assemble` as host code of the library.
+//
+// Reference: assemble() / assemble_process() (src/assemble.cpp:39-179) with BS::thread_pool::parallelize_loop
+// (src/BS_thread_pool.hpp:175-200): the BED list is cut into contiguous blocks, one per worker thread; every worker opens its own BAM /
+// FASTA handle, walks its block region by region (ingest -> the five hot-path calls -> emit under a mutex).
+//
+// Here a worker is a GPU.  The BED list is cut into one contiguous shard per device (the same static split), and every shard is cut into
+// bounded BATCHES of regions that flow through three stages running concurrently on host threads:
+//     ingest (otg_ingest_regions on T host threads, + reference flanks with -r)          -> queue (depth 2)
+//     hot path (otg_assemble_submit / run / collect; two contexts per device, so the upload of batch k+1 overlaps the kernels of batch k)
+//     emit (otg_emit_alleles / otg_emit_reads) + the caller's write callback, strictly in BED order
+// Memory is bounded by the batch size, not by the BED file; output order is the BED order whatever the number of devices or batches
+// (the reference's order with -t 1; with -t > 1 the reference prints in completion order).
+#include "otg_common.hpp"
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <thread>
+
+namespace {
+
+struct Batch {
+  uint32_t index = 0;                   // batch number inside its shard
+  uint32_t first = 0, n = 0;            // BED range [first, first + n)
+  std::vector<uint8_t> arena;
+  std::vector<otg_read> reads;
+  std::vector<otg_region> regions;
+  std::vector<otg_read_meta> meta;      // --reads-only
+  std::vector<char> names;
+  uint64_t arena_used = 0;
+  uint32_t n_reads = 0;
+  std::string text;                     // emitted records
+};
+
+template <class T>
+class BoundedQueue {
+ public:
+  explicit BoundedQueue(size_t cap) : cap_(cap) {}
+  bool push(T v) {
+    std::unique_lock<std::mutex> lk(m_);
+    cv_space_.wait(lk, [&] { return q_.size() < cap_ || closed_; });
+    if (closed_) return false;
+    q_.push_back(std::move(v));
+    cv_item_.notify_one();
+    return true;
+  }
+  bool pop(T& out) {
+    std::unique_lock<std::mutex> lk(m_);
+    cv_item_.wait(lk, [&] { return !q_.empty() || done_ || closed_; });
+    if (closed_ || q_.empty()) return false;
+    out = std::move(q_.front());
+    q_.pop_front();
+    cv_space_.notify_one();
+    return true;
+  }
+  void finish() { std::lock_guard<std::mutex> lk(m_); done_ = true; cv_item_.notify_all(); }           // no more items will come
+  void abort() { std::lock_guard<std::mutex> lk(m_); closed_ = true; cv_item_.notify_all(); cv_space_.notify_all(); }
+ private:
+  std::mutex m_;
+  std::condition_variable cv_item_, cv_space_;
+  std::deque<T> q_;
+  size_t cap_;
+  bool done_ = false, closed_ = false;
+};
+
+using BatchPtr = std::unique_ptr<Batch>;
+using Clock = std::chrono::steady_clock;
+double ms_since(Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
+
+struct Job {
+  const otg_assemble_job* j = nullptr;
+  std::vector<otg_bed> beds;
+  std::vector<char> chr_arena;
+  otg_bam* bam = nullptr;
+  otg_fasta* fasta = nullptr;
+  std::atomic<int> rc{OTG_OK};
+  std::mutex err_m;
+  std::string err;
+  // statistics (summed over threads)
+  std::mutex st_m;
+  otg_job_stats st{};
+  void fail(int code, const std::string& what) {
+    int expected = OTG_OK;
+    if (rc.compare_exchange_strong(expected, code)) { std::lock_guard<std::mutex> lk(err_m); err = what; }
+  }
+};
+
+std::string last_err() { const char* e = otg_last_error(nullptr); return e ? std::string(e) : std::string(); }
+
+// ---- stage 1: one batch of regions from the BAM (and the FASTA flanks with -r), buffers grown on OTG_ERR_CAPACITY
+int ingest_batch(Job& J, Batch& b, int threads)
+{
+  const otg_assemble_job& j = *J.j;
+  otg_ingest_opts o = j.ingest;
+  o.threads = threads;
+  b.regions.assign(b.n, otg_region{});
+  size_t cap_reads = std::max<size_t>(b.reads.size(), (size_t)b.n * 48 + 256), cap_arena = std::max<size_t>(b.arena.size(), (size_t)b.n * 48 * 4096 + 4096);
+  size_t cap_names = std::max<size_t>(b.names.size(), j.reads_only ? (size_t)b.n * 48 * 48 : 0);
+  for (int attempt = 0; attempt < 4; ++attempt) {
+    b.reads.resize(cap_reads); b.arena.resize(cap_arena);
+    if (j.reads_only) { b.meta.resize(cap_reads); b.names.resize(cap_names); }
+    uint64_t used = 0, nused = 0; uint32_t nr = 0;
+    const int rc = j.reads_only
+        ? otg_ingest_regions_named(J.bam, J.beds.data() + b.first, J.chr_arena.data(), b.n, &o, b.arena.data(), b.arena.size(), &used, b.reads.data(),
+                                   (uint32_t)b.reads.size(), &nr, b.regions.data(), b.meta.data(), b.names.data(), b.names.size(), &nused)
+        : otg_ingest_regions(J.bam, J.beds.data() + b.first, J.chr_arena.data(), b.n, &o, b.arena.data(), b.arena.size(), &used, b.reads.data(),
+                             (uint32_t)b.reads.size(), &nr, b.regions.data());
+    if (rc == OTG_ERR_CAPACITY) {      // the counters hold the needed totals
+      cap_reads = (size_t)nr + 256; cap_arena = (size_t)used + 4096 + (J.fasta ? (size_t)b.n * 2 * ((size_t)j.params.flank + 8) : 0); cap_names = (size_t)nused + 256;
+      continue;
+    }
+    if (rc != OTG_OK) return rc;
+    b.arena_used = used; b.n_reads = nr;
+    if (J.fasta) {
+      const size_t need = used + (size_t)b.n * 2 * ((size_t)j.params.flank + 8) + 128;
+      if (b.arena.size() < need) b.arena.resize(need);
+      uint64_t u2 = used;
+      const int rf = otg_fasta_region_flanks(J.fasta, J.beds.data() + b.first, J.chr_arena.data(), b.n, o.offset_l, o.offset_r, j.params.flank, b.arena.data(), b.arena.size(),
+                                             &u2, b.regions.data());
+      if (rf != OTG_OK) return rf;
+      b.arena_used = u2;
+    }
+    return OTG_OK;
+  }
+  return OTG_ERR_CAPACITY;
+}
+
+// ---- stage 2 + 3 of one batch on one context: hot path, then the record text
+int run_batch(Job& J, otg_ctx* ctx, Batch& b, std::vector<otg_region_result>& rr, std::vector<otg_allele>& al, std::vector<uint8_t>& seqs, double* ms_gpu, double* ms_emit)
+{
+  const otg_assemble_job& j = *J.j;
+  otg_params P = j.params;
+  P.realign = J.fasta ? 1 : 0;
+  const char* rg = j.read_group ? j.read_group : "";
+  auto t0 = Clock::now();
+  uint64_t need = 0;
+  if (j.reads_only) {
+    // --reads-only: the reads of each region; with -r they are printed after local_realignment trimmed them (src/assemble.cpp:72-89)
+    if (J.fasta && b.n_reads) {
+      int rc = otg_assemble_submit(ctx, &P, b.arena.data(), b.arena_used, b.reads.data(), b.n_reads, b.regions.data(), b.n);
+      if (rc == OTG_OK) rc = otg_assemble_realign(ctx);
+      if (rc == OTG_OK) rc = otg_assemble_collect_reads(ctx, b.reads.data(), b.n_reads);
+      if (rc != OTG_OK) return rc;
+    }
+    *ms_gpu += ms_since(t0);
+    t0 = Clock::now();
+    int rc = otg_emit_reads(J.beds.data() + b.first, J.chr_arena.data(), b.n, b.regions.data(), b.reads.data(), b.arena.data(), b.meta.data(), b.names.data(), rg, j.is_fasta,
+                            P.max_cov, nullptr, 0, &need);
+    if (rc != OTG_OK && rc != OTG_ERR_CAPACITY) return rc;
+    b.text.resize(need);
+    rc = otg_emit_reads(J.beds.data() + b.first, J.chr_arena.data(), b.n, b.regions.data(), b.reads.data(), b.arena.data(), b.meta.data(), b.names.data(), rg, j.is_fasta,
+                        P.max_cov, b.text.empty() ? nullptr : &b.text[0], b.text.size(), &need);
+    *ms_emit += ms_since(t0);
+    return rc;
+  }
+  int rc = otg_assemble_submit(ctx, &P, b.arena.data(), b.arena_used, b.reads.data(), b.n_reads, b.regions.data(), b.n);
+  if (rc == OTG_OK) rc = otg_assemble_run(ctx);
+  uint32_t na = 0; uint64_t sb = 0;
+  if (rc == OTG_OK) rc = otg_assemble_result_sizes(ctx, &na, &sb);
+  if (rc != OTG_OK) return rc;
+  rr.resize(b.n); al.resize((size_t)na + 1); seqs.resize((size_t)sb + 64);
+  rc = otg_assemble_collect(ctx, rr.data(), al.data(), (uint32_t)al.size(), seqs.data(), seqs.size(), nullptr);
+  if (rc != OTG_OK) return rc;
+  *ms_gpu += ms_since(t0);
+  t0 = Clock::now();
+  rc = otg_emit_alleles(J.beds.data() + b.first, J.chr_arena.data(), b.n, rr.data(), al.data(), seqs.data(), rg, j.is_fasta, nullptr, 0, &need);
+  if (rc != OTG_OK && rc != OTG_ERR_CAPACITY) return rc;
+  b.text.resize(need);
+  rc = otg_emit_alleles(J.beds.data() + b.first, J.chr_arena.data(), b.n, rr.data(), al.data(), seqs.data(), rg, j.is_fasta, b.text.empty() ? nullptr : &b.text[0], b.text.size(), &need);
+  *ms_emit += ms_since(t0);
+  {
+    std::lock_guard<std::mutex> lk(J.st_m);
+    J.st.n_alleles += na;
+    for (uint32_t r = 0; r < b.n; ++r) { if (rr[r].n_alleles) ++J.st.n_regions_ok; if (rr[r].status == OTG_REGION_SKIP_MAXCOV) ++J.st.n_regions_skipped; }
+  }
+  return rc;
+}
+
+// ---- one device's shard [a, b): ingest thread -> two hot-path threads -> ordered text
+struct ShardOut {
+  std::mutex m;
+  std::condition_variable cv;
+  std::map<uint32_t, std::string> ready;    // batch index -> text
+  uint32_t n_batches = 0;
+};
+
+void shard_worker(Job& J, int device, uint32_t a, uint32_t bnd, int ingest_threads, ShardOut& out)
+{
+  const uint32_t per = J.j->batch_regions ? J.j->batch_regions : 2048u;
+  BoundedQueue<BatchPtr> q_in(2);
+  double ms_ingest = 0, ms_gpu[2] = {0, 0}, ms_emit[2] = {0, 0};
+  std::thread ingest([&] {
+    try {
+      uint32_t idx = 0;
+      for (uint32_t f = a; f < bnd && J.rc.load() == OTG_OK; f += per, ++idx) {
+        BatchPtr b(new Batch());
+        b->index = idx; b->first = f; b->n = std::min(per, bnd - f);
+        const auto t0 = Clock::now();
+        const int rc = ingest_batch(J, *b, ingest_threads);
+        ms_ingest += ms_since(t0);
+        if (rc != OTG_OK) { J.fail(rc, "ingest: " + last_err()); break; }
+        { std::lock_guard<std::mutex> lk(J.st_m); J.st.n_reads += b->n_reads; J.st.input_bytes += b->arena_used; }
+        if (!q_in.push(std::move(b))) break;
+      }
+    } catch (const std::exception& e) { J.fail(OTG_ERR_ARG, std::string("ingest: ") + e.what()); }
+    q_in.finish();
+  });
+  auto gpu_thread = [&](int slot) {
+    otg_ctx* ctx = nullptr;
+    const bool need_gpu = !J.j->reads_only || J.fasta;
+    if (need_gpu && otg_create(device, &ctx) != OTG_OK) { J.fail(OTG_ERR_NO_DEVICE, "otg_create: " + last_err()); q_in.abort(); return; }
+    std::vector<otg_region_result> rr; std::vector<otg_allele> al; std::vector<uint8_t> seqs;
+    try {
+      BatchPtr b;
+      while (J.rc.load() == OTG_OK && q_in.pop(b)) {
+        const int rc = run_batch(J, ctx, *b, rr, al, seqs, &ms_gpu[slot], &ms_emit[slot]);
+        if (rc != OTG_OK) { J.fail(rc, "hot path: " + (ctx && otg_last_error(ctx) ? std::string(otg_last_error(ctx)) : last_err())); q_in.abort(); break; }
+        { std::lock_guard<std::mutex> lk(out.m); out.ready.emplace(b->index, std::move(b->text)); }
+        out.cv.notify_all();
+      }
+    } catch (const std::exception& e) { J.fail(OTG_ERR_ARG, std::string("hot path: ") + e.what()); }
+    if (J.rc.load() != OTG_OK) q_in.abort();               // whatever stopped the job: release the ingest thread
+    if (ctx) otg_destroy(ctx);
+  };
+  std::thread g0(gpu_thread, 0), g1(gpu_thread, 1);
+  ingest.join(); g0.join(); g1.join();
+  out.cv.notify_all();
+  std::lock_guard<std::mutex> lk(J.st_m);
+  J.st.ms_ingest += ms_ingest; J.st.ms_hot_path += ms_gpu[0] + ms_gpu[1]; J.st.ms_emit += ms_emit[0] + ms_emit[1];
+}
+
+} // namespace
+
+extern "C" {
+
+int otg_assemble_files(const otg_assemble_job* job, otg_write_fn write, void* user, otg_job_stats* stats)
+{
+  if (!job || !write || !job->bam_path || !job->bed_path) return otg_fail(nullptr, OTG_ERR_ARG, "otg_assemble_files: NULL job, writer, BAM or BED path");
+  if (job->n_devices < 0 || (job->n_devices > 0 && !job->devices)) return otg_fail(nullptr, OTG_ERR_ARG, "otg_assemble_files: bad device list");
+  const auto t_all = Clock::now();
+  Job J;
+  J.j = job;
+  // BED file (size protocol: first call reports the needed sizes)
+  {
+    uint32_t n = 0, skipped = 0; uint64_t cu = 0;
+    int rc = otg_parse_bed_file(job->bed_path, nullptr, 0, &n, nullptr, 0, &cu, &skipped);
+    if (rc != OTG_OK && rc != OTG_ERR_CAPACITY) return rc;
+    J.beds.resize((size_t)n + 1); J.chr_arena.resize((size_t)cu + 16);
+    rc = otg_parse_bed_file(job->bed_path, J.beds.data(), (uint32_t)J.beds.size(), &n, J.chr_arena.data(), J.chr_arena.size(), &cu, &skipped);
+    if (rc != OTG_OK) return rc;
+    J.beds.resize(n);
+    J.st.n_regions = n;
+  }
+  int rc = otg_bam_open(job->bam_path, &J.bam);
+  if (rc != OTG_OK) return rc;
+  if (job->fasta_path && job->fasta_path[0]) {
+    rc = otg_fasta_open(job->fasta_path, &J.fasta);
+    if (rc != OTG_OK) { otg_bam_close(J.bam); return rc; }
+  }
+  auto cleanup = [&] { if (J.fasta) otg_fasta_close(J.fasta); otg_bam_close(J.bam); };
+  // SAM header (src/assemble.cpp:167-177); FASTA output has none
+  if (!job->is_fasta) {
+    const uint32_t nt = otg_bam_n_targets(J.bam);
+    std::string names; std::vector<uint64_t> off(nt), len(nt); std::vector<uint32_t> nl(nt);
+    for (uint32_t i = 0; i < nt; ++i) { uint64_t l = 0; const char* nm = otg_bam_target(J.bam, i, &l); off[i] = names.size(); nl[i] = (uint32_t)strlen(nm); len[i] = l; names += nm; }
+    uint64_t need = 0;
+    rc = otg_emit_sam_header(names.data(), off.data(), nl.data(), len.data(), nt, job->read_group ? job->read_group : "", job->ingest.offset_l, job->ingest.offset_r, nullptr, 0, &need);
+    if (rc != OTG_OK && rc != OTG_ERR_CAPACITY) { cleanup(); return rc; }
+    std::string hdr(need, '\0');
+    rc = otg_emit_sam_header(names.data(), off.data(), nl.data(), len.data(), nt, job->read_group ? job->read_group : "", job->ingest.offset_l, job->ingest.offset_r, need ? &hdr[0] : nullptr, need, &need);
+    if (rc != OTG_OK) { cleanup(); return rc; }
+    if (write(user, hdr.data(), hdr.size()) != 0) { cleanup(); return otg_fail(nullptr, OTG_ERR_ARG, "otg_assemble_files: the writer failed"); }
+    J.st.output_bytes += hdr.size();
+  }
+  // static contiguous split over the devices (BS::thread_pool::parallelize_loop: block = total / workers, the last takes the remainder)
+  std::vector<int> devs;
+  if (job->n_devices > 0) devs.assign(job->devices, job->devices + job->n_devices); else devs.push_back(0);
+  const uint32_t R = (uint32_t)J.beds.size(), W = (uint32_t)devs.size();
+  const uint32_t block = R / W;
+  const int threads_total = job->ingest.threads > 0 ? job->ingest.threads : 1;
+  const int threads_per = std::max(1, threads_total / (int)W);
+  std::vector<std::unique_ptr<ShardOut>> outs;
+  std::vector<std::thread> workers;
+  std::vector<std::pair<uint32_t, uint32_t>> bounds;
+  for (uint32_t w = 0; w < W; ++w) {
+    const uint32_t a = block == 0 ? std::min(w, R) : w * block;
+    const uint32_t b = block == 0 ? std::min(w + 1, R) : (w == W - 1 ? R : a + block);
+    bounds.emplace_back(a, b);
+    outs.emplace_back(new ShardOut());
+    const uint32_t per = job->batch_regions ? job->batch_regions : 2048u;
+    outs.back()->n_batches = (b - a + per - 1) / per;
+  }
+  for (uint32_t w = 0; w < W; ++w) workers.emplace_back(shard_worker, std::ref(J), devs[w], bounds[w].first, bounds[w].second, threads_per, std::ref(*outs[w]));
+  // the writer: shards in order, batches in order
+  for (uint32_t w = 0; w < W; ++w) {
+    ShardOut& o = *outs[w];
+    for (uint32_t k = 0; k < o.n_batches; ++k) {
+      std::string text;
+      {
+        std::unique_lock<std::mutex> lk(o.m);
+        o.cv.wait_for(lk, std::chrono::milliseconds(50), [&] { return o.ready.count(k) || J.rc.load() != OTG_OK; });
+        while (!o.ready.count(k) && J.rc.load() == OTG_OK) o.cv.wait_for(lk, std::chrono::milliseconds(50));
+        if (!o.ready.count(k)) break;
+        text = std::move(o.ready[k]);
+        o.ready.erase(k);
+      }
+      if (!text.empty() && write(user, text.data(), text.size()) != 0) { J.fail(OTG_ERR_ARG, "the writer failed"); break; }
+      J.st.output_bytes += text.size();
+    }
+    if (J.rc.load() != OTG_OK) break;
+  }
+  for (auto& t : workers) t.join();
+  cleanup();
+  J.st.ms_total = ms_since(t_all);
+  J.st.n_devices = W;
+  if (stats) *stats = J.st;
+  if (J.rc.load() != OTG_OK) return otg_fail(nullptr, J.rc.load(), "otg_assemble_files: %s", J.err.c_str());
+  return OTG_OK;
+}
+
+} // extern "C"

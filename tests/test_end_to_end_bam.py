@@ -109,3 +109,73 @@ def test_bed_bam_fasta_to_sam_text_all_native_with_realign(gpu, oracle, tmp_path
     ora = oracle.assemble_batch(P, ref_batch)
     assert np.array_equal(res["labels"], ora["labels"])
     assert otter_amd.emit_alleles(beds, carena, res, "s1", False) == oracle.emit_alleles(beds, carena, ora, "s1", False)
+
+
+def _write_bed(path, regions):
+    with open(path, "w") as f:
+        for c, s, e in regions:
+            f.write("%s\t%d\t%d\n" % (c, s, e))
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_dispatcher_files_to_text(gpu, oracle, tmp_path):
+    """The library's dispatcher (otg_assemble_files, the role of assemble() / assemble_process(), src/assemble.cpp:39-179): BED + BAM
+    [+ FASTA] -> SAM / FASTA text in one call, bounded batches flowing through ingest / hot path / emit threads.  The text must not
+    depend on the batch size and must equal the chain the reference's own ingest -> oracle -> oracle emit produces."""
+    import os
+    import subprocess
+    import e2e_bam
+    ds = e2e_bam.make_dataset(str(tmp_path), n_regions=14, seed=71)
+    bam = os.path.join(str(tmp_path), "reads.bam")
+    bed = os.path.join(str(tmp_path), "regions.bed")
+    _write_bed(bed, ds["regions"])
+    beds, carena = abi.make_beds(ds["regions"])
+    hdr = oracle.emit_sam_header([(ds["chrom"], ds["ref_len"])], "s1", 1, 1)
+    for fasta_ref, realign in ((None, 0), (ds["fasta"], 1)):
+        ref_batch = e2e_bam.ingest_with_reference(ds, str(tmp_path), offset_l=1, offset_r=1, mapq=10, flank=100 if realign else 0)
+        ora = oracle.assemble_batch(abi.default_params(realign=realign), ref_batch)
+        for is_fa in (False, True):
+            expect = (b"" if is_fa else hdr) + oracle.emit_alleles(beds, carena, ora, "s1", is_fa)
+            for batch in (3, 5, 0):
+                text, st = otter_amd.assemble_files(bam, bed, fasta=fasta_ref, read_group="s1", is_fasta=is_fa, batch_regions=batch, offset_l=1, offset_r=1,
+                                                    mapq=10, threads=3)
+                assert text == expect, (realign, is_fa, batch)
+                assert st["n_regions"] == len(ds["regions"]) and st["n_alleles"] == len(ora["alleles"]) and st["output_bytes"] == len(text)
+    # the command-line host over the same entry point
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "otter_assemble")
+    if os.path.exists(tool):
+        p = subprocess.run([tool, "-b", bed, "-R", "s1", "-o", "1,1", "-m", "10", "-t", "2", "--batch", "4", "-r", ds["fasta"], bam], capture_output=True, timeout=300)
+        assert p.returncode == 0, p.stderr.decode()[-500:]
+        assert p.stdout == expect_sam_with_ref(hdr, oracle, beds, carena, ora)
+
+
+def expect_sam_with_ref(hdr, oracle, beds, carena, ora):
+    return hdr + oracle.emit_alleles(beds, carena, ora, "s1", False)
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_dispatcher_reads_only(gpu, oracle, tmp_path):
+    """--reads-only through the dispatcher (with and without -r): the read records of otg_ingest_regions_named [+ otg_assemble_realign]
+    + otg_emit_reads, batch by batch, equal to the one-batch chain."""
+    import os
+    import e2e_bam
+    ds = e2e_bam.make_dataset(str(tmp_path), n_regions=9, seed=72)
+    bam = os.path.join(str(tmp_path), "reads.bam")
+    bed = os.path.join(str(tmp_path), "regions.bed")
+    _write_bed(bed, ds["regions"])
+    for fasta_ref in (None, ds["fasta"]):
+        whole, _ = otter_amd.assemble_files(bam, bed, fasta=fasta_ref, read_group="s1", reads_only=True, batch_regions=0, offset_l=1, offset_r=1, mapq=10, threads=2)
+        parts, st = otter_amd.assemble_files(bam, bed, fasta=fasta_ref, read_group="s1", reads_only=True, batch_regions=2, offset_l=1, offset_r=1, mapq=10, threads=2)
+        assert whole == parts and whole.count(b"\n") > 60
+        # against the pieces called by hand
+        b = otter_amd.Bam(bam)
+        batch = b.ingest(ds["regions"], offset_l=1, offset_r=1, mapq=10, names=True)
+        hdr = otter_amd.emit_sam_header(b.targets(), "s1", 1, 1)
+        b.close()
+        beds, carena = abi.make_beds(ds["regions"])
+        if fasta_ref:
+            otter_amd.Fasta(fasta_ref).region_flanks(beds, carena, batch, flank=100, offset_l=1, offset_r=1)
+            batch = dict(batch, reads=gpu.realign_reads(abi.default_params(realign=1), batch))
+        assert whole == hdr + otter_amd.emit_reads(beds, carena, batch, read_group="s1", fasta=False, max_cov=200)
