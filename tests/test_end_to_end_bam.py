@@ -163,6 +163,7 @@ def test_dispatcher_reads_only(gpu, oracle, tmp_path):
     import e2e_bam
     ds = e2e_bam.make_dataset(str(tmp_path), n_regions=9, seed=72)
     bam = os.path.join(str(tmp_path), "reads.bam")
+    assert oracle_lib.ref_io().ref_sam_to_bam(ds["sam"].encode(), bam.encode()) == ds["n_records"]
     bed = os.path.join(str(tmp_path), "regions.bed")
     _write_bed(bed, ds["regions"])
     for fasta_ref in (None, ds["fasta"]):
