@@ -42,6 +42,7 @@ def parse_args():
     ap.add_argument("--regions", type=int, default=None, help="regions per GPU (default: the config's own count; config 4: 100000/8)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU work per cpu_baseline run (3 runs per kind)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--e2e-regions", type=int, default=1000, help="regions of the file-to-text leg (BED + BAM -> SAM text through otg_assemble_files); 0: skip")
     return ap.parse_args()
 
 
@@ -132,6 +133,37 @@ def cpu_baseline(batch, params, seconds, n_threads):
     else:
         out["reference_consensus"] = None
     return out
+
+
+# ------------------------------------------------------------------------------------------------ file-to-text leg
+def e2e_leg(n_regions, threads):
+    """BASELINE.json quotes the metric "on synthetic TR BED+BAM": the same path from files — BED + BAM/BAI -> otg_assemble_files (the library's
+    dispatcher: BAM ingest on host threads, batches through the GPU hot path, SAM text) — on a fixture of configs[1]'s shape written by
+    otter_amd/bamwrite.py.  Ingest-bound on the host; reported beside `value`, never as `value`."""
+    import shutil
+    import tempfile
+    import otter_amd
+    from otter_amd import bamwrite
+    tmp = tempfile.mkdtemp(prefix="otg_e2e_")
+    try:
+        t0 = time.perf_counter()
+        fx = bamwrite.make_tr_fixture(tmp, n_regions, depth=30, len_range=(1000, 5000), seed=7)
+        build_s = time.perf_counter() - t0
+        best = None
+        for _ in range(3):
+            t1 = time.perf_counter()
+            text, st = otter_amd.assemble_files(fx["bam"], fx["bed"], read_group="s1", batch_regions=max(64, n_regions // 8), offset_l=1, offset_r=1, mapq=10, threads=threads)
+            dt = time.perf_counter() - t1
+            if best is None or dt < best[0]:
+                best = (dt, st, len(text))
+        dt, st, nbytes = best
+        return {"regions_per_s": round(n_regions / dt, 1), "regions": n_regions, "reads": int(st["n_reads"]), "alleles": int(st["n_alleles"]), "sam_bytes": nbytes,
+                "bam_bytes": os.path.getsize(fx["bam"]), "host_threads": threads, "batch_regions": max(64, n_regions // 8), "wall_ms": round(dt * 1000.0, 1),
+                "stage_busy_ms": {"ingest": round(st["ms_ingest"], 1), "hot_path": round(st["ms_hot_path"], 1), "emit": round(st["ms_emit"], 1)},
+                "what": "BED file + BAM/BAI -> otg_assemble_files -> SAM text (header + allele records), best of 3; fixture: %d two-allele TR loci x 30 ONT-like reads of "
+                        "1-5 kb written by otter_amd/bamwrite.py in %.0f s" % (n_regions, build_s)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 # ------------------------------------------------------------------------------------------------ one rank
@@ -292,6 +324,12 @@ def run_rank(args):
             out["cpu_baseline"] = cpu_baseline(batch, params, args.cpu_seconds, nth)
         except Exception as e:  # the oracle is only a reported baseline; never fail the bench line on it
             out["cpu_baseline"] = {"value": None, "unit": "regions/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+    if args.e2e_regions > 0 and world == 1:
+        try:
+            ctx.close()                       # the dispatcher creates its own contexts
+            out["e2e"] = e2e_leg(args.e2e_regions, max(1, min(16, os.cpu_count() or 1)))
+        except Exception as e:
+            out["e2e"] = {"error": repr(e)}
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

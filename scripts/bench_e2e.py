@@ -1,7 +1,7 @@
 """File-to-text timing of the `otter assemble` drop-in on one GPU box: BED file + BAM/BAI -> otg_parse_bed_file -> otg_ingest_regions
 (host threads) -> otg_assemble_submit / run / collect (MI355X) -> otg_emit_alleles, with the time of every stage.  The BAM is
 synthetic: tandem-repeat loci with two alleles, ONT-like reads whose CIGARs are written alongside the errors that make them (no
-aligner needed), converted to BAM/BAI by the reference's htslib-lite (oracle/_ref/libotter_ref_io.so, prebuilt).
+aligner needed), written as BAM/BAI by otter_amd/bamwrite.py.
 usage: python scripts/bench_e2e.py [regions=1000] [reads=30] [threads=16]"""
 import os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,7 +9,6 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import otter_amd
 from otter_amd import abi
-import oracle_lib
 
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 D = int(sys.argv[2]) if len(sys.argv) > 2 else 30
@@ -18,89 +17,12 @@ rng = np.random.default_rng(7)
 ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
 
 
-def noisy(seq, rate=0.07):
-    """seq (uint8 array) with substitutions / insertions / deletions at `rate`; returns (read bytes, CIGAR ops as (len, op) list)."""
-    n = len(seq)
-    kind = rng.random(n)
-    out, ops = [], []
-
-    def push(l, o):
-        if ops and ops[-1][1] == o:
-            ops[-1][0] += l
-        else:
-            ops.append([l, o])
-    sub = kind < rate * 0.45
-    ins = (kind >= rate * 0.45) & (kind < rate * 0.72)
-    dele = (kind >= rate * 0.72) & (kind < rate)
-    s2 = seq.copy()
-    s2[sub] = ACGT[rng.integers(0, 4, int(sub.sum()))]
-    i = 0
-    edges = np.flatnonzero(ins | dele)
-    for e in edges:
-        if e > i:
-            out.append(s2[i:e]); push(int(e - i), "M")
-        if ins[e]:
-            k = int(rng.integers(1, 4))
-            out.append(ACGT[rng.integers(0, 4, k)]); push(k, "I")
-            out.append(s2[e:e + 1]); push(1, "M")
-        else:
-            push(1, "D")
-        i = e + 1
-    if i < n:
-        out.append(s2[i:]); push(n - i, "M")
-    return np.concatenate(out) if out else np.zeros(0, np.uint8), ops
-
-
+from otter_amd import bamwrite
 tmp = tempfile.mkdtemp()
 t0 = time.perf_counter()
-ref_parts, regions, recs = [], [], []
-pos = 0
-flank = 1200
-for r in range(R):
-    motif = ACGT[rng.integers(0, 4, int(rng.integers(2, 7)))]
-    L = int(rng.integers(1000, 5000))
-    tr = np.tile(motif, L // len(motif) + 1)[:L]
-    fl, fr = ACGT[rng.integers(0, 4, flank)], ACGT[rng.integers(0, 4, flank)]
-    start = pos + flank
-    ref_parts += [fl, tr, fr]
-    regions.append(("chrS", start, start + L))
-    delta = [0, int(rng.integers(-40, 41)) * len(motif)]          # allele 2 differs by whole copies
-    for d in range(D):
-        a = d % 2
-        lf, rf = int(rng.integers(200, 900)), int(rng.integers(200, 900))
-        body = tr if delta[a] >= 0 else tr[:L + delta[a]]
-        left, ops_l = noisy(fl[flank - lf:])
-        mid, ops_m = noisy(body)
-        right, ops_r = noisy(fr[:rf])
-        ops = ops_l + ops_m
-        extra = np.zeros(0, np.uint8)
-        if delta[a] > 0:
-            extra = np.tile(motif, delta[a] // len(motif))
-            ops = ops + [[len(extra), "I"]]
-        elif delta[a] < 0:
-            ops = ops + [[-delta[a], "D"]]
-        ops = ops + ops_r
-        merged = []
-        for l, o in ops:
-            if merged and merged[-1][1] == o:
-                merged[-1][0] += l
-            else:
-                merged.append([l, o])
-        read = np.concatenate([left, mid, extra, right])
-        recs.append((start - lf, "r%d_%d" % (r, d), "".join("%d%s" % (l, o) for l, o in merged), read.tobytes().decode()))
-    pos += flank + L + flank
-ref_len = pos
-recs.sort(key=lambda x: x[0])
-sam, bam, bed = os.path.join(tmp, "e.sam"), os.path.join(tmp, "e.bam"), os.path.join(tmp, "e.bed")
-with open(sam, "w") as f:
-    f.write("@HD\tVN:1.4\tSO:coordinate\n@SQ\tSN:chrS\tLN:%d\n" % ref_len)
-    for p, nm, cg, sq in recs:
-        f.write("%s\t0\tchrS\t%d\t60\t%s\t*\t0\t0\t%s\t*\n" % (nm, p + 1, cg, sq))
-with open(bed, "w") as f:
-    for c, s, e in regions:
-        f.write("%s\t%d\t%d\n" % (c, s, e))
-n = oracle_lib.ref_io().ref_sam_to_bam(sam.encode(), bam.encode())
-print("fixture: %d regions, %d records, BAM %.1f MB (%.1f s to build)" % (R, n, os.path.getsize(bam) / 1e6, time.perf_counter() - t0), flush=True)
+fx = bamwrite.make_tr_fixture(tmp, R, depth=D, len_range=(1000, 5000), seed=7)
+bam, bed, regions = fx["bam"], fx["bed"], fx["regions"]
+print("fixture: %d regions, %d records, BAM %.1f MB (%.1f s to build)" % (R, fx["n_records"], os.path.getsize(bam) / 1e6, time.perf_counter() - t0), flush=True)
 
 import ctypes as C
 L_ = otter_amd.load()
@@ -165,3 +87,12 @@ for rep in range(2):
         out.append(otter_amd.emit_alleles(sub, carena, rs, "s1", False))
     tot = time.perf_counter() - t0
     print("overlapped, 2 batches of %d: total %.3f s = %.0f regions/s end to end (%d MB of text)" % (half, tot, R / tot, sum(len(x) for x in out) // 1000000), flush=True)
+
+# ---- the library's dispatcher (otg_assemble_files): bounded batches, ingest / hot path / emit on concurrent host threads
+for batch in (R, max(64, R // 4), max(64, R // 8)):
+    for rep in range(2):
+        t0 = time.perf_counter()
+        txt, st = otter_amd.assemble_files(bam, bed, read_group="s1", batch_regions=batch, offset_l=1, offset_r=1, mapq=10, threads=T)
+        tot = time.perf_counter() - t0
+    print("dispatcher, batches of %d: total %.3f s = %.0f regions/s end to end (%d MB of text); stage busy ms: ingest %.0f, hot path %.0f, emit %.0f" % (
+        batch, tot, R / tot, len(txt) // 1000000, st["ms_ingest"], st["ms_hot_path"], st["ms_emit"]), flush=True)

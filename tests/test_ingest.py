@@ -222,3 +222,20 @@ def test_ingest_rejects_corrupt_and_truncated_bam(tmp_path):
         except otter_amd.OtterGpuError:
             n_err += 1
     assert n_err >= 6          # most corruptions are detected (a flipped byte may by chance leave a decodable stream); none crashed
+
+
+@needs_ref
+def test_python_bam_writer_is_read_alike_by_both_readers(tmp_path):
+    """otter_amd/bamwrite.py (the fixture writer of bench.py's end-to-end leg, numpy + zlib, no reference code): the BAM / BAI it writes is
+    read identically by the reference's own reader (htslib-lite + parse_anreads, oracle/_ref) and by the product's reader."""
+    from otter_amd import bamwrite
+    fx = bamwrite.make_tr_fixture(str(tmp_path), 40, depth=12, len_range=(300, 1500), seed=3)
+    regions = fx["regions"] + [("chrS", 0, 50), ("chrS", 100, 100000)]
+    bamh = otter_amd.Bam(fx["bam"])
+    assert bamh.targets()[0][0] == "chrS"
+    for kw in (dict(), dict(offset_l=1, offset_r=1, mapq=10)):
+        ref = _ref_ingest(fx["bam"], regions, **kw)
+        assert ref["regions"]["n_reads"][:40].min() >= 10
+        _same(bamh.ingest(regions, **kw), ref)
+        _same(bamh.ingest(regions, threads=4, **kw), ref)
+    bamh.close()
