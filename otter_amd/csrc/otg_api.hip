@@ -24,7 +24,7 @@ void* otg_slot(otg_ctx* ctx, int slot, size_t bytes)
   DevBuf& b = ctx->pool[slot];
   if (b.cap >= bytes) return b.p;
   if (b.p) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
-  size_t want = bytes + (bytes >> 3) + 256;
+  size_t want = bytes + (bytes >> 2) + 256;            // 25 % headroom: a slightly larger batch must not cost a hipFree + hipMalloc
   hipError_t e = hipMalloc(&b.p, want);
   if (e != hipSuccess) {
     otg_fail(ctx, OTG_ERR_HIP, "hipMalloc(%zu bytes, slot %d) failed: %s", want, slot, hipGetErrorString(e));

@@ -1927,7 +1927,9 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
   // visited-cell counter of the exact tiers (accumulates over the launches of a run; otg_assemble_run zeroes it)
   if (fresh_cnt || !ctx->affine_visited) { ctx->affine_visited = (unsigned long long*)(cnt + 96); HIP_TRY(ctx, hipMemsetAsync(cnt + 96, 0, 8, ctx->stream)); }
 
-  const size_t maxlen = ctx->max_seq_len;
+  // workspace sizes must not follow the batch: every change of size is a hipFree + hipMalloc of gigabytes, and batches of one job differ in
+  // their longest read and their task count — the longest read is rounded up to 4 kb steps and the grids are sized for a full device
+  const size_t maxlen = ((size_t)ctx->max_seq_len + 4095) & ~(size_t)4095;
   AffWs ws;
   ws.capa = (int)(2 * maxlen + 16) & ~1;
   ws.rm = std::max(xs, oes) + 1;
@@ -1944,8 +1946,9 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
 
   size_t free_b = 0, total_b = 0;
   HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
-  free_b += ctx->pool[SLOT_WF_WS].cap;       // what SLOT_WF_WS already holds is reusable
-  const size_t budget = (size_t)(free_b * 0.6);
+  // a fixed share of the device's memory (not of what happens to be free: two contexts share a device in the dispatcher, and a budget that
+  // follows the other context's allocations would resize this workspace batch after batch)
+  const size_t budget = std::min<size_t>((size_t)(total_b * 0.2), (size_t)((free_b + ctx->pool[SLOT_WF_WS].cap) * 0.8));
   // slab sized for ONT-divergence alignments of the batch's longest reads: ~ (0.7 L)^2 provenance bytes
   size_t slab1 = (size_t)(0.5 * (double)maxlen * (double)maxlen) + (1 << 16);
   if (slab1 > ((size_t)96 << 20)) slab1 = (size_t)96 << 20;
@@ -1956,7 +1959,7 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
   };
   // tier A: v3, LDS window 4096 diagonals, 7 single-wave blocks per CU
   constexpr int NWA = 4;                     // waves cooperating on one alignment
-  AffWs wsA = ws; uint32_t wavesA = std::min<uint32_t>((uint32_t)ctx->n_cu * 6, n_tasks); size_t slabA = slab1;   // blocks (one alignment each)
+  AffWs wsA = ws; uint32_t wavesA = (uint32_t)ctx->n_cu * 6; size_t slabA = slab1;   // blocks (one alignment each)
   fit(wavesA, slabA);
   wsA.slab_bytes = slabA & ~(size_t)255; wsA.stride = wsA.off_slab + wsA.slab_bytes;
   // tier B: v3, LDS window 12288 diagonals, 3 blocks per CU
@@ -1980,10 +1983,10 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
     w.slab_bytes = slab & ~(size_t)255; w.stride = w.off_slab + w.slab_bytes;
     return w;
   };
-  uint32_t blocksS = std::min<uint32_t>((uint32_t)ctx->n_cu * 10, n_tasks), blocksM = std::min<uint32_t>((uint32_t)ctx->n_cu * 5, n_tasks);   // resident blocks per CU (LDS / VGPR limits)
-  uint32_t blocksX = std::min<uint32_t>((uint32_t)ctx->n_cu * 7, n_tasks);
-  uint32_t blocksL = std::min<uint32_t>((uint32_t)ctx->n_cu * 2, n_tasks);
-  uint32_t blocksH = std::min<uint32_t>((uint32_t)ctx->n_cu * 3, n_tasks);
+  uint32_t blocksS = (uint32_t)ctx->n_cu * 10, blocksM = (uint32_t)ctx->n_cu * 5;   // resident blocks per CU (LDS / VGPR limits)
+  uint32_t blocksX = (uint32_t)ctx->n_cu * 7;
+  uint32_t blocksL = (uint32_t)ctx->n_cu * 2;
+  uint32_t blocksH = (uint32_t)ctx->n_cu * 3;
   AffWs wsS = lds_ws(1024, blocksS), wsM = lds_ws(2048, blocksM), wsX = lds_ws(1472, blocksX), wsL = lds_ws(4096, blocksL), wsH = lds_ws(3072, blocksH);
   const size_t need = std::max(std::max(std::max(wsA.stride * wavesA, wsB.stride * wavesB), wsC.stride * (size_t)gridC * WPB),
                                std::max(std::max(wsS.stride * blocksS, wsM.stride * blocksM), std::max(std::max(wsX.stride * blocksX, wsH.stride * blocksH), wsL.stride * blocksL)));
@@ -2053,7 +2056,7 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
           w.off_slab = (w.off_rev + ws.rev_cap + 255) & ~(size_t)255;
           w.slab_bytes = ((size_t)cap * (size_t)cap * 7 / 8 + (1 << 16)) & ~(size_t)255;
           w.stride = w.off_slab + w.slab_bytes;
-          blocks = std::min<uint32_t>((uint32_t)ctx->n_cu * blocks_per_cu, (n_tasks + 3) / 4);
+          blocks = (uint32_t)ctx->n_cu * blocks_per_cu;
           return w;
         };
         uint32_t b0, b1, b2;
