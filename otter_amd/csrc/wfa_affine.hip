@@ -1949,26 +1949,28 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
   // a fixed share of the device's memory (not of what happens to be free: two contexts share a device in the dispatcher, and a budget that
   // follows the other context's allocations would resize this workspace batch after batch)
   const size_t budget = std::min<size_t>((size_t)(total_b * 0.2), (size_t)((free_b + ctx->pool[SLOT_WF_WS].cap) * 0.8));
-  // slab sized for ONT-divergence alignments of the batch's longest reads: ~ (0.7 L)^2 provenance bytes
-  size_t slab1 = (size_t)(0.5 * (double)maxlen * (double)maxlen) + (1 << 16);
-  if (slab1 > ((size_t)96 << 20)) slab1 = (size_t)96 << 20;
+  // Provenance slabs of the HBM-row tiers: what a diamond of the tier's window can hold, not more (these tiers take what the LDS tiers
+  // cannot: windows beyond 4096 diagonals, bytes outside ACGT, alignments without a bound).  Workspaces are kept small on purpose: the
+  // first launch on a fresh allocation pays for every gigabyte (2.98 s for 52 GB measured, scripts/cold_probe.py), and the dispatcher
+  // starts fresh contexts per job.
   auto fit = [&](uint32_t& nwaves, size_t& slab) {
     while (nwaves > 1 && (ws.off_slab + slab) * (size_t)nwaves > budget) {
       if (slab > ((size_t)4 << 20)) slab /= 2; else nwaves = (nwaves + 1) / 2;
     }
   };
-  // tier A: v3, LDS window 4096 diagonals, 7 single-wave blocks per CU
+  auto diamond_slab = [&](size_t window) { return std::min<size_t>((size_t)(0.5 * (double)maxlen * (double)maxlen), window * window * 5 / 8) + (1 << 16); };
+  // tier A: v3, LDS window 4096 diagonals
   constexpr int NWA = 4;                     // waves cooperating on one alignment
-  AffWs wsA = ws; uint32_t wavesA = (uint32_t)ctx->n_cu * 6; size_t slabA = slab1;   // blocks (one alignment each)
+  AffWs wsA = ws; uint32_t wavesA = (uint32_t)ctx->n_cu * 2; size_t slabA = diamond_slab(4096);   // blocks (one alignment each)
   fit(wavesA, slabA);
   wsA.slab_bytes = slabA & ~(size_t)255; wsA.stride = wsA.off_slab + wsA.slab_bytes;
-  // tier B: v3, LDS window 12288 diagonals, 3 blocks per CU
-  AffWs wsB = ws; uint32_t wavesB = (uint32_t)ctx->n_cu * 3; size_t slabB = slab1;
+  // tier B: v3, LDS window 12288 diagonals
+  AffWs wsB = ws; uint32_t wavesB = (uint32_t)ctx->n_cu / 2; size_t slabB = diamond_slab(12288);
   fit(wavesB, slabB);
   wsB.slab_bytes = slabB & ~(size_t)255; wsB.stride = wsB.off_slab + wsB.slab_bytes;
-  // tier C: generic kernel (global int32 rings), few waves with the largest useful slabs
+  // tier C: generic kernel (global int32 rings), a few waves with the largest useful slabs
   constexpr int WPB = 4;
-  AffWs wsC = ws; uint32_t gridC = 8;
+  AffWs wsC = ws; uint32_t gridC = 2;
   size_t slabC = std::min<size_t>((size_t)2 * maxlen * (size_t)(ws.nrows), budget / (gridC * WPB));
   if (slabC > ws.off_slab + 256) slabC -= ws.off_slab + 256;
   wsC.slab_bytes = slabC & ~(size_t)255; wsC.stride = wsC.off_slab + wsC.slab_bytes;
@@ -1986,20 +1988,18 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
   uint32_t blocksS = (uint32_t)ctx->n_cu * 10, blocksM = (uint32_t)ctx->n_cu * 5;   // resident blocks per CU (LDS / VGPR limits)
   uint32_t blocksX = (uint32_t)ctx->n_cu * 7;
   uint32_t blocksL = (uint32_t)ctx->n_cu * 2;
-  uint32_t blocksH = (uint32_t)ctx->n_cu * 3;
-  AffWs wsS = lds_ws(1024, blocksS), wsM = lds_ws(2048, blocksM), wsX = lds_ws(1472, blocksX), wsL = lds_ws(4096, blocksL), wsH = lds_ws(3072, blocksH);
+  AffWs wsS = lds_ws(1024, blocksS), wsM = lds_ws(2048, blocksM), wsX = lds_ws(1472, blocksX), wsL = lds_ws(4096, blocksL);
   const size_t need = std::max(std::max(std::max(wsA.stride * wavesA, wsB.stride * wavesB), wsC.stride * (size_t)gridC * WPB),
-                               std::max(std::max(wsS.stride * blocksS, wsM.stride * blocksM), std::max(std::max(wsX.stride * blocksX, wsH.stride * blocksH), wsL.stride * blocksL)));
+                               std::max(std::max(wsS.stride * blocksS, wsM.stride * blocksM), std::max(wsX.stride * blocksX, wsL.stride * blocksL)));
   uint8_t* wsp = (uint8_t*)otg_slot(ctx, SLOT_WF_WS, need);
   if (!wsp) return OTG_ERR_HIP;
-  wsA.base = wsB.base = wsC.base = wsS.base = wsM.base = wsX.base = wsL.base = wsH.base = wsp;
+  wsA.base = wsB.base = wsC.base = wsS.base = wsM.base = wsX.base = wsL.base = wsp;
   uint32_t* listA = todo;                  // overflow of tier A
   uint32_t* listB = todo + n_tasks;        // overflow of tier B
   uint32_t* listS = todo + 2 * (size_t)n_tasks;   // overflow of the LDS tier with 1024 diagonals
   uint32_t* listM = todo + 3 * (size_t)n_tasks;   // ... 2048 diagonals
   uint32_t* listX = todo + 4 * (size_t)n_tasks;   // ... 1472 diagonals
   uint32_t* listL = todo + 5 * (size_t)n_tasks;   // ... 4096 diagonals
-  uint32_t* listH = todo + 7 * (size_t)n_tasks;   // ... 3072 diagonals (shares its slot with the register tiers' overflow list, which is consumed by then)
   static const bool no_v3 = getenv("OTG_NO_AFFINE_V3") != nullptr;
   if (kernel_ms) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   const uint32_t* cur = d_todo; const uint32_t* cur_n = d_n_todo; uint32_t cur_imm = n_tasks;
@@ -2098,13 +2098,7 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
       }
       if (nwm == 4) OTG_V4_LAUNCH(2048, 4, 3072, 5, blocksM, inM, inM_n, 0u, cnt + 26, cnt + 27, listM, wsM);
       else OTG_V4_LAUNCH(2048, 2, 3072, 3, blocksM, inM, inM_n, 0u, cnt + 26, cnt + 27, listM, wsM);
-      // diamonds of up to 3072 diagonals (reads of ~6-9 kb at ONT divergence): six waves per alignment, three alignments per CU
-      static const bool no_h = getenv("OTG_V4_NO_H") != nullptr;
       const uint32_t* outM = listM; const uint32_t* outM_n = cnt + 27;
-      if (!no_h) {
-        OTG_V4_LAUNCH(3072, 6, 5632, 3, blocksH, (const uint32_t*)listM, (const uint32_t*)(cnt + 27), 0u, cnt + 76, cnt + 77, listH, wsH);
-        outM = listH; outM_n = cnt + 77;
-      }
       // diamonds of up to 4096 diagonals: eight waves per alignment, two alignments per CU
       static const bool no_l = getenv("OTG_V4_NO_L") != nullptr;
       if (!no_l) {
