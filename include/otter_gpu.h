@@ -421,6 +421,8 @@ typedef struct otg_job_stats {
 } otg_job_stats;
 typedef int (*otg_write_fn)(void* user, const char* data, uint64_t len);
 int otg_assemble_files(const otg_assemble_job* job, otg_write_fn write, void* user, otg_job_stats* stats);
+/* The dispatcher keeps its per-device contexts (and their HBM workspaces) for the next job of the process; this frees them. */
+void otg_assemble_files_release(void);
 
 #ifdef __cplusplus
 }

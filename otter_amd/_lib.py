@@ -18,7 +18,7 @@ EXPORTS = [
     "otg_bam_open", "otg_bam_close", "otg_bam_n_targets", "otg_bam_target", "otg_ingest_regions",
     "otg_ingest_regions_named", "otg_emit_reads", "otg_parse_bed_file", "otg_fasta_open", "otg_fasta_close", "otg_fasta_n_seqs",
     "otg_fasta_seq", "otg_fasta_fetch", "otg_fasta_region_flanks",
-    "otg_bam_sample_index", "otg_bam_sample", "otg_ingest_alleles", "otg_emit_vcf_header", "otg_emit_vcf_lines", "otg_emit_genotype_lengths", "otg_assemble_files",
+    "otg_bam_sample_index", "otg_bam_sample", "otg_ingest_alleles", "otg_emit_vcf_header", "otg_emit_vcf_lines", "otg_emit_genotype_lengths", "otg_assemble_files", "otg_assemble_files_release",
 ]
 
 _lib = None

@@ -90,6 +90,21 @@ struct Job {
   }
 };
 
+// Contexts survive the job: a fresh context pays for its first launches (page mapping of newly allocated workspaces, ~0.2-1 s), so a process
+// that runs several jobs — or bench.py's repeated file-to-text leg — keeps them in a pool; otg_assemble_files_release() empties it.
+std::mutex g_pool_m;
+std::vector<std::pair<int, otg_ctx*>> g_pool;
+otg_ctx* pool_acquire(int device)
+{
+  {
+    std::lock_guard<std::mutex> lk(g_pool_m);
+    for (size_t i = 0; i < g_pool.size(); ++i) if (g_pool[i].first == device) { otg_ctx* c = g_pool[i].second; g_pool.erase(g_pool.begin() + (long)i); return c; }
+  }
+  otg_ctx* c = nullptr;
+  return otg_create(device, &c) == OTG_OK ? c : nullptr;
+}
+void pool_release(int device, otg_ctx* c) { std::lock_guard<std::mutex> lk(g_pool_m); g_pool.emplace_back(device, c); }
+
 std::string last_err() { const char* e = otg_last_error(nullptr); return e ? std::string(e) : std::string(); }
 
 // ---- stage 1: one batch of regions from the BAM (and the FASTA flanks with -r), buffers grown on OTG_ERR_CAPACITY
@@ -213,7 +228,7 @@ void shard_worker(Job& J, int device, uint32_t a, uint32_t bnd, int ingest_threa
   auto gpu_thread = [&](int slot) {
     otg_ctx* ctx = nullptr;
     const bool need_gpu = !J.j->reads_only || J.fasta;
-    if (need_gpu && otg_create(device, &ctx) != OTG_OK) { J.fail(OTG_ERR_NO_DEVICE, "otg_create: " + last_err()); q_in.abort(); return; }
+    if (need_gpu && !(ctx = pool_acquire(device))) { J.fail(OTG_ERR_NO_DEVICE, "otg_create: " + last_err()); q_in.abort(); return; }
     std::vector<otg_region_result> rr; std::vector<otg_allele> al; std::vector<uint8_t> seqs;
     try {
       BatchPtr b;
@@ -225,7 +240,7 @@ void shard_worker(Job& J, int device, uint32_t a, uint32_t bnd, int ingest_threa
       }
     } catch (const std::exception& e) { J.fail(OTG_ERR_ARG, std::string("hot path: ") + e.what()); }
     if (J.rc.load() != OTG_OK) q_in.abort();               // whatever stopped the job: release the ingest thread
-    if (ctx) otg_destroy(ctx);
+    if (ctx) pool_release(device, ctx);
   };
   std::thread g0(gpu_thread, 0), g1(gpu_thread, 1);
   ingest.join(); g0.join(); g1.join();
@@ -321,6 +336,13 @@ int otg_assemble_files(const otg_assemble_job* job, otg_write_fn write, void* us
   if (stats) *stats = J.st;
   if (J.rc.load() != OTG_OK) return otg_fail(nullptr, J.rc.load(), "otg_assemble_files: %s", J.err.c_str());
   return OTG_OK;
+}
+
+void otg_assemble_files_release(void)
+{
+  std::lock_guard<std::mutex> lk(g_pool_m);
+  for (auto& p : g_pool) otg_destroy(p.second);
+  g_pool.clear();
 }
 
 } // extern "C"

@@ -1958,14 +1958,17 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
       if (slab > ((size_t)4 << 20)) slab /= 2; else nwaves = (nwaves + 1) / 2;
     }
   };
-  auto diamond_slab = [&](size_t window) { return std::min<size_t>((size_t)(0.5 * (double)maxlen * (double)maxlen), window * window * 5 / 8) + (1 << 16); };
+  // a diamond of bound U holds ~U^2 / 2 cells and U stays below ~0.45 x length at ONT divergence: 0.2 x maxlen^2 is twice that; an alignment
+  // that needs more moves on to the next tier
+  auto diamond_slab = [&](size_t window) { return std::min<size_t>((size_t)(0.2 * (double)maxlen * (double)maxlen), window * window * 5 / 8) + (1 << 16); };
   // tier A: v3, LDS window 4096 diagonals
   constexpr int NWA = 4;                     // waves cooperating on one alignment
   AffWs wsA = ws; uint32_t wavesA = (uint32_t)ctx->n_cu * 2; size_t slabA = diamond_slab(4096);   // blocks (one alignment each)
   fit(wavesA, slabA);
   wsA.slab_bytes = slabA & ~(size_t)255; wsA.stride = wsA.off_slab + wsA.slab_bytes;
   // tier B: v3, LDS window 12288 diagonals
-  AffWs wsB = ws; uint32_t wavesB = (uint32_t)ctx->n_cu / 2; size_t slabB = diamond_slab(12288);
+  // (takes the longest reads of a 1-10 kb job, so it gets a full grid when the batch has reads beyond 8 kb)
+  AffWs wsB = ws; uint32_t wavesB = maxlen > 8192 ? (uint32_t)ctx->n_cu * 3 : (uint32_t)ctx->n_cu / 2; size_t slabB = diamond_slab(12288);
   fit(wavesB, slabB);
   wsB.slab_bytes = slabB & ~(size_t)255; wsB.stride = wsB.off_slab + wsB.slab_bytes;
   // tier C: generic kernel (global int32 rings), a few waves with the largest useful slabs
