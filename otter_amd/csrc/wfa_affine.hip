@@ -39,22 +39,49 @@ struct AffWs {
   unsigned long long* visited;   // device counter of visited (score, diagonal) cells, all exact tiers (nullable)
 };
 
+using lds_i16 = __attribute__((address_space(3))) int16_t;
+using lds_u16 = __attribute__((address_space(3))) uint16_t;
+using lds_u32 = __attribute__((address_space(3))) uint32_t;
+using lds_u8 = __attribute__((address_space(3))) uint8_t;
+
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 
-// Walks the provenance back from (s_end, k_end) and unpacks the op string (shared by both forward kernels).
+// Walks the provenance back from (s_end, k_end) and unpacks the op string (shared by every forward kernel).
 // Uniform control flow: every lane follows the same path and stores the same bytes.
+//
+// The walk is a chain of dependent reads (row table entry -> provenance byte -> next row), one HBM round trip per step when read in
+// place.  Instead the wave stages a WINDOW of the provenance in LDS: lane l fetches 32 bytes of row s0 - l around the current diagonal
+// (64 rows in flight at once: two round trips per window), and the walk then reads LDS until it leaves the window — the score drops by
+// 1, 2 or 4 per step and the diagonal moves by at most one, so a window lasts 16-64 steps.  `win` = 2 KB of LDS owned by this wave
+// (the forward kernels hand over state they no longer need).  `eq(v, h)` compares pattern base v with text base h (from LDS where the
+// kernel keeps the sequences there).
+constexpr int BT_ROWS = 64, BT_COLS = 32;
+template <class Eq>
 __device__ bool backtrace_unpack(const uint8_t* P, int pl, const uint8_t* T, int tl, int s_end, int k_end, int xs, int oes, int es,
                                  const int64_t* rowtab, const uint8_t* slab, uint8_t* rev, size_t rev_cap, uint8_t* out, int lane,
-                                 int32_t* score_out, uint32_t* len_out, int g)
+                                 int32_t* score_out, uint32_t* len_out, int g, volatile lds_u32* win, Eq eq)
 {
   uint32_t nrev = 0;
   int k0;
   {
     int s = s_end, k = k_end, comp = 0;
+    int ws0 = -1, wk0 = 0;                       // the staged window: rows ws0 .. ws0 - 63, columns wk0 .. wk0 + 31
+    volatile lds_u8* win8 = (volatile lds_u8*)win;
     while (s > 0 || comp != 0) {
-      const int64_t rb = rowtab[s];
-      const uint32_t bits = slab[rb + k];
+      if (ws0 < 0 || ws0 - s >= BT_ROWS || s > ws0 || k < wk0 || k >= wk0 + BT_COLS) {
+        ws0 = s; wk0 = k - BT_COLS / 2;
+        const int r = ws0 - lane;
+        uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (r >= 0) {
+          const int64_t rb = rowtab[r];
+          if (rb != -1) __builtin_memcpy(w, slab + rb + wk0, 32);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) win[lane * 8 + j] = w[j];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      }
+      const uint32_t bits = win8[(ws0 - s) * BT_COLS + (k - wk0)];
       uint8_t op;
       if (comp == 0) {
         const uint32_t org = bits & 3u;
@@ -88,22 +115,28 @@ __device__ bool backtrace_unpack(const uint8_t* P, int pl, const uint8_t* T, int
       const int rem = imin(pl - v, tl - h);
       if (rem <= 0) break;
       const int n = rem < 64 ? rem : 64;
-      const bool eq = lane < n && P[v + lane] == T[h + lane];
-      const unsigned long long ne = ~__ballot(eq);
+      const bool same = lane < n && eq(v + lane, h + lane);
+      const unsigned long long ne = ~__ballot(same);
       const int m = ne ? (int)__builtin_ctzll(ne) : 64;
       if (lane < m) out[pos + lane] = 'M';
       v += m; h += m; pos += m;
       if (m < 64) break;
     }
   };
+  // the reversed op list is read back 64 ops at a time (one load per chunk instead of one dependent load per op)
   int state = 0;
-  for (int q = (int)nrev - 1; q >= 0; --q) {
-    if (state == 0) emit_matches();
-    const uint8_t op = rev[q];
-    if (op == 'I') { out[pos] = 'I'; ++pos; ++h; state = 1; }
-    else if (op == 'D') { out[pos] = 'D'; ++pos; ++v; state = 2; }
-    else if (op == 'c') { state = 0; }
-    else { out[pos] = 'X'; ++pos; ++v; ++h; }
+  for (int q0 = (int)nrev - 1; q0 >= 0; q0 -= 64) {
+    const int qi = q0 - lane;
+    const int myop = qi >= 0 ? (int)rev[qi] : 0;
+    const int nin = q0 + 1 < 64 ? q0 + 1 : 64;
+    for (int j = 0; j < nin; ++j) {
+      if (state == 0) emit_matches();
+      const int op = __builtin_amdgcn_readlane(myop, j);
+      if (op == 'I') { out[pos] = 'I'; ++pos; ++h; state = 1; }
+      else if (op == 'D') { out[pos] = 'D'; ++pos; ++v; state = 2; }
+      else if (op == 'c') { state = 0; }
+      else { out[pos] = 'X'; ++pos; ++v; ++h; }
+    }
   }
   emit_matches();
   { const int n = tl - h; for (int q = lane; q < n; q += 64) out[pos + q] = 'I'; if (n > 0) { pos += n; h = tl; } }
@@ -112,6 +145,20 @@ __device__ bool backtrace_unpack(const uint8_t* P, int pl, const uint8_t* T, int
   *len_out = pos;
   return true;
 }
+// base comparison straight from the byte sequences in HBM / L2 (kernels that do not keep the pair in LDS)
+struct EqBytes {
+  const uint8_t* P; const uint8_t* T;
+  __device__ __forceinline__ bool operator()(int v, int h) const { return P[v] == T[h]; }
+};
+// base comparison on the 2-bit packed pair in LDS (word q holds bases 16q .. 16q+15; pattern at word 0, text at word offT)
+struct EqPacked {
+  volatile lds_u32* SQ; int offT;
+  __device__ __forceinline__ bool operator()(int v, int h) const
+  {
+    const uint32_t a = (SQ[v >> 4] >> (2 * (v & 15))) & 3u, b = (SQ[offT + (h >> 4)] >> (2 * (h & 15))) & 3u;
+    return a == b;
+  }
+};
 
 template <int WPB>
 __global__ __launch_bounds__(WPB * 64) void wfa_affine_kernel(
@@ -319,7 +366,7 @@ __global__ __launch_bounds__(WPB * 64) void wfa_affine_kernel(
       continue;
     }
 
-    if (!backtrace_unpack(P, pl, T, tl, s_end, k_end, xs, oes, es, rowtab, slab, rev, ws.rev_cap, cig_arena + cig_off[ti], lane, &scores[ti], &cig_len[ti], g)) continue;
+    if (!backtrace_unpack(P, pl, T, tl, s_end, k_end, xs, oes, es, rowtab, slab, rev, ws.rev_cap, cig_arena + cig_off[ti], lane, &scores[ti], &cig_len[ti], g, (volatile lds_u32*)&s_queue[wib][0], EqBytes{P, T})) continue;
     if (cells) cells[ti] = W;
   }
 }
@@ -647,9 +694,6 @@ __global__ __launch_bounds__(256) void wfa_affine_bound1_kernel(
 //   * per 64-diagonal chunk the HBM traffic drops from ~2.1 KB (five int32 row reads, three row writes) to
 //     ~0.7 KB (two dword row reads, one 16-bit row write, 64 provenance bytes).
 // Same provenance bytes, row table, backtrace and unpack as the generic kernel (its last tier).
-using lds_i16 = __attribute__((address_space(3))) int16_t;
-using lds_u16 = __attribute__((address_space(3))) uint16_t;
-using lds_u32 = __attribute__((address_space(3))) uint32_t;
 
 __device__ __forceinline__ int dpp_shr1(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x138, 0xf, 0xf, false); }
 
@@ -964,7 +1008,7 @@ __global__ __launch_bounds__(NW * 64) void wfa_affine_kernel_v3(
       else { scores[ti] = -1; cig_len[ti] = 0; }
       continue;
     }
-    if (!backtrace_unpack(P, pl, T, tl, s_end, k_end, xs, oes, es, rowtab, slab, rev, ws.rev_cap, cig_arena + cig_off[ti], lane, &scores[ti], &cig_len[ti], g)) continue;
+    if (!backtrace_unpack(P, pl, T, tl, s_end, k_end, xs, oes, es, rowtab, slab, rev, ws.rev_cap, cig_arena + cig_off[ti], lane, &scores[ti], &cig_len[ti], g, (volatile lds_u32*)&s_I[0], EqBytes{P, T})) continue;
     if (cells) cells[ti] = affine_cells(t, xs, oes, s_end);
     if (ws.visited && lane == 0) atomicAdd(ws.visited, (unsigned long long)slab_top);
   }
@@ -1323,7 +1367,7 @@ __global__ __launch_bounds__(NW * 64, WPEU) void wfa_affine_kernel_v4(
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");      // provenance bytes of the other waves (same CU, through L2)
     if (ws.dbg & 2) { scores[ti] = s_end * g; cig_len[ti] = 0; continue; }
-    if (!backtrace_unpack(P, pl, T, tl, s_end, k_end, xs, oes, es, rowtab, slab, rev, ws.rev_cap, cig_arena + cig_off[ti], lane, &scores[ti], &cig_len[ti], g)) continue;
+    if (!backtrace_unpack(P, pl, T, tl, s_end, k_end, xs, oes, es, rowtab, slab, rev, ws.rev_cap, cig_arena + cig_off[ti], lane, &scores[ti], &cig_len[ti], g, (volatile lds_u32*)&s_M[0][0], EqPacked{SQ, offT})) continue;
     if (cells) cells[ti] = affine_cells(t, xs, oes, s_end);
     if ((ws.dbg & 1) && threadIdx.x == 0) { atomicAdd(&otg_dbg_v4_cells[0], (unsigned long long)slab_top); atomicAdd(&otg_dbg_v4_cells[1], 1ull); }
     if (ws.visited && threadIdx.x == 0) atomicAdd(ws.visited, (unsigned long long)slab_top);
@@ -1744,7 +1788,7 @@ __global__ __launch_bounds__(256, WPEU) void wfa_affine_kernel_v5(
       continue;
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
-    if (!backtrace_unpack(P, pl, T, tl, s_end, k_end, xs, oes, es, rowtab, slab, rev, ws.rev_cap, cig_arena + cig_off[ti], lane, &scores[ti], &cig_len[ti], g)) continue;
+    if (!backtrace_unpack(P, pl, T, tl, s_end, k_end, xs, oes, es, rowtab, slab, rev, ws.rev_cap, cig_arena + cig_off[ti], lane, &scores[ti], &cig_len[ti], g, (volatile lds_u32*)&s_queue[wv][0], EqPacked{(volatile lds_u32*)&s_seq[wv][0], offT})) continue;
     if (cells) cells[ti] = affine_cells(t, xs, oes, s_end);
     if (visited && lane == 0) atomicAdd(visited, (unsigned long long)slab_top);
   }
