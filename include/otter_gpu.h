@@ -346,6 +346,20 @@ int  otg_fasta_region_flanks(const otg_fasta* fa, const otg_bed* beds, const cha
                              int32_t offset_l, int32_t offset_r, int32_t flank, uint8_t* arena, uint64_t arena_capacity,
                              uint64_t* arena_used, otg_region* regions);
 
+/* A sink for record text: called with consecutive pieces of the output; a non-zero return aborts the call. */
+typedef int (*otg_write_fn)(void* user, const char* data, uint64_t len);
+
+/* ---------------------------------------------------------------------------------------------
+ * `otter wgat`: the BED regions sliced out of whole-genome assembly alignments, as allele records `otter genotype`
+ * reads — wgat() / wga_bam_genotyper_process (src/wgat.cpp:31-179) with get_op_intervals (src/opinterval.cpp:12-34).  Host code.
+ * Per BAM target in header order, per alignment in file order, per overlapping region in the order the reference's interval tree reports
+ * them: the query interval under [start - offset_l, end + offset_r] from the CIGAR operations that overlap it; alignments clipped inside
+ * the interval are skipped (the reference's warning).  Record lines as ANALLELE::stdout_sam / stdout_fa print them (name
+ * `contig#chr:start-end_index`, tc / ac / sc = 1, sp:A:b); SAM output starts with the @SQ / @RG / @PG OF: lines.  Order = the reference's
+ * with -t 1.  *n_records (nullable) = records written. */
+int otg_wgat(otg_bam* bam, const otg_bed* beds, const char* chr_arena, uint32_t n_beds, const char* read_group, int is_fasta,
+             int32_t offset_l, int32_t offset_r, otg_write_fn write, void* user, uint64_t* n_records);
+
 /* Workload statistics of the last otg_assemble_run (for the roofline figure). */
 typedef struct otg_run_stats {
   uint64_t n_regions, n_regions_ok;
@@ -419,7 +433,7 @@ typedef struct otg_job_stats {
   double   ms_total;             /* wall                                                             */
   double   ms_ingest, ms_hot_path, ms_emit;   /* busy time of the three stages, summed over their threads (they overlap) */
 } otg_job_stats;
-typedef int (*otg_write_fn)(void* user, const char* data, uint64_t len);
+/* (otg_write_fn is declared above, with otg_wgat) */
 int otg_assemble_files(const otg_assemble_job* job, otg_write_fn write, void* user, otg_job_stats* stats);
 /* The dispatcher keeps its per-device contexts (and their HBM workspaces) for the next job of the process; this frees them. */
 void otg_assemble_files_release(void);

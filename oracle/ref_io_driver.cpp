@@ -13,6 +13,7 @@
 #include "anfahelper.hpp"
 #include "anbamdb.hpp"
 #include "otter_opts.hpp"
+#include "wgat.hpp"
 #include "sam.h"
 #include "faidx.h"
 #include <vector>
@@ -217,6 +218,25 @@ int64_t ref_ingest_alleles(void* hnd, const char* bam_path, const char* chr, uin
   }
   *arena_used = used;
   return (int64_t)block.size();
+}
+
+// `otter wgat` (src/wgat.cpp:157-179) as the reference runs it with -t 1: stdout captured (warnings on stderr dropped).
+uint64_t ref_wgat(const char* bam, const char* bed, const char* read_group, int is_fasta, int offset_l, int offset_r, char* out, uint64_t cap)
+{
+  OtterOpts params;
+  params.read_group = read_group ? read_group : "";
+  params.is_fa = is_fasta != 0;
+  params.offset_l = (uint32_t)offset_l; params.offset_r = (uint32_t)offset_r;
+  params.threads = 1;
+  std::ostringstream os, sink;
+  std::streambuf* old = std::cout.rdbuf(os.rdbuf());
+  std::streambuf* olde = std::cerr.rdbuf(sink.rdbuf());
+  wgat(params, bam, bed);
+  std::cout.rdbuf(old);
+  std::cerr.rdbuf(olde);
+  const std::string t = os.str();
+  if (out && t.size() <= cap) memcpy(out, t.data(), t.size());
+  return t.size();
 }
 
 } // extern "C"

@@ -18,7 +18,7 @@ EXPORTS = [
     "otg_bam_open", "otg_bam_close", "otg_bam_n_targets", "otg_bam_target", "otg_ingest_regions",
     "otg_ingest_regions_named", "otg_emit_reads", "otg_parse_bed_file", "otg_fasta_open", "otg_fasta_close", "otg_fasta_n_seqs",
     "otg_fasta_seq", "otg_fasta_fetch", "otg_fasta_region_flanks",
-    "otg_bam_sample_index", "otg_bam_sample", "otg_ingest_alleles", "otg_emit_vcf_header", "otg_emit_vcf_lines", "otg_emit_genotype_lengths", "otg_assemble_files", "otg_assemble_files_release",
+    "otg_bam_sample_index", "otg_bam_sample", "otg_ingest_alleles", "otg_emit_vcf_header", "otg_emit_vcf_lines", "otg_emit_genotype_lengths", "otg_assemble_files", "otg_assemble_files_release", "otg_wgat",
 ]
 
 _lib = None
@@ -548,3 +548,21 @@ def assemble_files(bam, bed, fasta=None, read_group="", is_fasta=False, reads_on
     if rc != 0:
         raise OtterGpuError("otg_assemble_files failed (%d): %s" % (rc, (L.otg_last_error(None) or b"").decode()))
     return b"".join(chunks), {k: getattr(st, k) for k, _ in abi.JobStats._fields_}
+
+
+def wgat(bam, regions, read_group="", fasta=False, offset_l=1, offset_r=0):
+    """otg_wgat: `otter wgat` on an open Bam handle; regions = list of (chr, start, end) or the (beds, chr_arena) pair.  Returns the text."""
+    L = load()
+    beds, carena = regions if isinstance(regions, tuple) else abi.make_beds(regions)
+    chunks = []
+
+    def sink(_user, data, n):
+        chunks.append(C.string_at(data, n))
+        return 0
+    cb = abi.WRITE_FN(sink)
+    nrec = C.c_uint64(0)
+    L.otg_wgat.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_uint32, C.c_char_p, C.c_int, C.c_int32, C.c_int32, abi.WRITE_FN, C.c_void_p, C.POINTER(C.c_uint64)]
+    rc = L.otg_wgat(bam._h, abi.ptr(beds), abi.ptr(carena, C.c_char_p), C.c_uint32(len(beds)), read_group.encode(), int(fasta), offset_l, offset_r, cb, None, C.byref(nrec))
+    if rc != 0:
+        raise OtterGpuError("otg_wgat failed (%d): %s" % (rc, _err(L)))
+    return b"".join(chunks), int(nrec.value)

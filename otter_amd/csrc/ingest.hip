@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <string>
 #include <thread>
+#include <memory>
 #include <unordered_map>
 #include <vector>
 
@@ -781,3 +782,183 @@ int otg_ingest_alleles(otg_bam* b, const otg_bed* beds, const char* chr_arena, u
 }
 
 } // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// `otter wgat`: slice the BED regions out of whole-genome assembly alignments — wga_bam_genotyper_process
+// (src/wgat.cpp:31-124) with get_op_intervals (src/opinterval.cpp:12-34).  Host code, no device work.
+//
+// The reference finds overlaps with the interval tree vendored in its src/interval_tree.h (E. Garrison's intervaltree, MIT licence:
+// "Copyright (c) 2011 Erik Garrison").  The ORDER in which that tree reports overlaps decides the order of the emitted records and, through an
+// unstable std::sort on equal (start, stop) keys, which CIGAR operation counts as the first of a region — so the tree's construction
+// (centre = (min start + max stop) / 2, leaf buckets below 64 intervals, depth 16) and visit order (node, left, right) are restated
+// here; std::sort is libstdc++'s on both sides.
+namespace {
+
+struct Iv { int start, stop, value; };
+
+struct ITree {
+  std::vector<Iv> ivs;
+  std::unique_ptr<ITree> left, right;
+  int center = 0;
+  ITree() = default;
+  ITree(std::vector<Iv>&& v, size_t depth = 16, size_t minbucket = 64, size_t maxbucket = 512, int leftextent = 0, int rightextent = 0)
+  {
+    --depth;
+    auto by_start = [](const Iv& a, const Iv& b) { return a.start < b.start; };
+    auto by_stop = [](const Iv& a, const Iv& b) { return a.stop < b.stop; };
+    if (!v.empty()) {
+      const auto mm_stop = std::minmax_element(v.begin(), v.end(), by_stop);
+      const auto mm_start = std::minmax_element(v.begin(), v.end(), by_start);
+      center = (mm_start.first->start + mm_stop.second->stop) / 2;
+    }
+    if (leftextent == 0 && rightextent == 0) std::sort(v.begin(), v.end(), by_start);
+    if (depth == 0 || (v.size() < minbucket && v.size() < maxbucket)) {
+      std::sort(v.begin(), v.end(), by_start);
+      ivs = std::move(v);
+      return;
+    }
+    int leftp, rightp;
+    if (leftextent || rightextent) { leftp = leftextent; rightp = rightextent; }
+    else { leftp = v.front().start; rightp = std::max_element(v.begin(), v.end(), by_stop)->stop; }
+    std::vector<Iv> lefts, rights;
+    for (const Iv& x : v) {
+      if (x.stop < center) lefts.push_back(x);
+      else if (x.start > center) rights.push_back(x);
+      else ivs.push_back(x);
+    }
+    if (!lefts.empty()) left.reset(new ITree(std::move(lefts), depth, minbucket, maxbucket, leftp, center));
+    if (!rights.empty()) right.reset(new ITree(std::move(rights), depth, minbucket, maxbucket, center, rightp));
+  }
+  void overlapping(int start, int stop, std::vector<Iv>& out) const
+  {
+    if (!ivs.empty() && !(stop < ivs.front().start)) for (const Iv& x : ivs) if (x.stop >= start && x.start <= stop) out.push_back(x);
+    if (left && start <= center) left->overlapping(start, stop, out);
+    if (right && stop >= center) right->overlapping(start, stop, out);
+  }
+};
+
+struct SinkW {            // buffered writer over the caller's callback
+  otg_write_fn write; void* user; std::string buf; bool failed = false; uint64_t total = 0;
+  void put(const std::string& s) { buf += s; if (buf.size() > (1u << 20)) flush(); }
+  void flush() { if (!buf.empty() && !failed) { if (write(user, buf.data(), buf.size()) != 0) failed = true; total += buf.size(); } buf.clear(); }
+};
+
+} // namespace
+
+extern "C" int otg_wgat(otg_bam* b, const otg_bed* beds, const char* chr_arena, uint32_t n_beds, const char* read_group, int is_fasta,
+                        int32_t offset_l, int32_t offset_r, otg_write_fn write, void* user, uint64_t* n_records)
+{
+  if (!b || (n_beds && (!beds || !chr_arena)) || !write) return otg_fail(nullptr, OTG_ERR_ARG, "otg_wgat: null argument");
+  const std::string rg = read_group ? read_group : "";
+  SinkW out{write, user};
+  if (!is_fasta) {        // src/wgat.cpp:166-174
+    for (size_t i = 0; i < b->names.size(); ++i) out.put("@SQ\tSN:" + b->names[i] + "\tLN:" + std::to_string(b->lengths[i]) + "\n");
+    out.put("@RG\tID:" + rg + "\n");
+    out.put("@PG\tID:otter\tOF:" + std::to_string((uint32_t)offset_l) + "," + std::to_string((uint32_t)offset_r) + "\n");
+  }
+  // construct_bed_interval_tree (src/wgat.cpp:19-29): every region of every chromosome in ONE tree, extended by the offsets (uint32 arithmetic)
+  std::vector<Iv> bed_iv;
+  std::vector<std::string> bed_chr(n_beds), bed_sc(n_beds);
+  for (uint32_t i = 0; i < n_beds; ++i) {
+    const int start = (int)((uint32_t)beds[i].start - (uint32_t)offset_l), end = (int)((uint32_t)beds[i].end + (uint32_t)offset_r);
+    bed_iv.push_back({std::min(start, end), std::max(start, end), (int)i});
+    bed_chr[i].assign(chr_arena + beds[i].chr_off, beds[i].chr_len);
+    bed_sc[i] = bed_chr[i] + ":" + std::to_string((uint32_t)beds[i].start) + "-" + std::to_string((uint32_t)beds[i].end);       // BED::toScString
+  }
+  const ITree bed_tree(std::move(bed_iv));
+  static const char nt16[] = "=ACMGRSVTWYHKDBN";
+  otg_bam local;
+  if (!local.fp.open(b->path.c_str())) return otg_fail(nullptr, OTG_ERR_ARG, "otg_wgat: cannot reopen %s", b->path.c_str());
+  std::vector<uint32_t> bins;
+  std::vector<std::pair<uint64_t, uint64_t>> chunks;
+  std::string err;
+  uint64_t nrec = 0;
+  int rc_all = OTG_OK;
+  for (size_t tid = 0; tid < b->names.size() && rc_all == OTG_OK; ++tid) {
+    int alignment_index = 0;
+    std::vector<Iv> hits, ops_hit;
+    // bam_itr_querys("chr:1-len"): every alignment that overlaps [0, len)
+    const int rc = scan_region(b, local, (int)tid, 0, (long long)b->lengths[tid], bins, chunks, err, [&](const Rec& r) {
+      if (r.l_seq <= 0) return;
+      const uint8_t* cg = (const uint8_t*)r.cigar;
+      const int ref_end = r.pos + cigar_rlen(r);
+      hits.clear();
+      bed_tree.overlapping(r.pos, ref_end, hits);
+      size_t keep = 0;
+      for (const Iv& h : hits) if (bed_chr[(size_t)h.value] == b->names[tid]) hits[keep++] = h;
+      hits.resize(keep);
+      if (!hits.empty()) {
+        const std::string name(r.name, r.l_name);
+        // get_op_intervals (src/opinterval.cpp:12-34): one reference / query interval per CIGAR operation
+        std::vector<Iv> op_iv; std::vector<int> q_start, q_end, q_op;
+        int rpos = r.pos, qpos = 0;
+        for (uint32_t i = 0; i < r.n_cigar; ++i) {
+          const int op = cig_op(cg, i), ol = cig_len(cg, i);
+          int rn = rpos, qn = qpos;
+          if (op == 4) qn += ol;
+          else if (op == 0 || op == 7 || op == 8) { rn += ol; qn += ol; }
+          else if (op == 1) qn += ol;
+          else if (op == 2) rn += ol;
+          op_iv.push_back({rpos, rn, (int)i}); q_start.push_back(qpos); q_end.push_back(qn); q_op.push_back(op);
+          rpos = rn; qpos = qn;
+        }
+        const ITree op_tree(std::move(op_iv));
+        for (const Iv& ov : hits) {
+          ops_hit.clear();
+          op_tree.overlapping(ov.start, ov.stop, ops_hit);
+          std::sort(ops_hit.begin(), ops_hit.end(), [](const Iv& x, const Iv& y) { if (x.start == y.start) return x.stop < y.stop; else return x.start < y.start; });
+          bool clipped_l = false, clipped_r = false;
+          int query_start = 0, query_end = 0;
+          for (int i = 0; i < (int)ops_hit.size(); ++i) {
+            const Iv& o = ops_hit[(size_t)i];
+            const int qs = q_start[(size_t)o.value], qe = q_end[(size_t)o.value], op = q_op[(size_t)o.value];
+            if (op == 4 || op == 5) {
+              if (i == 0) { clipped_l = true; query_start = qe; }
+              else { clipped_r = true; query_end = qs; }
+            } else {
+              if (i == 0) {
+                if (op == 2) { if (o.start <= ov.start && o.stop >= ov.stop) break; else query_start = qs; }
+                else query_start = qs + (ov.start - o.start);
+              }
+              if (i + 1 == (int)ops_hit.size()) {
+                if (op == 2) query_end = qe;
+                else query_end = qe - (o.stop - ov.stop);
+              }
+            }
+          }
+          if (clipped_l || clipped_r) continue;            // "[WARNING] skipping non-spanning whole-genome alignment"
+          const long long len = (long long)query_end - query_start;
+          // An alignment that begins or ends INSIDE the interval without a clip gives the reference a query interval outside the sequence
+          // (negative start / end past l_seq): it then reads bytes before or behind the packed sequence — undefined output.  Such an alignment
+          // does not span the region; it is skipped here like the clipped ones.
+          if (len < 0 || query_start < 0 || query_end > r.l_seq) continue;
+          std::string seq((size_t)(len == 0 ? 1 : len), 'N');
+          for (int i = query_start; i < query_end; ++i) seq[(size_t)(i - query_start)] = nt16[(r.seq[i >> 1] >> ((~i & 1) << 2)) & 0xf];
+          const otg_bed& lb = beds[(size_t)ov.value];
+          const std::string& sc = bed_sc[(size_t)ov.value];
+          std::string line;
+          if (is_fasta) {
+            // stdout_fa(read_group, name#region#index, is_read, 1, 1): tc / ac / sc = 1, sp:A:b (src/anseqs.cpp:58-64)
+            line = ">" + rg + "#" + name + "#" + sc + "#" + std::to_string(alignment_index) + "#tc:i:1#ac:i:1#sc:i:1#sp:A:b\n" + seq + "\n";
+          } else {
+            const std::string chr = bed_chr[(size_t)ov.value];
+            line = name + "#" + sc + "_" + std::to_string(alignment_index) + "\t0\t" + chr + "\t" + std::to_string(lb.start) + "\t0\t" + std::to_string(seq.size()) + "M\t*\t0\t0\t" +
+                   seq + "\t" + std::string(seq.size(), '!');
+            if (!rg.empty()) line += "\tRG:Z:" + rg;
+            line += "\tta:Z:" + chr + ":" + std::to_string(lb.start) + "-" + std::to_string(lb.end) + "\ttc:i:1\tac:i:1\tsc:i:1\tsp:A:b\tic:i:1\tse:f:0\n";
+          }
+          out.put(line);
+          ++nrec;
+        }
+      }
+      ++alignment_index;
+    });
+    if (rc != OTG_OK) { rc_all = rc; break; }
+  }
+  local.fp.close();
+  out.flush();
+  if (n_records) *n_records = nrec;
+  if (rc_all != OTG_OK) return otg_fail(nullptr, rc_all, "otg_wgat: %s", err.c_str());
+  if (out.failed) return otg_fail(nullptr, OTG_ERR_ARG, "otg_wgat: the writer failed");
+  return OTG_OK;
+}
