@@ -198,6 +198,24 @@ struct Lds {
   double b0, b1, bc, dist_final, bandwidth;
 };
 
+// ---- The two functions below (cutree_k_dev, nn_chain_average) restate, operation for operation, the tree cutting and the NN-chain
+// average-linkage core of the vendored hclust-cpp / fastcluster the reference links (include/hclust-cpp/fastcluster.cpp:33-81,
+// fastcluster_dm.hpp:563-766): merge order, tie-breaks and the floating-point evaluation order of `s*a + t*b` decide the labels, so the
+// order of operations is kept.  That code carries this notice (BSD 2-clause, include/hclust-cpp/LICENSE):
+//
+//   fastcluster: Fast hierarchical clustering routines for R and Python.  Copyright (c) 2011 Daniel Müllner <http://danifold.net>.
+//   C++ standalone version (hclust-cpp): Copyright Christoph Dalitz, 2020; Daniel Müllner, 2011.  All rights reserved.
+//
+//   Redistribution and use in source and binary forms, with or without modification, are permitted provided that the following
+//   conditions are met: (1) redistributions of source code must retain the above copyright notice, this list of conditions and the
+//   following disclaimer; (2) redistributions in binary form must reproduce the above copyright notice, this list of conditions and the
+//   following disclaimer in the documentation and/or other materials provided with the distribution.
+//   THIS SOFTWARE IS PROVIDED BY THE COPYRIGHT HOLDERS AND CONTRIBUTORS "AS IS" AND ANY EXPRESS OR IMPLIED WARRANTIES, INCLUDING, BUT NOT
+//   LIMITED TO, THE IMPLIED WARRANTIES OF MERCHANTABILITY AND FITNESS FOR A PARTICULAR PURPOSE ARE DISCLAIMED.  IN NO EVENT SHALL THE
+//   COPYRIGHT HOLDER OR CONTRIBUTORS BE LIABLE FOR ANY DIRECT, INDIRECT, INCIDENTAL, SPECIAL, EXEMPLARY, OR CONSEQUENTIAL DAMAGES
+//   (INCLUDING, BUT NOT LIMITED TO, PROCUREMENT OF SUBSTITUTE GOODS OR SERVICES; LOSS OF USE, DATA, OR PROFITS; OR BUSINESS INTERRUPTION)
+//   HOWEVER CAUSED AND ON ANY THEORY OF LIABILITY, WHETHER IN CONTRACT, STRICT LIABILITY, OR TORT (INCLUDING NEGLIGENCE OR OTHERWISE)
+//   ARISING IN ANY WAY OUT OF THE USE OF THIS SOFTWARE, EVEN IF ADVISED OF THE POSSIBILITY OF SUCH DAMAGE.
 __device__ void cutree_k_dev(int n, const int* merge, int nclust, int* labels, int* last_merge, int* z)
 {
   if (nclust > n || nclust < 2) { for (int j = 0; j < n; j++) labels[j] = 0; return; }
