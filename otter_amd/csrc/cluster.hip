@@ -242,23 +242,52 @@ __device__ void cutree_k_dev(int n, const int* merge, int nclust, int* labels, i
   }
 }
 
-__device__ void nn_chain_average(int N, double* D, Lds& L)
+// NN-chain average linkage run by ONE WAVE (64 lanes, uniform control flow; called by wave 0 of the block).  The chain logic is the
+// reference's (restart when the chain tip is <= 3, merged cluster keeps the larger index, sizes as doubles); the three O(V) loops of every
+// step — nearest neighbour of the chain tip, and the distance update `s*a + t*b` — run across the lanes: lane l owns the indices l, l + 64,
+// ...  A nearest-neighbour search is a min-reduction over (distance, index) with ties to the LOWEST index, which is what the reference's
+// ascending strict-'<' scan returns (fastcluster_dm.hpp:612-640); the incumbent keeps its place on a tie, as there.  Same doubles, same
+// comparisons, same update expression per element => same merges.  L.pred doubles as the active flag here.
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+__device__ __forceinline__ double wave_min_f64(double v)
+{
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(v, off); v = o < v ? o : v; }
+  return v;
+}
+__device__ __forceinline__ int wave_min_i32(int v)
+{
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(v, off); v = o < v ? o : v; }
+  return v;
+}
+__device__ void nn_chain_average(int N, double* D, Lds& L, int lane)
 {
 #define D_(r_, c_) (D[didx(N, (r_), (c_))])
-  int start = 0;
-  for (int i = 0; i < N; ++i) { L.pred[i + 1] = i; L.succ[i] = i + 1; L.members[i] = 1.0; }
-  int tip = 0, idx1 = 0, idx2 = 0, i;
+  constexpr double INF = 1.0e300;
+  int* act = L.pred;                                  // 1 = still a cluster of its own
+  for (int i = lane; i < N; i += 64) { act[i] = 1; L.members[i] = 1.0; }
+  wave_sync();
+  // lowest-index nearest neighbour of node `a` among the active nodes i with i > lo_excl, i != a; (INF, N) when there is none
+  auto nearest = [&](int a, int lo_excl, double& dmin, int& imin) {
+    double bd = INF; int bi = N;
+    for (int i = lane; i < N; i += 64) {
+      if (i > lo_excl && i != a && act[i]) {
+        const double d = i < a ? D_(i, a) : D_(a, i);
+        if (d < bd) { bd = d; bi = i; }                 // ascending per lane: keeps the lane's lowest index
+      }
+    }
+    dmin = wave_min_f64(bd);
+    imin = wave_min_i32(bd == dmin ? bi : N);
+  };
+  int start = 0, tip = 0, idx1 = 0, idx2 = 0;
   double mn = 0;
   for (int j = 0; j < N - 1; ++j) {
     if (tip <= 3) {
-      L.nn_chain[0] = idx1 = start;
+      if (lane == 0) L.nn_chain[0] = start;
+      idx1 = start;
       tip = 1;
-      idx2 = L.succ[idx1];
-      mn = D_(idx1, idx2);
-      for (i = L.succ[idx2]; i < N; i = L.succ[i]) {
-        double d = D_(idx1, i);
-        if (d < mn) { mn = d; idx2 = i; }
-      }
+      nearest(idx1, idx1, mn, idx2);                    // first strict minimum over the active nodes after `start`
     } else {
       tip -= 3;
       idx1 = L.nn_chain[tip - 1];
@@ -266,40 +295,39 @@ __device__ void nn_chain_average(int N, double* D, Lds& L)
       mn = idx1 < idx2 ? D_(idx1, idx2) : D_(idx2, idx1);
     }
     do {
-      L.nn_chain[tip] = idx2;
-      for (i = start; i < idx2; i = L.succ[i]) {
-        double d = D_(i, idx2);
-        if (d < mn) { mn = d; idx1 = i; }
-      }
-      for (i = L.succ[idx2]; i < N; i = L.succ[i]) {
-        double d = D_(idx2, i);
-        if (d < mn) { mn = d; idx1 = i; }
-      }
+      if (lane == 0) L.nn_chain[tip] = idx2;
+      wave_sync();
+      double dm; int im;
+      nearest(idx2, -1, dm, im);                        // over every active node but idx2; the incumbent idx1 stays on a tie
+      if (dm < mn) { mn = dm; idx1 = im; }
       idx2 = idx1;
       idx1 = L.nn_chain[tip++];
     } while (idx2 != L.nn_chain[tip - 2]);
-    L.z1[j] = idx1; L.z2[j] = idx2; L.zdist[j] = mn;
-    if (idx1 > idx2) { int t = idx1; idx1 = idx2; idx2 = t; }
+    if (lane == 0) { L.z1[j] = idx1; L.z2[j] = idx2; L.zdist[j] = mn; }
+    if (idx1 > idx2) { const int t = idx1; idx1 = idx2; idx2 = t; }
     const double size1 = L.members[idx1], size2 = L.members[idx2];
-    L.members[idx2] += L.members[idx1];
-    // active_nodes.remove(idx1)
-    if (idx1 == start) start = L.succ[idx1];
-    else { L.succ[L.pred[idx1]] = L.succ[idx1]; L.pred[L.succ[idx1]] = L.pred[idx1]; }
-    L.succ[idx1] = 0;
+    wave_sync();
+    if (lane == 0) { L.members[idx2] = size2 + size1; act[idx1] = 0; }
+    wave_sync();
+    if (idx1 == start) { int c = N; for (int i = lane; i < N; i += 64) if (act[i] && i < c) c = i; start = wave_min_i32(c); }
     const double s = size1 / (size1 + size2), t = size2 / (size1 + size2);
-    for (i = start; i < idx1; i = L.succ[i]) D_(i, idx2) = s * D_(i, idx1) + t * D_(i, idx2);
-    for (; i < idx2; i = L.succ[i]) D_(i, idx2) = s * D_(idx1, i) + t * D_(i, idx2);
-    for (i = L.succ[idx2]; i < N; i = L.succ[i]) D_(idx2, i) = s * D_(idx1, i) + t * D_(idx2, i);
+    for (int i = lane; i < N; i += 64) {
+      if (!act[i] || i == idx2) continue;
+      if (i < idx1) D_(i, idx2) = s * D_(i, idx1) + t * D_(i, idx2);
+      else if (i < idx2) D_(i, idx2) = s * D_(idx1, i) + t * D_(i, idx2);
+      else D_(idx2, i) = s * D_(idx1, i) + t * D_(idx2, i);
+    }
+    wave_sync();
   }
 #undef D_
 }
 
-// hclust_fast(AVERAGE): NN-chain (thread 0) + generate_R_dendrogram<false> (stable sort by height = rank by
+// hclust_fast(AVERAGE): NN-chain (wave 0) + generate_R_dendrogram<false> (stable sort by height = rank by
 // (dist, position), computed in parallel; union-find relabel by thread 0).  Block-cooperative: call from all
 // threads.  Leaves L.merge (R convention, column-major) and L.height.
 __device__ void hclust_to_merge(int n, double* D, Lds& L, int tid)
 {
-  if (tid == 0) nn_chain_average(n, D, L);
+  if (tid < 64) nn_chain_average(n, D, L, tid);
   __syncthreads();
   for (int i = tid; i < n - 1; i += blockDim.x) {
     int rank = 0;

@@ -61,3 +61,31 @@ def test_cluster_from_real_distances(gpu, oracle):
         assert len(idx) == nv
         cases.append((d.copy(), b["reads"]["seq_len"][idx].astype(np.uint32)))
     _compare(gpu, oracle, cases)
+
+
+def test_cluster_large_v_ties_and_time(gpu, oracle):
+    """V = 100-200 with structure that stresses the nearest-neighbour tie rules of the wave-parallel NN-chain (quantised distances: many equal
+    minima; several groups; noise), 48 regions.  The NN search and the `s*a + t*b` update run across the 64 lanes of a wave; results must not move."""
+    import time
+    rng = np.random.default_rng(34)
+    cases = []
+    for c in range(48):
+        n = int(rng.integers(100, 201))
+        k = int(rng.integers(1, 5))
+        g = rng.integers(0, k, n)
+        cen = np.sort(rng.uniform(0.0, 0.6, k))
+        full = np.abs(cen[g][:, None] - cen[g][None, :]) + 0.05 + rng.random((n, n)) * 0.04
+        if c % 3 == 0:
+            full = np.round(full, 2)                     # ties everywhere
+        elif c % 3 == 1:
+            full = np.round(full, 3)
+        full = np.triu(full, 1)
+        cases.append((full[np.triu_indices(n, 1)].copy(), rng.integers(300, 3000, n).astype(np.uint32)))
+    _compare(gpu, oracle, cases)
+    P = abi.default_params()
+    packed = pack_cluster_cases(cases)
+    t0 = time.perf_counter()
+    gpu.cluster_batch(P, *packed)
+    dt = time.perf_counter() - t0
+    print("48 regions of V=100..200: %.1f ms through otg_cluster_batch (upload + kernel + download)" % (dt * 1e3))
+    assert dt < 2.0
