@@ -40,3 +40,17 @@ def test_bench_refuses_a_world_size_mismatch():
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, timeout=120)
     assert p.returncode == 2 and b"WORLD_SIZE=1" in p.stderr
+
+
+def test_bench_self_launch_propagates_rank_failure():
+    """`python bench.py --gpus 2` without a launcher starts the ranks itself (fresh children, env set before anything is imported).  In a
+    container without GPUs every rank fails at device selection: the parent must come back non-zero, promptly, and say which rank failed —
+    the failure path of the N-rank launch (the success path needs two GPUs: tests/test_gpu_rccl.py)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPUs visible: the launch would succeed or run long; covered by tests/test_gpu_rccl.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--regions", "250", "--no-cpu-baseline"], env=env,
+                       capture_output=True, timeout=300)
+    assert p.returncode != 0
+    assert b"bench.py: rank" in p.stderr and b"exited with" in p.stderr
