@@ -42,7 +42,7 @@ def parse_args():
     ap.add_argument("--regions", type=int, default=None, help="regions per GPU (default: the config's own count; config 4: 100000/8)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU work per cpu_baseline run (3 runs per kind)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--e2e-regions", type=int, default=1000, help="regions of the file-to-text leg (BED + BAM -> SAM text through otg_assemble_files); 0: skip")
+    ap.add_argument("--e2e-regions", type=int, default=2000, help="regions of the file-to-text leg (BED + BAM -> SAM text through otg_assemble_files); 0: skip")
     return ap.parse_args()
 
 
@@ -152,13 +152,13 @@ def e2e_leg(n_regions, threads):
         best = None
         for _ in range(3):
             t1 = time.perf_counter()
-            text, st = otter_amd.assemble_files(fx["bam"], fx["bed"], read_group="s1", batch_regions=max(64, n_regions // 8), offset_l=1, offset_r=1, mapq=10, threads=threads)
+            text, st = otter_amd.assemble_files(fx["bam"], fx["bed"], read_group="s1", batch_regions=max(64, n_regions // 4), offset_l=1, offset_r=1, mapq=10, threads=threads)
             dt = time.perf_counter() - t1
             if best is None or dt < best[0]:
                 best = (dt, st, len(text))
         dt, st, nbytes = best
         return {"regions_per_s": round(n_regions / dt, 1), "regions": n_regions, "reads": int(st["n_reads"]), "alleles": int(st["n_alleles"]), "sam_bytes": nbytes,
-                "bam_bytes": os.path.getsize(fx["bam"]), "host_threads": threads, "batch_regions": max(64, n_regions // 8), "wall_ms": round(dt * 1000.0, 1),
+                "bam_bytes": os.path.getsize(fx["bam"]), "host_threads": threads, "batch_regions": max(64, n_regions // 4), "wall_ms": round(dt * 1000.0, 1),
                 "stage_busy_ms": {"ingest": round(st["ms_ingest"], 1), "hot_path": round(st["ms_hot_path"], 1), "emit": round(st["ms_emit"], 1)},
                 "what": "BED file + BAM/BAI -> otg_assemble_files -> SAM text (header + allele records), best of 3; fixture: %d two-allele TR loci x 30 ONT-like reads of "
                         "1-5 kb written by otter_amd/bamwrite.py in %.0f s" % (n_regions, build_s)}
