@@ -6,9 +6,9 @@ invalid_reassignment -> rapid_consensus) over one batch of synthetic TR regions 
 (otg_assemble_submit ran before the timed region), INCLUDING the hand-over of the allele records to the host:
 otg_assemble_collect at N=1, the RCCL gather to rank 0 + its one device-to-host copy at N>1.
 
-Workloads come from otter_amd.synth.CONFIGS (= BASELINE.json configs): --config 1 (default at N=1: 10 000 regions x 1-5 kb,
-30x ONT), --config 2 (the same with -r and soft-clipped divergent flanks), --config 4 (default at N>1: 1-10 kb regions,
-12 500 per GPU = the per-GPU shard of the 100 000-region 8-GPU job).  N>1: static contiguous BED split (rank r owns the
+Workloads come from otter_amd.synth.CONFIGS (= BASELINE.json configs): --config 1 (default at every N: 10 000 regions x 1-5 kb,
+30x ONT per GPU), --config 2 (the same with -r and soft-clipped divergent flanks), --config 4 (1-10 kb regions, 12 500 per GPU = the
+per-GPU shard of the 100 000-region 8-GPU job).  N>1: static contiguous BED split (rank r owns the
 r-th shard, weak scaling), no data-path collective, end-of-run gather of the records over RCCL as north_star specifies.
 
 `python bench.py --gpus N` without a launcher starts the N ranks itself: the parent never imports torch or touches the
@@ -38,7 +38,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", type=int, default=None, choices=(1, 2, 4), help="BASELINE.json configs index (default: 1 at N=1, 4 at N>1)")
+    ap.add_argument("--config", type=int, default=None, choices=(1, 2, 4), help="BASELINE.json configs index (default 1 at every N: weak scaling over identical per-GPU shards)")
     ap.add_argument("--regions", type=int, default=None, help="regions per GPU (default: the config's own count; config 4: 100000/8)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU work per cpu_baseline run (3 runs per kind)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -187,7 +187,9 @@ def run_rank(args):
     import otter_amd
     from otter_amd import abi, synth, parallel
 
-    cfg = args.config if args.config is not None else (1 if world == 1 else 4)
+    # Same per-GPU workload at every N (weak scaling): the driver derives scaling efficiency from the per-N values, so N = 1 and N > 1 must run the
+    # same shape — configs[1], the configuration the metric is quoted on.  `--config 4` selects the 1-10 kb shard of the 8-GPU configs[4] at any N.
+    cfg = args.config if args.config is not None else 1
     n_regions = args.regions if args.regions is not None else (synth.CONFIGS[cfg]["n_regions"] // 8 if cfg == 4 else synth.CONFIGS[cfg]["n_regions"])
     ctx = otter_amd.Context(local_rank)
     params = abi.default_params(realign=1 if synth.CONFIGS[cfg].get("realign") else 0)
