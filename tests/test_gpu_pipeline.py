@@ -252,3 +252,20 @@ def test_stale_cigar_member(gpu, oracle):
         if int(a["acov"]) > 2 and int(reads["seq_len"][i]) > int(a["seq_len"]) - 8:
             live += 1
     assert live >= 4
+
+
+def test_reads_with_n_bases(gpu, oracle):
+    """Reads that carry bases outside ACGT ('N', lower case): their gap-affine alignments cannot use the 2-bit packed LDS tiers and take the
+    byte-compare tiers inside the pipeline; edit distances compare raw bytes (N == N, case-sensitive, as WFA2 does).  Same records as the oracle."""
+    b = synth.make_batch(24, len_range=(400, 1500), n_reads=14, err="ont", seed=91, frac_partial=0.15)
+    arena = b["arena"].copy()
+    rng = np.random.default_rng(91)
+    n = arena.size - 64
+    hit = rng.random(n) < 0.004
+    arena[:n][hit] = ord("N")
+    low = rng.random(n) < 0.002
+    arena[:n][low] = np.where(arena[:n][low] == ord("N"), ord("N"), arena[:n][low] | 0x20)
+    b2 = dict(b, arena=arena)
+    res, st = run_both(gpu, oracle, b2)
+    nseq = int(res["alleles"]["seq_len"].astype(np.int64).sum())
+    assert (res["seqs"][:nseq] == ord("N")).sum() > 0 or int(st["affine_tasks"]) > 50
