@@ -1411,8 +1411,13 @@ __device__ __forceinline__ int lo16s(uint32_t w) { return (int)(int16_t)(w & 0xf
 __device__ __forceinline__ int hi16s(uint32_t w) { return (int)w >> 16; }
 __device__ __forceinline__ uint32_t pack16(int lo, int hi) { return __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u); }   // {lo16: lo, hi16: hi}
 
-template <int S2, int SEQB, int WPEU>
-__global__ __launch_bounds__(256, WPEU) void wfa_affine_kernel_v5(
+// NW > 1: NW waves share ONE alignment whose window is NW x S2 pair-slots wide.  Pair-slot g belongs to wave g % NW (cyclic, so the touched
+// slots of a score spread evenly over the waves); every neighbour of a slot then lives in another wave, and the two export words per slot
+// travel through a double-buffered LDS table that the owner writes at the END of a score for the next one.  One barrier per score: it
+// closes the score (exports and the waves' termination candidates are published before it, read after it).  NW == 1 is the kernel above
+// (four independent one-wave alignments per block; neighbours through registers).
+template <int NW, int S2, int SEQB, int WPEU>
+__global__ __launch_bounds__(NW == 1 ? 256 : NW * 64, WPEU) void wfa_affine_kernel_v5(
     const uint8_t* __restrict__ arena, const otg_align_task* __restrict__ tasks,
     const uint32_t* __restrict__ todo, const uint32_t* __restrict__ seg, int g,
     int32_t* __restrict__ scores, const uint64_t* __restrict__ cig_off, uint32_t* __restrict__ cig_len,
@@ -1421,27 +1426,45 @@ __global__ __launch_bounds__(256, WPEU) void wfa_affine_kernel_v5(
     AffWs ws, const int32_t* __restrict__ bound, unsigned long long* __restrict__ visited)
 {
   constexpr int xs = 2, oes = 4, es = 1;
-  constexpr int CAP = S2 * 128;
+  constexpr int CAP = NW * S2 * 128;
+  constexpr int ALN = NW == 1 ? 4 : 1;              // alignments per block
+  constexpr int WAVES = NW == 1 ? 4 : NW;           // waves per block
+  constexpr int GS = NW * S2;                        // pair-slots of the window
+  constexpr int FAILV = -2147483647 - 1;
   constexpr int QCAP = 512;
   constexpr uint32_t NN = 0x80008000u;
   constexpr int NUL16 = -32768;
-  __shared__ uint32_t s_seq[4][SEQB / 4];
-  __shared__ uint32_t s_patch[4][CAP / 2];
-  __shared__ uint32_t s_queue[4][QCAP];
+  __shared__ uint32_t s_seq[ALN][SEQB / 4];
+  __shared__ uint32_t s_patch[ALN][CAP / 2];
+  __shared__ uint32_t s_queue[WAVES][QCAP];
+  __shared__ uint32_t s_xl[2][GS + 2], s_xr[2][GS + 2];     // [score parity][slot + 1]: export words of the slots (left-going / right-going)
+  __shared__ int s_cand[2][WAVES];
+  __shared__ int s_misc[4];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  uint32_t* SQ = &s_seq[wv][0];
-  volatile lds_u32* PT = (volatile lds_u32*)&s_patch[wv][0];
+  const int al = NW == 1 ? wv : 0;                  // which alignment of the block this wave works on
+  const int ww = NW == 1 ? 0 : wv;                  // its rank among the waves of that alignment
+  uint32_t* SQ = &s_seq[al][0];
+  volatile lds_u32* PT = (volatile lds_u32*)&s_patch[al][0];
   volatile lds_u32* QU = (volatile lds_u32*)&s_queue[wv][0];
-  volatile lds_u16* PT16 = (volatile lds_u16*)&s_patch[wv][0];
-  uint8_t* my = ws.base + (size_t)(blockIdx.x * 4 + wv) * ws.stride;
+  volatile lds_u16* PT16 = (volatile lds_u16*)&s_patch[al][0];
+  volatile lds_u32* XL = (volatile lds_u32*)&s_xl[0][0];
+  volatile lds_u32* XR = (volatile lds_u32*)&s_xr[0][0];
+  volatile __attribute__((address_space(3))) int* CA = (volatile __attribute__((address_space(3))) int*)&s_cand[0][0];
+  volatile __attribute__((address_space(3))) int* MISC = (volatile __attribute__((address_space(3))) int*)&s_misc[0];
+  uint8_t* my = ws.base + (size_t)(blockIdx.x * ALN + al) * ws.stride;
   int64_t* rowtab = (int64_t*)(my + ws.off_rowtab);
   uint8_t* rev = my + ws.off_rev;
   uint8_t* slab = my + ws.off_slab;
   const uint32_t seg0 = seg[0], n_todo = seg[1] - seg[0];
 
   for (;;) {
-    const uint32_t tk = otg_wave_atomic_add(ticket, 1u);
+    uint32_t tk;
+    if (NW > 1) {
+      if (wv == 0) MISC[0] = (int)otg_wave_atomic_add(ticket, 1u);
+      __syncthreads();
+      tk = (uint32_t)MISC[0];
+    } else tk = otg_wave_atomic_add(ticket, 1u);
     if (tk >= n_todo) break;
     const uint32_t ti = todo[seg0 + tk];
     const otg_align_task t = tasks[ti];
@@ -1469,10 +1492,11 @@ __global__ __launch_bounds__(256, WPEU) void wfa_affine_kernel_v5(
     static_for<0, S2 + 1>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value;
       MC[0][i][0] = NN; MC[0][i][1] = NN; MC[1][i][0] = NN; MC[1][i][1] = NN; ID[i][0] = NN; ID[i][1] = NN; });
     if (!fail) {
-      for (int q = lane; q < CAP / 2; q += 64) PT[q] = NN;
+      for (int q = (NW == 1 ? lane : (int)threadIdx.x); q < CAP / 2; q += (NW == 1 ? 64 : NW * 64)) PT[q] = NN;
+      if (NW > 1) for (int q = (int)threadIdx.x; q < 2 * (GS + 2); q += NW * 64) { XL[q] = NN; XR[q] = NN; }
       bool bad = false;
       auto pack = [&](const uint8_t* S, int len, int woff) {
-        for (int q = lane; q < (len + 15) / 16; q += 64) {
+        for (int q = (NW == 1 ? lane : (int)threadIdx.x); q < (len + 15) / 16; q += (NW == 1 ? 64 : NW * 64)) {
           uint32_t w = 0;
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
@@ -1492,9 +1516,11 @@ __global__ __launch_bounds__(256, WPEU) void wfa_affine_kernel_v5(
       pack(P, pl, 0);
       pack(T, tl, offT);
       // slack words a probe may read past the packed ends
-      if (lane < 3) { SQ[(pl + 15) / 16 + lane] = 0; SQ[offT + (tl + 15) / 16 + lane] = 0; }
-      fail = __ballot(bad) != 0ull;
+      if ((NW == 1 ? lane : (int)threadIdx.x) < 3) { const int q3 = NW == 1 ? lane : (int)threadIdx.x; SQ[(pl + 15) / 16 + q3] = 0; SQ[offT + (tl + 15) / 16 + q3] = 0; }
+      if (NW > 1) { if (threadIdx.x == 0) MISC[2] = 0; __syncthreads(); if (bad) MISC[2] = 1; __syncthreads(); fail = MISC[2] != 0; }
+      else fail = __ballot(bad) != 0ull;
     }
+    if (NW > 1) __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     auto ld32b = [&](int woff, int pos) -> uint64_t {
       const int w = woff + (pos >> 4);
@@ -1558,26 +1584,23 @@ __global__ __launch_bounds__(256, WPEU) void wfa_affine_kernel_v5(
       }
       lo = __builtin_amdgcn_readfirstlane(lo); hi = __builtin_amdgcn_readfirstlane(hi);     // wave-uniform by construction: say so, the whole score loop stays scalar
       r4lo = r3lo; r4hi = r3hi; r3lo = r2lo; r3hi = r2hi; r2lo = r1lo; r2hi = r1hi;
+      int cand = 0x7fffffff;
+      int j0 = 1, j1 = 0;                        // touched pair-slots of this score (none when the score is unreachable)
       if (hi < lo) {   // unreachable score: nothing is written, the parity arrays still trade places
         r1lo = 1; r1hi = 0; idlo = 1; idhi = 0;
         rowtab[s] = -1;
-        if (s > 2 * (oes + es * (pl + tl)) + 8) fail = true;
-        static_for<0, S2>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value;
-          { const uint32_t t_ = MC[0][i][0]; MC[0][i][0] = MC[1][i][0]; MC[1][i][0] = t_; }
-          { const uint32_t t_ = MC[0][i][1]; MC[0][i][1] = MC[1][i][1]; MC[1][i][1] = t_; } });
-        continue;
-      }
+        if (s > 2 * (oes + es * (pl + tl)) + 8) { fail = true; break; }
+      } else {
       r1lo = lo; r1hi = hi;
       const int xlo = lo - kbase, xhi = hi - kbase;
       if (xlo < 2 || xhi + 3 >= CAP) { fail = true; break; }
-      const int j0 = xlo >> 7, j1 = xhi >> 7;
+      j0 = xlo >> 7; j1 = xhi >> 7;
       const int width = (j1 - j0 + 1) * 128;
       if (slab_top + (size_t)width > ws.slab_bytes) { fail = true; break; }
       uint8_t* brow = slab + slab_top - 128 * j0;                  // provenance byte of window index x: brow[x]
-      rowtab[s] = (int64_t)slab_top - (int64_t)(kbase + 128 * j0);  // wave-uniform store (same value from every lane)
+      rowtab[s] = (int64_t)slab_top - (int64_t)(kbase + 128 * j0);  // wave-uniform store (same value from every lane and every wave)
       slab_top += (size_t)width;
       int qn = 0;
-      int cand = 0x7fffffff;
       // ---- drain: queued cells {x | h << 16} are extended to the end of their match run in 64-lane batches; final offsets go to the patch table
       auto drain = [&]() {
         int pass = 0;
@@ -1653,8 +1676,9 @@ __global__ __launch_bounds__(256, WPEU) void wfa_affine_kernel_v5(
       if (s == 0) {
         // score 0: offset max(k, 0) on every start diagonal, no I / D wavefronts; everything is extended through the queue
         static_for<0, S2>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value;
-          if (i < j0 || i > j1) return;
-          const int xE = 128 * i + lane2, kE = kb + xE, kO = kE + 1;
+          const int gi = NW == 1 ? i : i * NW + ww;
+          if (gi < j0 || gi > j1) return;
+          const int xE = 128 * gi + lane2, kE = kb + xE, kO = kE + 1;
           const int hE = kE > 0 ? kE : 0, vE = hE - kE, hO = kO > 0 ? kO : 0, vO = hO - kO;
           const bool validE = kE >= lo && kE <= hi && hE <= tl && vE <= pl, validO = kO >= lo && kO <= hi && hO <= tl && vO <= pl;
           MC[0][i][0] = pack16(NUL16, validE ? hE : NUL16);
@@ -1664,7 +1688,7 @@ __global__ __launch_bounds__(256, WPEU) void wfa_affine_kernel_v5(
             const bool fE = validE && !moreE && fin_ef(hE, vE), fO = validO && !moreO && fin_ef(hO, vO);
             const unsigned long long fm = __ballot(fE || fO);
             if (fm) { int kc = fE ? kE : (fO ? kO : 0x7fffffff); kc = -otg_wave_max_i32(-kc); cand = imin(cand, kc); }
-          } else if (xe >= 128 * i && xe < 128 * i + 128) {
+          } else if (xe >= 128 * gi && xe < 128 * gi + 128) {
             const int hx = __builtin_amdgcn_readlane((xe & 1) ? (validO && !moreO ? hO : -1) : (validE && !moreE ? hE : -1), (xe & 127) >> 1);
             if (hx >= tl) cand = kend;
           }
@@ -1672,21 +1696,28 @@ __global__ __launch_bounds__(256, WPEU) void wfa_affine_kernel_v5(
         });
       } else {
         // ---- the sweep over the touched pair-slots, ascending
-        uint32_t carryL = NN;                     // {M[s-4], I[s-1]} of the diagonal left of the current pair-slot
+        uint32_t carryL = NN;                     // {M[s-4], I[s-1]} of the diagonal left of the current pair-slot (NW == 1: carried in a register)
+        const int xp = (s & 1) * (GS + 2);        // this score's half of the export tables
         static_for<0, S2>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value;
-          if (i + 1 == j0) {                       // the slot left of the first touched one: its lane 63 is the left neighbour of the sweep
+          const int gi = NW == 1 ? i : i * NW + ww;
+          if (NW == 1 && gi + 1 == j0) {           // the slot left of the first touched one: its lane 63 is the left neighbour of the sweep
             carryL = (uint32_t)__builtin_amdgcn_readlane((int)pack16(lo16s(MC[0][i][1]), lo16s(ID[i][1])), 63);
           }
-          if (i < j0 || i > j1) return;
+          if (gi < j0 || gi > j1) return;
           const uint32_t mE = MC[0][i][0], mO = MC[0][i][1], dE = ID[i][0], dO = ID[i][1];
           const uint32_t Lx = pack16(lo16s(mO), lo16s(dO));                               // what the lane to the right needs: {M[s-4][odd], I[s-1][odd]}
           const uint32_t Rx = pack16(lo16s(mE), hi16s(dE));                               // what the lane to the left needs: {M[s-4][even], D[s-1][even]}
-          uint32_t rcar = NN;
-          if (i + 1 < S2) rcar = (uint32_t)__builtin_amdgcn_readlane((int)pack16(lo16s(MC[0][i + 1][0]), hi16s(ID[i + 1][0])), 0);   // the next pair-slot's lane 0, still old
-          const uint32_t lnb = (uint32_t)__builtin_amdgcn_update_dpp((int)carryL, (int)Lx, 0x138, 0xf, 0xf, false);   // lane l <- lane l-1, lane 0 <- carryL
-          const uint32_t rnb = (uint32_t)__builtin_amdgcn_update_dpp((int)rcar, (int)Rx, 0x130, 0xf, 0xf, false);     // lane l <- lane l+1, lane 63 <- rcar
-          carryL = (uint32_t)__builtin_amdgcn_readlane((int)Lx, 63);
-          const int xE = 128 * i + lane2, kE = kb + xE;
+          uint32_t rcar = NN, lcar = carryL;
+          if (NW == 1) {
+            if (i + 1 < S2) rcar = (uint32_t)__builtin_amdgcn_readlane((int)pack16(lo16s(MC[0][i + 1][0]), hi16s(ID[i + 1][0])), 0);   // the next pair-slot's lane 0, still old
+          } else {
+            lcar = (uint32_t)__builtin_amdgcn_readfirstlane((int)XL[xp + gi]);             // export of slot gi - 1 (entry g + 1 holds slot g)
+            rcar = (uint32_t)__builtin_amdgcn_readfirstlane((int)XR[xp + gi + 2]);         // export of slot gi + 1
+          }
+          const uint32_t lnb = (uint32_t)__builtin_amdgcn_update_dpp((int)lcar, (int)Lx, 0x138, 0xf, 0xf, false);   // lane l <- lane l-1, lane 0 <- the left slot
+          const uint32_t rnb = (uint32_t)__builtin_amdgcn_update_dpp((int)rcar, (int)Rx, 0x130, 0xf, 0xf, false);   // lane l <- lane l+1, lane 63 <- the right slot
+          if (NW == 1) carryL = (uint32_t)__builtin_amdgcn_readlane((int)Lx, 63);
+          const int xE = 128 * gi + lane2, kE = kb + xE;
           int insE, delE, mxE, insO, delO, mxO;
           uint32_t bitsE, bitsO;
           {   // even diagonal: left neighbour from lane l-1, right neighbour is the lane's own odd diagonal
@@ -1752,29 +1783,52 @@ __global__ __launch_bounds__(256, WPEU) void wfa_affine_kernel_v5(
             const bool fE = validE && !moreE && fin_ef(hE, hE - kE), fO = validO && !moreO && fin_ef(hO, hO - kE - 1);
             const unsigned long long fm = __ballot(fE || fO);
             if (fm) { int kc = fE ? kE : (fO ? kE + 1 : 0x7fffffff); kc = -otg_wave_max_i32(-kc); cand = imin(cand, kc); }
-          } else if (xe >= 128 * i && xe < 128 * i + 128) {
+          } else if (xe >= 128 * gi && xe < 128 * gi + 128) {
             const int hx = __builtin_amdgcn_readlane((xe & 1) ? (validO && !moreO ? hO : -1) : (validE && !moreE ? hE : -1), (xe & 127) >> 1);
             if (hx >= tl) cand = kend;
           }
           push2(moreE, moreO, xE, hE, hO);
         });
       }
-      if (qfull) { fail = true; break; }
-      if (pushed) {
+      if (qfull) cand = FAILV;
+      else if (pushed) {
         drain();
         // fold the final offsets of the queued cells into the M words (partial offset <= final offset: a packed max)
         static_for<0, S2>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value;
-          if (i < j0 || i > j1) return;
-          const uint32_t pw = PT[64 * i + lane];
+          const int gi = NW == 1 ? i : i * NW + ww;
+          if (gi < j0 || gi > j1) return;
+          const uint32_t pw = PT[64 * gi + lane];
           if (__ballot(pw != NN)) {
             MC[0][i][0] = pk_max_i16(MC[0][i][0], pack16(NUL16, lo16s(pw)));
             MC[0][i][1] = pk_max_i16(MC[0][i][1], pack16(NUL16, hi16s(pw)));
-            PT[64 * i + lane] = NN;
+            PT[64 * gi + lane] = NN;
           }
         });
       }
       idlo = s == 0 ? 1 : lo; idhi = s == 0 ? 0 : hi;
+      }
+      // ---- close the score: (NW > 1) publish the export words the neighbours need for score s + 1 — from the arrays of the OTHER parity,
+      // which are the current ones of the next score, and the I / D words just written — and this wave's candidate; one barrier; then every
+      // wave sees every candidate
       cand = __builtin_amdgcn_readfirstlane(cand);
+      if (NW > 1) {
+        const int np = ((s + 1) & 1) * (GS + 2);
+        static_for<0, S2>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value;
+          const int gi = i * NW + ww;
+          if (gi + 2 < j0 || gi > j1 + 2) return;          // the next score's range moves by at most one diagonal
+          const uint32_t Lx = pack16(lo16s(MC[1][i][1]), lo16s(ID[i][1]));
+          const uint32_t Rx = pack16(lo16s(MC[1][i][0]), hi16s(ID[i][0]));
+          if (lane == 63) XL[np + gi + 1] = Lx;
+          if (lane == 0) XR[np + gi + 1] = Rx;
+        });
+        if (lane == 0) CA[(s & 1) * WAVES + ww] = cand;
+        __syncthreads();
+        int gc = 0x7fffffff;
+#pragma unroll
+        for (int w2 = 0; w2 < NW; ++w2) { const int c2 = CA[(s & 1) * WAVES + w2]; gc = c2 < gc ? c2 : gc; }
+        cand = __builtin_amdgcn_readfirstlane(gc);
+      }
+      if (cand == FAILV) { fail = true; break; }
       if (cand != 0x7fffffff) { s_end = s; k_end = cand; break; }
       // the other parity is next
       static_for<0, S2>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value;
@@ -1782,13 +1836,14 @@ __global__ __launch_bounds__(256, WPEU) void wfa_affine_kernel_v5(
         { const uint32_t t_ = MC[0][i][1]; MC[0][i][1] = MC[1][i][1]; MC[1][i][1] = t_; } });
     }
 
+    if (NW > 1 && wv != 0) continue;           // wave 0 reports / unpacks; the others wait at the next ticket barrier
     if (fail || s_end < 0) {
       const uint32_t q = otg_wave_atomic_add(n_overflow, 1u);
       overflow_list[q] = ti;                                   // wave-uniform store
       continue;
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
-    if (!backtrace_unpack(P, pl, T, tl, s_end, k_end, xs, oes, es, rowtab, slab, rev, ws.rev_cap, cig_arena + cig_off[ti], lane, &scores[ti], &cig_len[ti], g, (volatile lds_u32*)&s_queue[wv][0], EqPacked{(volatile lds_u32*)&s_seq[wv][0], offT})) continue;
+    if (!backtrace_unpack(P, pl, T, tl, s_end, k_end, xs, oes, es, rowtab, slab, rev, ws.rev_cap, cig_arena + cig_off[ti], lane, &scores[ti], &cig_len[ti], g, (volatile lds_u32*)&s_queue[wv][0], EqPacked{(volatile lds_u32*)&s_seq[al][0], offT})) continue;
     if (cells) cells[ti] = affine_cells(t, xs, oes, s_end);
     if (visited && lane == 0) atomicAdd(visited, (unsigned long long)slab_top);
   }
@@ -1856,9 +1911,12 @@ __global__ __launch_bounds__(256) void K_asort_scatter(const uint32_t* __restric
 
 // ---- register-resident tiers (v5): which tier takes an alignment follows from its score bound and shape alone — the same window
 // arithmetic as the kernel — so one counting sort on (tier, bound) hands every tier its own list, longest alignments first
-constexpr int V5_TIERS = 3;                                         // pair-slots 8 / 12 / 16: windows of 1024 / 1536 / 2048 diagonals
+#ifndef OTG_V5_DEFAULT_MASK
+#define OTG_V5_DEFAULT_MASK 0
+#endif
+constexpr int V5_TIERS = 4;                                         // pair-slots 8 / 12 / 16 (one wave each): windows of 1024 / 1536 / 2048 diagonals; 4 waves x 8: 4096
 constexpr int TSORT_BUCKETS = (V5_TIERS + 1) * ASORT_BUCKETS;       // last tier = everything else (LDS / HBM tiers)
-__device__ __forceinline__ int v5_tier(const otg_align_task& t, int U)
+__device__ __forceinline__ int v5_tier(const otg_align_task& t, int U, int mask)
 {
   const int pl = (int)t.pattern_len, tl = (int)t.text_len;
   if (U < 0 || U >= 0x40000000 || pl >= 32766 || tl >= 32766) return V5_TIERS;
@@ -1871,20 +1929,22 @@ __device__ __forceinline__ int v5_tier(const otg_align_task& t, int U)
   const int wlo = imax((lo0 + elo - U) >> 1, -pl) - 1, whi = imin((hi0 + ehi + U + 1) >> 1, tl) + 1;
   const int need = whi - (wlo - 2) + 4;                             // the kernel wants need < CAP
   const int seqb = ((pl + 15) / 16 + 3 + (tl + 15) / 16 + 3) * 4;
-  if (need < 1024 && seqb <= 4096) return 0;
-  if (need < 1536 && seqb <= 4608) return 1;
-  if (need < 2048 && seqb <= 6144) return 2;
+  if ((mask & 1) && need < 1024 && seqb <= 4096) return 0;
+  if ((mask & 2) && need < 1536 && seqb <= 4608) return 1;
+  if ((mask & 4) && need < 2048 && seqb <= 6144) return 2;
+  // the multi-wave tier takes what the smaller LDS tiers cannot (their windows end at 2048 diagonals)
+  if ((mask & 8) && need < 4096 && seqb <= 8192 && (need >= 2048 || seqb > 3072 || (mask & 7))) return 3;
   return V5_TIERS;
 }
-__device__ __forceinline__ int tsort_bucket(const otg_align_task& t, int U) { return v5_tier(t, U) * ASORT_BUCKETS + asort_bucket(U); }
+__device__ __forceinline__ int tsort_bucket(const otg_align_task& t, int U, int mask) { return v5_tier(t, U, mask) * ASORT_BUCKETS + asort_bucket(U); }
 __global__ __launch_bounds__(256) void K_tsort_hist(const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_ptr, uint32_t n_imm,
-                                                    const otg_align_task* __restrict__ tasks, const int32_t* __restrict__ bound, uint32_t* __restrict__ hist)
+                                                    const otg_align_task* __restrict__ tasks, const int32_t* __restrict__ bound, uint32_t* __restrict__ hist, int mask)
 {
   __shared__ uint32_t h[TSORT_BUCKETS];
   for (int b = (int)threadIdx.x; b < TSORT_BUCKETS; b += 256) h[b] = 0;
   __syncthreads();
   const uint32_t n = n_ptr ? *n_ptr : n_imm;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { const uint32_t ti = list ? list[i] : i; atomicAdd(&h[tsort_bucket(tasks[ti], bound[ti])], 1u); }
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { const uint32_t ti = list ? list[i] : i; atomicAdd(&h[tsort_bucket(tasks[ti], bound[ti], mask)], 1u); }
   __syncthreads();
   for (int b = (int)threadIdx.x; b < TSORT_BUCKETS; b += 256) if (h[b]) atomicAdd(&hist[b], h[b]);
 }
@@ -1916,7 +1976,7 @@ __global__ __launch_bounds__(1024) void K_tsort_scan(uint32_t* __restrict__ hist
 }
 __global__ __launch_bounds__(256) void K_tsort_scatter(const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_ptr, uint32_t n_imm,
                                                        const otg_align_task* __restrict__ tasks, const int32_t* __restrict__ bound,
-                                                       uint32_t* __restrict__ pos, uint32_t* __restrict__ out)
+                                                       uint32_t* __restrict__ pos, uint32_t* __restrict__ out, int mask)
 {
   __shared__ uint32_t cnt[TSORT_BUCKETS], basep[TSORT_BUCKETS];
   const uint32_t n = n_ptr ? *n_ptr : n_imm;
@@ -1924,13 +1984,13 @@ __global__ __launch_bounds__(256) void K_tsort_scatter(const uint32_t* __restric
   const uint32_t lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
   for (int b = (int)threadIdx.x; b < TSORT_BUCKETS; b += 256) cnt[b] = 0;
   __syncthreads();
-  for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) { const uint32_t ti = list ? list[i] : i; atomicAdd(&cnt[tsort_bucket(tasks[ti], bound[ti])], 1u); }
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) { const uint32_t ti = list ? list[i] : i; atomicAdd(&cnt[tsort_bucket(tasks[ti], bound[ti], mask)], 1u); }
   __syncthreads();
   for (int b = (int)threadIdx.x; b < TSORT_BUCKETS; b += 256) { basep[b] = cnt[b] ? atomicAdd(&pos[b], cnt[b]) : 0u; cnt[b] = 0; }
   __syncthreads();
   for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
     const uint32_t ti = list ? list[i] : i;
-    const int b = tsort_bucket(tasks[ti], bound[ti]);
+    const int b = tsort_bucket(tasks[ti], bound[ti], mask);
     out[basep[b] + atomicAdd(&cnt[b], 1u)] = ti;
   }
 }
@@ -2077,10 +2137,11 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
       // alignments in decreasing order of their bound (work ~ bound^2): short tails in every tier kernel
       const uint32_t* inS = d_todo; const uint32_t* inS_n = d_n_todo; uint32_t inS_imm = n_tasks;
       static const bool no_asort = getenv("OTG_NO_AFFINE_SORT") != nullptr;
-      static const bool no_v5 = getenv("OTG_AFFINE_V5") == nullptr;      // register-resident tiers: opt-in (measured on par with the LDS tiers)
+      // register-resident tiers (bit mask: 1 / 2 / 4 = the one-wave tiers of 1024 / 1536 / 2048 diagonals, 8 = the four-wave tier of 4096)
+      static const int v5_mask = getenv("OTG_AFFINE_V5") ? atoi(getenv("OTG_AFFINE_V5")) : OTG_V5_DEFAULT_MASK;
+      const bool no_v5 = v5_mask == 0;
       if (!no_v5) {
-        // register-resident tiers: one counting sort on (tier, bound) gives each tier its list; what no tier takes (or a tier gives up)
-        // is the input of the LDS / HBM tiers below
+        // one counting sort on (tier, bound) gives each tier its list; what no tier takes (or a tier gives up) is the input of the LDS / HBM tiers below
         uint32_t* hist = (uint32_t*)otg_slot(ctx, SLOT_ROWTAB, TSORT_BUCKETS * sizeof(uint32_t));
         uint32_t* sorted = todo + 6 * (size_t)n_tasks;
         uint32_t* ovf5 = todo + 7 * (size_t)n_tasks;
@@ -2089,13 +2150,13 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
         if (!hist) return OTG_ERR_HIP;
         HIP_TRY(ctx, hipMemsetAsync(hist, 0, TSORT_BUCKETS * sizeof(uint32_t), ctx->stream));
         const uint32_t sg = std::min<uint32_t>((n_tasks + 2047) / 2048, (uint32_t)ctx->n_cu * 2);
-        hipLaunchKernelGGL(K_tsort_hist, dim3(sg), dim3(256), 0, ctx->stream, d_todo, d_n_todo, n_tasks, d_tasks, (const int32_t*)d_bound, hist);
+        hipLaunchKernelGGL(K_tsort_hist, dim3(sg), dim3(256), 0, ctx->stream, d_todo, d_n_todo, n_tasks, d_tasks, (const int32_t*)d_bound, hist, v5_mask);
         hipLaunchKernelGGL(K_tsort_scan, dim3(1), dim3(1024), 0, ctx->stream, hist, seg);
-        hipLaunchKernelGGL(K_tsort_scatter, dim3(sg), dim3(256), 0, ctx->stream, d_todo, d_n_todo, n_tasks, d_tasks, (const int32_t*)d_bound, hist, sorted);
+        hipLaunchKernelGGL(K_tsort_scatter, dim3(sg), dim3(256), 0, ctx->stream, d_todo, d_n_todo, n_tasks, d_tasks, (const int32_t*)d_bound, hist, sorted, v5_mask);
         hipLaunchKernelGGL(K_seg_copy, dim3(std::min<uint32_t>((n_tasks + 255) / 256, 1024u)), dim3(256), 0, ctx->stream, (const uint32_t*)sorted,
                            (const uint32_t*)(seg + V5_TIERS), ovf5, n_ovf5);
-        // per-wave workspaces of the three tiers side by side (they may run concurrently); row table sized by the window (a score is a row)
-        auto v5_ws = [&](int cap, uint32_t blocks_per_cu, uint32_t& blocks) {
+        // workspaces of the tiers side by side; row table sized by the window (a score is a row); `units` = alignments in flight
+        auto v5_ws = [&](int cap, uint32_t units) {
           AffWs w = ws;
           w.nrows = cap + 64;
           w.off_rowtab = 0;
@@ -2103,22 +2164,25 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
           w.off_slab = (w.off_rev + ws.rev_cap + 255) & ~(size_t)255;
           w.slab_bytes = ((size_t)cap * (size_t)cap * 7 / 8 + (1 << 16)) & ~(size_t)255;
           w.stride = w.off_slab + w.slab_bytes;
-          blocks = (uint32_t)ctx->n_cu * blocks_per_cu;
+          (void)units;
           return w;
         };
-        uint32_t b0, b1, b2;
-        AffWs w0 = v5_ws(1024, 4, b0), w1 = v5_ws(1536, 3, b1), w2 = v5_ws(2048, 2, b2);
-        const size_t need5 = w0.stride * b0 * 4 + w1.stride * b1 * 4 + w2.stride * b2 * 4;
+        const uint32_t b0 = (v5_mask & 1) ? (uint32_t)ctx->n_cu * 4 : 0, b1 = (v5_mask & 2) ? (uint32_t)ctx->n_cu * 3 : 0, b2 = (v5_mask & 4) ? (uint32_t)ctx->n_cu * 2 : 0,
+                       b3 = (v5_mask & 8) ? (uint32_t)ctx->n_cu * 4 : 0;          // blocks; tiers 0-2 run four alignments per block, tier 3 one
+        AffWs w0 = v5_ws(1024, b0 * 4), w1 = v5_ws(1536, b1 * 4), w2 = v5_ws(2048, b2 * 4), w3 = v5_ws(4096, b3);
+        const size_t need5 = w0.stride * b0 * 4 + w1.stride * b1 * 4 + w2.stride * b2 * 4 + w3.stride * b3 + 256;
         uint8_t* ws5 = (uint8_t*)otg_slot(ctx, SLOT_REVOPS, need5);
         if (!ws5) return OTG_ERR_HIP;
-        w0.base = ws5; w1.base = ws5 + w0.stride * b0 * 4; w2.base = w1.base + w1.stride * b1 * 4;
+        w0.base = ws5; w1.base = w0.base + w0.stride * b0 * 4; w2.base = w1.base + w1.stride * b1 * 4; w3.base = w2.base + w2.stride * b2 * 4;
         unsigned long long* vis = ctx->affine_visited;
-        hipLaunchKernelGGL((wfa_affine_kernel_v5<8, 4096, 4>), dim3(b0), dim3(256), 0, ctx->stream, d_arena, d_tasks, (const uint32_t*)sorted, (const uint32_t*)(seg + 0), g,
-                           d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, cnt + 72, n_ovf5, ovf5, w0, (const int32_t*)d_bound, vis);
-        hipLaunchKernelGGL((wfa_affine_kernel_v5<12, 4608, 3>), dim3(b1), dim3(256), 0, ctx->stream, d_arena, d_tasks, (const uint32_t*)sorted, (const uint32_t*)(seg + 1), g,
-                           d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, cnt + 73, n_ovf5, ovf5, w1, (const int32_t*)d_bound, vis);
-        hipLaunchKernelGGL((wfa_affine_kernel_v5<16, 6144, 2>), dim3(b2), dim3(256), 0, ctx->stream, d_arena, d_tasks, (const uint32_t*)sorted, (const uint32_t*)(seg + 2), g,
-                           d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, cnt + 74, n_ovf5, ovf5, w2, (const int32_t*)d_bound, vis);
+        if (b0) hipLaunchKernelGGL((wfa_affine_kernel_v5<1, 8, 4096, 4>), dim3(b0), dim3(256), 0, ctx->stream, d_arena, d_tasks, (const uint32_t*)sorted, (const uint32_t*)(seg + 0), g,
+                                   d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, cnt + 72, n_ovf5, ovf5, w0, (const int32_t*)d_bound, vis);
+        if (b1) hipLaunchKernelGGL((wfa_affine_kernel_v5<1, 12, 4608, 3>), dim3(b1), dim3(256), 0, ctx->stream, d_arena, d_tasks, (const uint32_t*)sorted, (const uint32_t*)(seg + 1), g,
+                                   d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, cnt + 73, n_ovf5, ovf5, w1, (const int32_t*)d_bound, vis);
+        if (b2) hipLaunchKernelGGL((wfa_affine_kernel_v5<1, 16, 6144, 2>), dim3(b2), dim3(256), 0, ctx->stream, d_arena, d_tasks, (const uint32_t*)sorted, (const uint32_t*)(seg + 2), g,
+                                   d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, cnt + 74, n_ovf5, ovf5, w2, (const int32_t*)d_bound, vis);
+        if (b3) hipLaunchKernelGGL((wfa_affine_kernel_v5<4, 8, 8192, 4>), dim3(b3), dim3(256), 0, ctx->stream, d_arena, d_tasks, (const uint32_t*)sorted, (const uint32_t*)(seg + 3), g,
+                                   d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, cnt + 75, n_ovf5, ovf5, w3, (const int32_t*)d_bound, vis);
         inS = ovf5; inS_n = n_ovf5; inS_imm = 0;
       } else if (!no_asort) {
         uint32_t* hist = (uint32_t*)otg_slot(ctx, SLOT_ROWTAB, ASORT_BUCKETS * sizeof(uint32_t));
@@ -2174,8 +2238,8 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
     HIP_TRY(ctx, hipMemcpy(h, cnt, sizeof(h), hipMemcpyDeviceToHost));
     fprintf(stderr, "[otg] affine: LDS tiers overflow %u / %u, tier A overflow %u, tier B overflow %u\n", h[25], h[27], h[9], h[11]);
     { uint32_t h5[8]; HIP_TRY(ctx, hipMemcpy(h5, cnt + 64, sizeof(h5), hipMemcpyDeviceToHost));
-      fprintf(stderr, "[otg] affine: register tiers take %u / %u / %u alignments, %u go to the LDS tiers (of which given up by a register tier: %u)\n",
-              h5[1] - h5[0], h5[2] - h5[1], h5[3] - h5[2], h5[6], h5[6] - (h5[4] - h5[3])); }
+      fprintf(stderr, "[otg] affine: register tiers take %u / %u / %u / %u alignments, %u go to the LDS tiers (of which given up by a register tier: %u)\n",
+              h5[1] - h5[0], h5[2] - h5[1], h5[3] - h5[2], h5[4] - h5[3], h5[6], h5[6] - (h5[5] - h5[4])); }
     {
       unsigned long long vc[2] = {0, 0};
       HIP_TRY(ctx, hipMemcpyFromSymbol(vc, HIP_SYMBOL(otg_dbg_v4_cells), sizeof(vc)));
