@@ -1914,6 +1914,9 @@ __global__ __launch_bounds__(256) void K_asort_scatter(const uint32_t* __restric
 #ifndef OTG_V5_DEFAULT_MASK
 #define OTG_V5_DEFAULT_MASK 0
 #endif
+#ifndef OTG_V5_DEFAULT_SHAPE
+#define OTG_V5_DEFAULT_SHAPE 0
+#endif
 constexpr int V5_TIERS = 4;                                         // pair-slots 8 / 12 / 16 (one wave each): windows of 1024 / 1536 / 2048 diagonals; 4 waves x 8: 4096
 constexpr int TSORT_BUCKETS = (V5_TIERS + 1) * ASORT_BUCKETS;       // last tier = everything else (LDS / HBM tiers)
 __device__ __forceinline__ int v5_tier(const otg_align_task& t, int U, int mask)
@@ -2167,22 +2170,30 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
           (void)units;
           return w;
         };
-        const uint32_t b0 = (v5_mask & 1) ? (uint32_t)ctx->n_cu * 4 : 0, b1 = (v5_mask & 2) ? (uint32_t)ctx->n_cu * 3 : 0, b2 = (v5_mask & 4) ? (uint32_t)ctx->n_cu * 2 : 0,
-                       b3 = (v5_mask & 8) ? (uint32_t)ctx->n_cu * 4 : 0;          // blocks; tiers 0-2 run four alignments per block, tier 3 one
-        AffWs w0 = v5_ws(1024, b0 * 4), w1 = v5_ws(1536, b1 * 4), w2 = v5_ws(2048, b2 * 4), w3 = v5_ws(4096, b3);
-        const size_t need5 = w0.stride * b0 * 4 + w1.stride * b1 * 4 + w2.stride * b2 * 4 + w3.stride * b3 + 256;
+        // tier shapes: waves per alignment x pair-slots per wave (experiment switch OTG_V5_SHAPE = four digits, one per tier, 0 = the first shape)
+        static const int shape = getenv("OTG_V5_SHAPE") ? atoi(getenv("OTG_V5_SHAPE")) : OTG_V5_DEFAULT_SHAPE;
+        const int sh0 = (shape / 1000) % 10, sh1 = (shape / 100) % 10, sh2 = (shape / 10) % 10, sh3 = shape % 10;
+        // alignments in flight per tier (blocks x alignments per block) size the workspaces
+        const uint32_t ncu = (uint32_t)ctx->n_cu;
+        const uint32_t bl0 = !(v5_mask & 1) ? 0 : (sh0 == 0 ? ncu * 4 : ncu * 8), al0 = sh0 == 0 ? bl0 * 4 : bl0;
+        const uint32_t bl1 = !(v5_mask & 2) ? 0 : (sh1 == 0 ? ncu * 3 : ncu * 8), al1 = sh1 == 0 ? bl1 * 4 : bl1;
+        const uint32_t bl2 = !(v5_mask & 4) ? 0 : (sh2 == 0 ? ncu * 2 : (sh2 == 1 ? ncu * 8 : ncu * 4)), al2 = sh2 == 0 ? bl2 * 4 : bl2;
+        const uint32_t bl3 = !(v5_mask & 8) ? 0 : (sh3 == 0 ? ncu * 4 : ncu * 2), al3 = bl3;
+        AffWs w0 = v5_ws(1024, al0), w1 = v5_ws(1536, al1), w2 = v5_ws(2048, al2), w3 = v5_ws(4096, al3);
+        const size_t need5 = w0.stride * al0 + w1.stride * al1 + w2.stride * al2 + w3.stride * al3 + 256;
         uint8_t* ws5 = (uint8_t*)otg_slot(ctx, SLOT_REVOPS, need5);
         if (!ws5) return OTG_ERR_HIP;
-        w0.base = ws5; w1.base = w0.base + w0.stride * b0 * 4; w2.base = w1.base + w1.stride * b1 * 4; w3.base = w2.base + w2.stride * b2 * 4;
+        w0.base = ws5; w1.base = w0.base + w0.stride * al0; w2.base = w1.base + w1.stride * al1; w3.base = w2.base + w2.stride * al2;
         unsigned long long* vis = ctx->affine_visited;
-        if (b0) hipLaunchKernelGGL((wfa_affine_kernel_v5<1, 8, 4096, 4>), dim3(b0), dim3(256), 0, ctx->stream, d_arena, d_tasks, (const uint32_t*)sorted, (const uint32_t*)(seg + 0), g,
-                                   d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, cnt + 72, n_ovf5, ovf5, w0, (const int32_t*)d_bound, vis);
-        if (b1) hipLaunchKernelGGL((wfa_affine_kernel_v5<1, 12, 4608, 3>), dim3(b1), dim3(256), 0, ctx->stream, d_arena, d_tasks, (const uint32_t*)sorted, (const uint32_t*)(seg + 1), g,
-                                   d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, cnt + 73, n_ovf5, ovf5, w1, (const int32_t*)d_bound, vis);
-        if (b2) hipLaunchKernelGGL((wfa_affine_kernel_v5<1, 16, 6144, 2>), dim3(b2), dim3(256), 0, ctx->stream, d_arena, d_tasks, (const uint32_t*)sorted, (const uint32_t*)(seg + 2), g,
-                                   d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, cnt + 74, n_ovf5, ovf5, w2, (const int32_t*)d_bound, vis);
-        if (b3) hipLaunchKernelGGL((wfa_affine_kernel_v5<4, 8, 8192, 4>), dim3(b3), dim3(256), 0, ctx->stream, d_arena, d_tasks, (const uint32_t*)sorted, (const uint32_t*)(seg + 3), g,
-                                   d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, cnt + 75, n_ovf5, ovf5, w3, (const int32_t*)d_bound, vis);
+#define OTG_V5_LAUNCH(NWV, S2V, SEQV, WPEUV, BLOCKS, SEGI, TICK, WS)                                                                      \
+        hipLaunchKernelGGL((wfa_affine_kernel_v5<NWV, S2V, SEQV, WPEUV>), dim3(BLOCKS), dim3(NWV == 1 ? 256 : NWV * 64), 0, ctx->stream, d_arena, d_tasks, \
+                           (const uint32_t*)sorted, (const uint32_t*)(seg + SEGI), g, d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, cnt + TICK, n_ovf5, ovf5, \
+                           WS, (const int32_t*)d_bound, vis)
+        if (bl0) { if (sh0 == 0) OTG_V5_LAUNCH(1, 8, 4096, 4, bl0, 0, 72, w0); else OTG_V5_LAUNCH(2, 4, 4096, 4, bl0, 0, 72, w0); }
+        if (bl1) { if (sh1 == 0) OTG_V5_LAUNCH(1, 12, 4608, 3, bl1, 1, 73, w1); else OTG_V5_LAUNCH(2, 6, 4608, 4, bl1, 1, 73, w1); }
+        if (bl2) { if (sh2 == 0) OTG_V5_LAUNCH(1, 16, 6144, 2, bl2, 2, 74, w2); else if (sh2 == 1) OTG_V5_LAUNCH(2, 8, 6144, 4, bl2, 2, 74, w2); else OTG_V5_LAUNCH(4, 4, 6144, 4, bl2, 2, 74, w2); }
+        if (bl3) { if (sh3 == 0) OTG_V5_LAUNCH(4, 8, 8192, 4, bl3, 3, 75, w3); else OTG_V5_LAUNCH(8, 4, 8192, 4, bl3, 3, 75, w3); }
+#undef OTG_V5_LAUNCH
         inS = ovf5; inS_n = n_ovf5; inS_imm = 0;
       } else if (!no_asort) {
         uint32_t* hist = (uint32_t*)otg_slot(ctx, SLOT_ROWTAB, ASORT_BUCKETS * sizeof(uint32_t));
