@@ -1912,12 +1912,12 @@ __global__ __launch_bounds__(256) void K_asort_scatter(const uint32_t* __restric
 // ---- register-resident tiers (v5): which tier takes an alignment follows from its score bound and shape alone — the same window
 // arithmetic as the kernel — so one counting sort on (tier, bound) hands every tier its own list, longest alignments first
 #ifndef OTG_V5_DEFAULT_MASK
-#define OTG_V5_DEFAULT_MASK 0
+#define OTG_V5_DEFAULT_MASK 25     /* measured: the one-wave 1024 tier (1), the four-wave 4096 tier (8) and the eight-wave 8192 tier (16) beat the LDS tiers; 1536 / 2048 do not */
 #endif
 #ifndef OTG_V5_DEFAULT_SHAPE
 #define OTG_V5_DEFAULT_SHAPE 0
 #endif
-constexpr int V5_TIERS = 4;                                         // pair-slots 8 / 12 / 16 (one wave each): windows of 1024 / 1536 / 2048 diagonals; 4 waves x 8: 4096
+constexpr int V5_TIERS = 5;                                         // pair-slots 8 / 12 / 16 (one wave each): windows of 1024 / 1536 / 2048 diagonals; 4 waves x 8: 4096; 8 waves x 8: 8192
 constexpr int TSORT_BUCKETS = (V5_TIERS + 1) * ASORT_BUCKETS;       // last tier = everything else (LDS / HBM tiers)
 __device__ __forceinline__ int v5_tier(const otg_align_task& t, int U, int mask)
 {
@@ -1937,6 +1937,7 @@ __device__ __forceinline__ int v5_tier(const otg_align_task& t, int U, int mask)
   if ((mask & 4) && need < 2048 && seqb <= 6144) return 2;
   // the multi-wave tier takes what the smaller LDS tiers cannot (their windows end at 2048 diagonals)
   if ((mask & 8) && need < 4096 && seqb <= 8192 && (need >= 2048 || seqb > 3072 || (mask & 7))) return 3;
+  if ((mask & 16) && need < 8192 && seqb <= 12288 && (need >= 4096 || seqb > 6144 || (mask & 8))) return 4;
   return V5_TIERS;
 }
 __device__ __forceinline__ int tsort_bucket(const otg_align_task& t, int U, int mask) { return v5_tier(t, U, mask) * ASORT_BUCKETS + asort_bucket(U); }
@@ -2141,7 +2142,9 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
       const uint32_t* inS = d_todo; const uint32_t* inS_n = d_n_todo; uint32_t inS_imm = n_tasks;
       static const bool no_asort = getenv("OTG_NO_AFFINE_SORT") != nullptr;
       // register-resident tiers (bit mask: 1 / 2 / 4 = the one-wave tiers of 1024 / 1536 / 2048 diagonals, 8 = the four-wave tier of 4096)
-      static const int v5_mask = getenv("OTG_AFFINE_V5") ? atoi(getenv("OTG_AFFINE_V5")) : OTG_V5_DEFAULT_MASK;
+      static const int v5_mask_env = getenv("OTG_AFFINE_V5") ? atoi(getenv("OTG_AFFINE_V5")) : OTG_V5_DEFAULT_MASK;
+      // the 8192 tier only when the batch can need it (reads beyond 4 kb): its slabs are the largest.  The sort sees the mask of the tiers that run.
+      const int v5_mask = maxlen <= 4096 ? (v5_mask_env & ~16) : v5_mask_env;
       const bool no_v5 = v5_mask == 0;
       if (!no_v5) {
         // one counting sort on (tier, bound) gives each tier its list; what no tier takes (or a tier gives up) is the input of the LDS / HBM tiers below
@@ -2149,7 +2152,7 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
         uint32_t* sorted = todo + 6 * (size_t)n_tasks;
         uint32_t* ovf5 = todo + 7 * (size_t)n_tasks;
         uint32_t* seg = cnt + 64;               // seg[0 .. V5_TIERS + 1]
-        uint32_t* n_ovf5 = cnt + 70;
+        uint32_t* n_ovf5 = cnt + 71;
         if (!hist) return OTG_ERR_HIP;
         HIP_TRY(ctx, hipMemsetAsync(hist, 0, TSORT_BUCKETS * sizeof(uint32_t), ctx->stream));
         const uint32_t sg = std::min<uint32_t>((n_tasks + 2047) / 2048, (uint32_t)ctx->n_cu * 2);
@@ -2179,11 +2182,13 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
         const uint32_t bl1 = !(v5_mask & 2) ? 0 : (sh1 == 0 ? ncu * 3 : ncu * 8), al1 = sh1 == 0 ? bl1 * 4 : bl1;
         const uint32_t bl2 = !(v5_mask & 4) ? 0 : (sh2 == 0 ? ncu * 2 : (sh2 == 1 ? ncu * 8 : ncu * 4)), al2 = sh2 == 0 ? bl2 * 4 : bl2;
         const uint32_t bl3 = !(v5_mask & 8) ? 0 : (sh3 == 0 ? ncu * 4 : ncu * 2), al3 = bl3;
-        AffWs w0 = v5_ws(1024, al0), w1 = v5_ws(1536, al1), w2 = v5_ws(2048, al2), w3 = v5_ws(4096, al3);
-        const size_t need5 = w0.stride * al0 + w1.stride * al1 + w2.stride * al2 + w3.stride * al3 + 256;
+        const uint32_t bl4 = !(v5_mask & 16) ? 0 : ncu * 2, al4 = bl4;
+        AffWs w0 = v5_ws(1024, al0), w1 = v5_ws(1536, al1), w2 = v5_ws(2048, al2), w3 = v5_ws(4096, al3), w4 = v5_ws(8192, al4);
+        w4.slab_bytes = std::min<size_t>(w4.slab_bytes, ((size_t)(0.2 * (double)maxlen * (double)maxlen) + (1 << 20)) & ~(size_t)255); w4.stride = w4.off_slab + w4.slab_bytes;
+        const size_t need5 = w0.stride * al0 + w1.stride * al1 + w2.stride * al2 + w3.stride * al3 + w4.stride * al4 + 256;
         uint8_t* ws5 = (uint8_t*)otg_slot(ctx, SLOT_REVOPS, need5);
         if (!ws5) return OTG_ERR_HIP;
-        w0.base = ws5; w1.base = w0.base + w0.stride * al0; w2.base = w1.base + w1.stride * al1; w3.base = w2.base + w2.stride * al2;
+        w0.base = ws5; w1.base = w0.base + w0.stride * al0; w2.base = w1.base + w1.stride * al1; w3.base = w2.base + w2.stride * al2; w4.base = w3.base + w3.stride * al3;
         unsigned long long* vis = ctx->affine_visited;
 #define OTG_V5_LAUNCH(NWV, S2V, SEQV, WPEUV, BLOCKS, SEGI, TICK, WS)                                                                      \
         hipLaunchKernelGGL((wfa_affine_kernel_v5<NWV, S2V, SEQV, WPEUV>), dim3(BLOCKS), dim3(NWV == 1 ? 256 : NWV * 64), 0, ctx->stream, d_arena, d_tasks, \
@@ -2193,6 +2198,7 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
         if (bl1) { if (sh1 == 0) OTG_V5_LAUNCH(1, 12, 4608, 3, bl1, 1, 73, w1); else OTG_V5_LAUNCH(2, 6, 4608, 4, bl1, 1, 73, w1); }
         if (bl2) { if (sh2 == 0) OTG_V5_LAUNCH(1, 16, 6144, 2, bl2, 2, 74, w2); else if (sh2 == 1) OTG_V5_LAUNCH(2, 8, 6144, 4, bl2, 2, 74, w2); else OTG_V5_LAUNCH(4, 4, 6144, 4, bl2, 2, 74, w2); }
         if (bl3) { if (sh3 == 0) OTG_V5_LAUNCH(4, 8, 8192, 4, bl3, 3, 75, w3); else OTG_V5_LAUNCH(8, 4, 8192, 4, bl3, 3, 75, w3); }
+        if (bl4) OTG_V5_LAUNCH(8, 8, 12288, 4, bl4, 4, 76, w4);
 #undef OTG_V5_LAUNCH
         inS = ovf5; inS_n = n_ovf5; inS_imm = 0;
       } else if (!no_asort) {
@@ -2249,8 +2255,8 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
     HIP_TRY(ctx, hipMemcpy(h, cnt, sizeof(h), hipMemcpyDeviceToHost));
     fprintf(stderr, "[otg] affine: LDS tiers overflow %u / %u, tier A overflow %u, tier B overflow %u\n", h[25], h[27], h[9], h[11]);
     { uint32_t h5[8]; HIP_TRY(ctx, hipMemcpy(h5, cnt + 64, sizeof(h5), hipMemcpyDeviceToHost));
-      fprintf(stderr, "[otg] affine: register tiers take %u / %u / %u / %u alignments, %u go to the LDS tiers (of which given up by a register tier: %u)\n",
-              h5[1] - h5[0], h5[2] - h5[1], h5[3] - h5[2], h5[4] - h5[3], h5[6], h5[6] - (h5[5] - h5[4])); }
+      fprintf(stderr, "[otg] affine: register tiers take %u / %u / %u / %u / %u alignments, %u go to the LDS tiers (of which given up by a register tier: %u)\n",
+              h5[1] - h5[0], h5[2] - h5[1], h5[3] - h5[2], h5[4] - h5[3], h5[5] - h5[4], h5[7], h5[7] - (h5[6] - h5[5])); }
     {
       unsigned long long vc[2] = {0, 0};
       HIP_TRY(ctx, hipMemcpyFromSymbol(vc, HIP_SYMBOL(otg_dbg_v4_cells), sizeof(vc)));
