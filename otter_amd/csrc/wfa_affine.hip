@@ -1935,9 +1935,9 @@ __device__ __forceinline__ int v5_tier(const otg_align_task& t, int U, int mask)
   if ((mask & 1) && need < 1024 && seqb <= 4096) return 0;
   if ((mask & 2) && need < 1536 && seqb <= 4608) return 1;
   if ((mask & 4) && need < 2048 && seqb <= 6144) return 2;
-  // the multi-wave tier takes what the smaller LDS tiers cannot (their windows end at 2048 diagonals)
-  if ((mask & 8) && need < 4096 && seqb <= 8192 && (need >= 2048 || seqb > 3072 || (mask & 7))) return 3;
-  if ((mask & 16) && need < 8192 && seqb <= 12288 && (need >= 4096 || seqb > 6144 || (mask & 8))) return 4;
+  // the multi-wave tiers take what lies beyond the smaller windows (those stay with the one-wave / LDS tiers, which are faster on narrow rows)
+  if ((mask & 8) && need < 4096 && seqb <= 8192 && (need >= 2048 || seqb > 3072)) return 3;
+  if ((mask & 16) && need < 8192 && seqb <= 12288 && (need >= 4096 || seqb > 8192)) return 4;
   return V5_TIERS;
 }
 __device__ __forceinline__ int tsort_bucket(const otg_align_task& t, int U, int mask) { return v5_tier(t, U, mask) * ASORT_BUCKETS + asort_bucket(U); }
