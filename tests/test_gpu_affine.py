@@ -135,14 +135,14 @@ def test_affine_non_acgt_bytes(gpu, oracle):
 
 
 def test_affine_lds_tier_admission_sweep(gpu, oracle):
-    """Alignments whose score bound sits right at the admission limit of each LDS tier (windows of 1024 / 1472 / 2048 /
-    4096 diagonals): one long gap (reduced score = gap length + 3) or two gaps in opposite directions, early and late
+    """Alignments whose score bound sits right at the admission limit of each tier (LDS tiers: windows of 1024 / 1472 / 2048 / 4096
+    diagonals; register tiers: 1024 / 1536 / 2048 / 4096 / 8192): one long gap (reduced score = gap length + 3) or two gaps in opposite directions, early and late
     in the sequence.  Whether such an alignment is admitted to a tier or passed on, op string and score must match."""
     rng = np.random.default_rng(27)
     pairs = []
     L = 900
     core = rand_seq(rng, L)
-    for cap in (1024, 1472, 2048, 4096):
+    for cap in (1024, 1472, 1536, 2048, 4096, 8192):
         for G in list(range(cap - 26, cap + 5, 3)):
             for pos in (120, L - 120):
                 a = core[:pos] + rand_seq(rng, G) + core[pos:]
@@ -161,12 +161,14 @@ def test_affine_lds_tier_admission_sweep(gpu, oracle):
 
 
 def test_affine_packed_sequence_capacity_sweep(gpu, oracle):
-    """The LDS tiers hold both sequences packed to 2 bits per base in a fixed slice (2304 / 2688 / 3072 bytes): near-identical
-    pairs whose combined length crosses each capacity (about 9.1, 10.6 and 12.1 kb) must be admitted or passed on cleanly."""
+    """The LDS and register tiers hold both sequences packed to 2 bits per base in a fixed slice (2304 / 2688 / 3072 / 6144 bytes; 4096 /
+    4608 / 6144 / 8192 / 12288 bytes): near-identical pairs whose combined length crosses each capacity (about 9.1, 10.6, 12.1, 16.3, 18.3,
+    24.4, 32.6 and 49 kb) must be admitted or passed on cleanly."""
     rng = np.random.default_rng(28)
-    base = rand_seq(rng, 6400)
+    base = rand_seq(rng, 24800)
     pairs = []
-    for tot in list(range(9000, 9260, 20)) + list(range(10520, 10780, 20)) + list(range(12060, 12330, 20)):
+    for tot in (list(range(9000, 9260, 20)) + list(range(10520, 10780, 20)) + list(range(12060, 12330, 20)) + list(range(16240, 16440, 20)) +
+                list(range(18300, 18460, 20)) + list(range(24400, 24620, 20)) + list(range(32600, 32800, 20)) + list(range(48960, 49200, 30))):
         la = tot // 2 + int(rng.integers(-40, 41))
         lb = tot - la
         a = bytearray(base[:la]); b = bytearray(base[:lb])

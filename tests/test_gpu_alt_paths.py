@@ -13,6 +13,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = [
     ("OTG_NO_AFFINE_BOUND", ["tests/test_gpu_affine.py"]),
     ("OTG_NO_AFFINE_V4", ["tests/test_gpu_affine.py"]),
+    ("OTG_AFFINE_V5=0", ["tests/test_gpu_affine.py"]),                                   # LDS / HBM tiers only
+    ("OTG_AFFINE_V5=31", ["tests/test_gpu_affine.py", "tests/test_gpu_poa.py"]),         # every register tier (one-wave 1024 / 1536 / 2048, four- and eight-wave)
+    ("OTG_AFFINE_V5=31 OTG_V5_SHAPE=1121", ["tests/test_gpu_affine.py"]),                # the multi-wave shapes of the small tiers
+    ("OTG_AFFINE_V5=31 OTG_NO_AFFINE_V4=1", ["tests/test_gpu_affine.py"]),               # register tiers in front of the HBM-row tiers
     ("OTG_AFFINE_BOUND_STATIC", ["tests/test_gpu_affine.py"]),
     ("OTG_NO_AFFINE_SORT", ["tests/test_gpu_affine.py::test_affine_small_mixed", "tests/test_gpu_affine.py::test_affine_long_ont"]),
     ("OTG_NO_MYERS", ["tests/test_gpu_edit.py::test_edit_small_mixed", "tests/test_gpu_edit.py::test_edit_long_ont"]),
@@ -24,10 +28,12 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("switch,targets", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("switch,targets", CASES, ids=[c[0].replace(" ", "+") for c in CASES])
 def test_alternative_path(gpu, switch, targets):
     env = dict(os.environ)
-    env[switch] = "1"
+    for kv in switch.split():
+        k, _, v = kv.partition("=")
+        env[k] = v or "1"
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"] + targets,
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (switch, r.stdout[-2000:], r.stderr[-1000:])
