@@ -74,6 +74,10 @@ void otg_params_default(otg_params* p);
 /* ---------------------------------------------------------------- context */
 int         otg_create(int device, otg_ctx** out);
 void        otg_destroy(otg_ctx* ctx);
+/* Gives the aligners' scratch workspaces (provenance slabs, row tables: tens of GB once long reads have been seen) back to the device;
+ * the next call that needs them allocates them again.  Resident batches and results are untouched.  For hosts that share a device
+ * between contexts or processes; the reference has no counterpart (its aligners own host memory, src/assemble.cpp:45-50).          */
+int         otg_trim(otg_ctx* ctx);
 const char* otg_last_error(otg_ctx* ctx);     /* ctx may be NULL: last global error           */
 int         otg_device_count(void);           /* number of visible HIP devices (0 if none)    */
 /* Which libm exp() rounding variant the device KDE mirrors (1 = glibc FMA build, 0 = non-FMA).

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libotter_gpu.so")
 
 EXPORTS = [
-    "otg_params_default", "otg_create", "otg_destroy", "otg_last_error", "otg_device_count", "otg_exp_variant",
+    "otg_params_default", "otg_create", "otg_destroy", "otg_trim", "otg_last_error", "otg_device_count", "otg_exp_variant",
     "otg_edit_distance_batch", "otg_affine_align_batch", "otg_cluster_batch", "otg_poa_consensus_batch",
     "otg_genotype_cluster_batch", "otg_assemble_submit", "otg_assemble_run", "otg_assemble_result_sizes",
     "otg_assemble_collect", "otg_assemble_device_results", "otg_assemble_stats", "otg_assemble_realign", "otg_assemble_collect_reads",
@@ -47,6 +47,7 @@ def load():
         _lib.otg_last_error.argtypes = [C.c_void_p]
         _lib.otg_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
         _lib.otg_destroy.argtypes = [C.c_void_p]
+        _lib.otg_trim.argtypes = [C.c_void_p]
     return _lib
 
 
@@ -68,6 +69,10 @@ class Context:
         if getattr(self, "_h", None):
             self._L.otg_destroy(self._h)
             self._h = None
+
+    def trim(self):
+        """Release the aligners' scratch workspaces (otg_trim); they come back with the next call that needs them."""
+        self._check(self._L.otg_trim(self._h), "otg_trim")
 
     def __del__(self):
         try:

@@ -24,8 +24,11 @@ void* otg_slot(otg_ctx* ctx, int slot, size_t bytes)
   DevBuf& b = ctx->pool[slot];
   if (b.cap >= bytes) return b.p;
   if (b.p) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
-  size_t want = bytes + (bytes >> 2) + 256;            // 25 % headroom: a slightly larger batch must not cost a hipFree + hipMalloc
+  // 25 % headroom (at most 1 GB): a slightly larger batch must not cost a hipFree + hipMalloc; the multi-gigabyte kernel workspaces are
+  // sized independently of the batch by their callers and need none
+  size_t want = bytes + std::min<size_t>(bytes >> 2, (size_t)1 << 30) + 256;
   hipError_t e = hipMalloc(&b.p, want);
+  if (e != hipSuccess && want > bytes) { (void)hipGetLastError(); want = bytes; e = hipMalloc(&b.p, want); }
   if (e != hipSuccess) {
     otg_fail(ctx, OTG_ERR_HIP, "hipMalloc(%zu bytes, slot %d) failed: %s", want, slot, hipGetErrorString(e));
     b.p = nullptr;
@@ -109,6 +112,19 @@ void otg_destroy(otg_ctx* ctx)
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
+}
+
+int otg_trim(otg_ctx* ctx)
+{
+  if (!ctx) return otg_fail(nullptr, OTG_ERR_NO_DEVICE, "otg_trim: no context");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  // the aligners' per-launch workspaces (provenance slabs, row tables, op lists): nothing in them outlives a call
+  for (int slot : {SLOT_WF_WS, SLOT_REVOPS, SLOT_BT_POOL}) {
+    DevBuf& b = ctx->pool[slot];
+    if (b.p) { HIP_TRY(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+  }
+  return OTG_OK;
 }
 
 int otg_exp_variant(otg_ctx* ctx) { return ctx ? ctx->exp_variant : -1; }

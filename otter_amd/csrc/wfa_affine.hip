@@ -2181,11 +2181,16 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
         const uint32_t bl0 = !(v5_mask & 1) ? 0 : (sh0 == 0 ? ncu * 4 : ncu * 8), al0 = sh0 == 0 ? bl0 * 4 : bl0;
         const uint32_t bl1 = !(v5_mask & 2) ? 0 : (sh1 == 0 ? ncu * 3 : ncu * 8), al1 = sh1 == 0 ? bl1 * 4 : bl1;
         const uint32_t bl2 = !(v5_mask & 4) ? 0 : (sh2 == 0 ? ncu * 2 : (sh2 == 1 ? ncu * 8 : ncu * 4)), al2 = sh2 == 0 ? bl2 * 4 : bl2;
-        const uint32_t bl3 = !(v5_mask & 8) ? 0 : (sh3 == 0 ? ncu * 4 : ncu * 2), al3 = bl3;
-        const uint32_t bl4 = !(v5_mask & 16) ? 0 : ncu * 2, al4 = bl4;
+        uint32_t bl3 = !(v5_mask & 8) ? 0 : (sh3 == 0 ? ncu * 4 : ncu * 2), al3 = bl3;
+        uint32_t bl4 = !(v5_mask & 16) ? 0 : ncu * 2, al4 = bl4;
         AffWs w0 = v5_ws(1024, al0), w1 = v5_ws(1536, al1), w2 = v5_ws(2048, al2), w3 = v5_ws(4096, al3), w4 = v5_ws(8192, al4);
         w4.slab_bytes = std::min<size_t>(w4.slab_bytes, ((size_t)(0.2 * (double)maxlen * (double)maxlen) + (1 << 20)) & ~(size_t)255); w4.stride = w4.off_slab + w4.slab_bytes;
-        const size_t need5 = w0.stride * al0 + w1.stride * al1 + w2.stride * al2 + w3.stride * al3 + w4.stride * al4 + 256;
+        // the same share of the device as the tiers behind: beyond it the two widest tiers keep fewer alignments in flight (reads beyond ~16 kb only)
+        auto total5 = [&]() { return w0.stride * al0 + w1.stride * al1 + w2.stride * al2 + w3.stride * al3 + w4.stride * al4 + 256; };
+        while (total5() > budget && (bl4 > ncu / 4 || bl3 > ncu / 2)) {
+          if (bl4 > ncu / 4 && (w4.stride * al4 >= w3.stride * al3 || bl3 <= ncu / 2)) { bl4 /= 2; al4 = bl4; } else { bl3 /= 2; al3 = bl3; }
+        }
+        const size_t need5 = total5();
         uint8_t* ws5 = (uint8_t*)otg_slot(ctx, SLOT_REVOPS, need5);
         if (!ws5) return OTG_ERR_HIP;
         w0.base = ws5; w1.base = w0.base + w0.stride * al0; w2.base = w1.base + w1.stride * al1; w3.base = w2.base + w2.stride * al2; w4.base = w3.base + w3.stride * al3;

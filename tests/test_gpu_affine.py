@@ -33,8 +33,9 @@ def test_affine_small_mixed(gpu, oracle):
     arena, tasks = pair_tasks(pairs, forms)
     gs, gc, gcells = gpu.affine_align_batch(arena, tasks, want_cells=True)
     es, ec, ecells = oracle.affine_align_batch(arena, tasks, want_cells=True)
-    assert np.array_equal(gs, es)
-    assert gc == ec
+    assert np.array_equal(gs, es), [(i, int(gs[i]), int(es[i]), len(pairs[i][0]), len(pairs[i][1])) for i in np.flatnonzero(gs != es)[:8]]
+    bad = [(i, len(pairs[i][0]), len(pairs[i][1])) for i in range(len(pairs)) if gc[i] != ec[i]]
+    assert not bad, bad[:8]
     assert np.array_equal(gcells, ecells)
 
 
@@ -60,8 +61,9 @@ def test_affine_long_ont(gpu, oracle):
     arena, tasks = pair_tasks(pairs)
     gs, gc = gpu.affine_align_batch(arena, tasks)
     es, ec = oracle.affine_align_batch(arena, tasks)
-    assert np.array_equal(gs, es)
-    assert gc == ec
+    assert np.array_equal(gs, es), [(i, int(gs[i]), int(es[i]), len(pairs[i][0]), len(pairs[i][1])) for i in np.flatnonzero(gs != es)[:8]]
+    bad = [(i, len(pairs[i][0]), len(pairs[i][1])) for i in range(len(pairs)) if gc[i] != ec[i]]
+    assert not bad, bad[:8]
 
 
 def test_affine_cigar_valid_full_size(gpu, oracle):
@@ -129,8 +131,9 @@ def test_affine_non_acgt_bytes(gpu, oracle):
     arena, tasks = pair_tasks(pairs, forms)
     gs, gc, gcells = gpu.affine_align_batch(arena, tasks, want_cells=True)
     es, ec, ecells = oracle.affine_align_batch(arena, tasks, want_cells=True)
-    assert np.array_equal(gs, es)
-    assert gc == ec
+    assert np.array_equal(gs, es), [(i, int(gs[i]), int(es[i]), len(pairs[i][0]), len(pairs[i][1])) for i in np.flatnonzero(gs != es)[:8]]
+    bad = [(i, len(pairs[i][0]), len(pairs[i][1])) for i in range(len(pairs)) if gc[i] != ec[i]]
+    assert not bad, bad[:8]
     assert np.array_equal(gcells, ecells)
 
 
@@ -180,5 +183,6 @@ def test_affine_packed_sequence_capacity_sweep(gpu, oracle):
     arena, tasks = pair_tasks(pairs)
     gs, gc = gpu.affine_align_batch(arena, tasks)
     es, ec = oracle.affine_align_batch(arena, tasks)
-    assert np.array_equal(gs, es)
-    assert gc == ec
+    assert np.array_equal(gs, es), [(i, int(gs[i]), int(es[i]), len(pairs[i][0]), len(pairs[i][1])) for i in np.flatnonzero(gs != es)[:8]]
+    bad = [(i, len(pairs[i][0]), len(pairs[i][1])) for i in range(len(pairs)) if gc[i] != ec[i]]
+    assert not bad, bad[:8]

@@ -30,10 +30,18 @@ CASES = [
 
 @pytest.mark.parametrize("switch,targets", CASES, ids=[c[0].replace(" ", "+") for c in CASES])
 def test_alternative_path(gpu, switch, targets):
+    gpu.trim()          # the session context's aligner workspaces (tens of GB after the long-read tests): the child needs the room
     env = dict(os.environ)
     for kv in switch.split():
         k, _, v = kv.partition("=")
         env[k] = v or "1"
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"] + targets,
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, (switch, r.stdout[-2000:], r.stderr[-1000:])
+    if r.returncode != 0:       # the whole output of the child, where a GPU box run leaves it behind
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "alt_path_%s.log" % switch.replace(" ", "+").replace("=", "-")), "w") as f:
+                f.write(r.stdout + "\n---- stderr ----\n" + r.stderr)
+        except OSError:
+            pass
+    assert r.returncode == 0, (switch, r.stdout[-3000:], r.stderr[-1000:])
