@@ -1409,6 +1409,10 @@ __device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b)
 }
 __device__ __forceinline__ int lo16s(uint32_t w) { return (int)(int16_t)(w & 0xffffu); }
 __device__ __forceinline__ int hi16s(uint32_t w) { return (int)w >> 16; }
+__device__ __forceinline__ uint64_t v5_uniform64(uint64_t x)
+{
+  return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(x >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
+}
 __device__ __forceinline__ uint32_t pack16(int lo, int hi) { return __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u); }   // {lo16: lo, hi16: hi}
 
 // NW > 1: NW waves share ONE alignment whose window is NW x S2 pair-slots wide.  Pair-slot g belongs to wave g % NW (cyclic, so the touched
@@ -1466,8 +1470,16 @@ __global__ __launch_bounds__(NW == 1 ? 256 : NW * 64, WPEU) void wfa_affine_kern
       tk = (uint32_t)MISC[0];
     } else tk = otg_wave_atomic_add(ticket, 1u);
     if (tk >= n_todo) break;
-    const uint32_t ti = todo[seg0 + tk];
-    const otg_align_task t = tasks[ti];
+    // The descriptor is wave-uniform and must live in SGPRs: everything the score loop branches on derives from it.  Whether hipcc turns
+    // these loads into scalar loads depends on the size of the instantiation (its clobber walk over the persistent loop gives up on the
+    // 12- and 16-slot bodies, and the whole score loop then runs on vector compares and exec masks), so every field is pinned explicitly.
+    const uint32_t ti = (uint32_t)__builtin_amdgcn_readfirstlane((int)todo[seg0 + tk]);
+    otg_align_task t = tasks[ti];
+    t.pattern_off = v5_uniform64(t.pattern_off); t.text_off = v5_uniform64(t.text_off);
+    t.pattern_len = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.pattern_len); t.text_len = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.text_len);
+    t.pattern_begin_free = __builtin_amdgcn_readfirstlane(t.pattern_begin_free); t.pattern_end_free = __builtin_amdgcn_readfirstlane(t.pattern_end_free);
+    t.text_begin_free = __builtin_amdgcn_readfirstlane(t.text_begin_free); t.text_end_free = __builtin_amdgcn_readfirstlane(t.text_end_free);
+    t.endsfree = __builtin_amdgcn_readfirstlane(t.endsfree);
     const uint8_t* P = arena + t.pattern_off;
     const uint8_t* T = arena + t.text_off;
     const int pl = (int)t.pattern_len, tl = (int)t.text_len;
@@ -1701,7 +1713,9 @@ __global__ __launch_bounds__(NW == 1 ? 256 : NW * 64, WPEU) void wfa_affine_kern
         static_for<0, S2>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value;
           const int gi = NW == 1 ? i : i * NW + ww;
           if (NW == 1 && gi + 1 == j0) {           // the slot left of the first touched one: its lane 63 is the left neighbour of the sweep
-            carryL = (uint32_t)__builtin_amdgcn_readlane((int)pack16(lo16s(MC[0][i][1]), lo16s(ID[i][1])), 63);
+            // (packed on the scalar side: a vector pack here is hoisted above the branch and then paid by every untouched slot)
+            const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)MC[0][i][1], 63), b = (uint32_t)__builtin_amdgcn_readlane((int)ID[i][1], 63);
+            carryL = (a & 0xffffu) | (b << 16);
           }
           if (gi < j0 || gi > j1) return;
           const uint32_t mE = MC[0][i][0], mO = MC[0][i][1], dE = ID[i][0], dO = ID[i][1];
@@ -1709,7 +1723,10 @@ __global__ __launch_bounds__(NW == 1 ? 256 : NW * 64, WPEU) void wfa_affine_kern
           const uint32_t Rx = pack16(lo16s(mE), hi16s(dE));                               // what the lane to the left needs: {M[s-4][even], D[s-1][even]}
           uint32_t rcar = NN, lcar = carryL;
           if (NW == 1) {
-            if (i + 1 < S2) rcar = (uint32_t)__builtin_amdgcn_readlane((int)pack16(lo16s(MC[0][i + 1][0]), hi16s(ID[i + 1][0])), 0);   // the next pair-slot's lane 0, still old
+            if (i + 1 < S2) {                      // the next pair-slot's lane 0, still old
+              const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)MC[0][i + 1][0], 0), b = (uint32_t)__builtin_amdgcn_readlane((int)ID[i + 1][0], 0);
+              rcar = (a & 0xffffu) | (b & 0xffff0000u);
+            }
           } else {
             lcar = (uint32_t)__builtin_amdgcn_readfirstlane((int)XL[xp + gi]);             // export of slot gi - 1 (entry g + 1 holds slot g)
             rcar = (uint32_t)__builtin_amdgcn_readfirstlane((int)XR[xp + gi + 2]);         // export of slot gi + 1
@@ -1775,6 +1792,28 @@ __global__ __launch_bounds__(NW == 1 ? 256 : NW * 64, WPEU) void wfa_affine_kern
             m = probeO ? m : 0;
             hO += m;
             moreO = probeO && m == 32 && vO + m < pl && hO < tl;
+          }
+          // a second probe where a run outlives the first (one in 120 cells at ONT divergence, i.e. most slot visits have one): the queue, its
+          // drain and the fold-back of the patch table — a fixed cost per score — are then left to runs beyond 64 bases (one slot visit in 100)
+          if (__ballot(moreE || moreO)) {
+            {
+              const int v2 = hE - kE;
+              const uint64_t xx = ld32b(0, moreE ? v2 : 0) ^ ld32b(offT, moreE ? hE : 0);
+              int m = xx ? (int)(__builtin_ctzll(xx) >> 1) : 32;
+              m = imin(m, imin(pl - v2, tl - hE));
+              m = moreE ? m : 0;
+              hE += m;
+              moreE = moreE && m == 32 && v2 + m < pl && hE < tl;
+            }
+            {
+              const int v2 = hO - kE - 1;
+              const uint64_t xx = ld32b(0, moreO ? v2 : 0) ^ ld32b(offT, moreO ? hO : 0);
+              int m = xx ? (int)(__builtin_ctzll(xx) >> 1) : 32;
+              m = imin(m, imin(pl - v2, tl - hO));
+              m = moreO ? m : 0;
+              hO += m;
+              moreO = moreO && m == 32 && v2 + m < pl && hO < tl;
+            }
           }
           const int sE = validE ? hE : NUL16, sO = validO ? hO : NUL16;
           MC[0][i][0] = (mE >> 16) | ((uint32_t)sE << 16);
@@ -1912,7 +1951,7 @@ __global__ __launch_bounds__(256) void K_asort_scatter(const uint32_t* __restric
 // ---- register-resident tiers (v5): which tier takes an alignment follows from its score bound and shape alone — the same window
 // arithmetic as the kernel — so one counting sort on (tier, bound) hands every tier its own list, longest alignments first
 #ifndef OTG_V5_DEFAULT_MASK
-#define OTG_V5_DEFAULT_MASK 25     /* measured: the one-wave 1024 tier (1), the four-wave 4096 tier (8) and the eight-wave 8192 tier (16) beat the LDS tiers; 1536 / 2048 do not */
+#define OTG_V5_DEFAULT_MASK 27     /* measured: the one-wave 1024 and 1536 tiers (1, 2), the four-wave 4096 tier (8) and the eight-wave 8192 tier (16) beat the LDS tiers; the one-wave 2048 tier (2 waves per SIMD) does not */
 #endif
 #ifndef OTG_V5_DEFAULT_SHAPE
 #define OTG_V5_DEFAULT_SHAPE 0
