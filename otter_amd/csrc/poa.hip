@@ -50,7 +50,13 @@ struct PoaDev {
   unsigned long long* prof;   // OTG_POA_PROFILE: wall-clock ticks per phase, summed over graphs (null otherwise)
   uint32_t* fb_list;          // graphs left to the global-memory kernel by the LDS kernel (outgrew the optimistic capacities)
   uint32_t* fb_count;
+  // second generation of the global-memory path (v2 != 0): per edge its source and its successor in the edge list of its ANCHOR (the backbone
+  // node its subtree of alt nodes hangs off; -1 = subtrees of start nodes), per anchor (index anchor + 1, base node_off[g] + g) that list's
+  // head / tail / length, per alt node its one in-edge
+  int v2;
+  uint32_t* esrc; int32_t* anext; int32_t* ahead; int32_t* atail; uint32_t* acnt; int32_t* inedge;
 };
+struct PoaAux { uint32_t* esrc; int32_t* anext; int32_t* ahead; int32_t* atail; uint32_t* acnt; int32_t* inedge; };
 
 // capacity bounds per member: alt = ops that can create a node (X, I); mrun = 'M' ops not preceded by an 'M' — with the X / I ops the
 // only ones that can create an edge outside the backbone (insert_edge from a non-'M' predecessor, src/anppoa.hpp:96-110)
@@ -104,6 +110,8 @@ template <> struct PoaStore<false> {
   __device__ __forceinline__ void incIndeg(uint32_t i) const { nodes[i].indeg = nodes[i].indeg + 1u; }
   __device__ __forceinline__ void incIndegAtomic(uint32_t i) const { atomicAdd(&nodes[i].indeg, 1u); }
   __device__ __forceinline__ float ldHw(uint32_t i) const { return nodes[i].hw; }
+  __device__ __forceinline__ void stHw(uint32_t i, float w) const { nodes[i].hw = w; }
+  __device__ __forceinline__ void stHwPred(uint32_t i, float w, int pr) const { nodes[i].hw = w; nodes[i].pred = pr; }
   __device__ __forceinline__ int ldPred(uint32_t i) const { return nodes[i].pred; }
   __device__ __forceinline__ EdgeG ldE(int e) const { return edges[e]; }
   __device__ __forceinline__ void stE(int e, const EdgeG& x) const { edges[e] = x; }
@@ -122,6 +130,8 @@ template <> struct PoaStore<true> {
   __device__ __forceinline__ void incIndeg(uint32_t i) const { nodes[i].indeg = (uint16_t)(nodes[i].indeg + 1u); }
   __device__ __forceinline__ void incIndegAtomic(uint32_t i) const { incIndeg(i); }     // not used: the LDS pass is wave-uniform
   __device__ __forceinline__ float ldHw(uint32_t i) const { return nodes[i].hw; }
+  __device__ __forceinline__ void stHw(uint32_t i, float w) const { nodes[i].hw = w; }
+  __device__ __forceinline__ void stHwPred(uint32_t i, float w, int pr) const { nodes[i].hw = w; nodes[i].pred = (int16_t)pr; }
   __device__ __forceinline__ int ldPred(uint32_t i) const { return nodes[i].pred; }
   __device__ __forceinline__ EdgeG ldE(int e) const { EdgeG x; x.sink = edges[e].sink; x.w = (float)edges[e].w; x.next = edges[e].next; x.base = edges[e].base; return x; }
   __device__ __forceinline__ void stE(int e, const EdgeG& x) const { edges[e].sink = (uint16_t)x.sink; edges[e].w = (uint16_t)x.w; edges[e].next = (int16_t)x.next; edges[e].base = (uint16_t)x.base; }
@@ -136,16 +146,69 @@ template <bool LDS> __device__ __forceinline__ void poa_phase_fence()
 }
 
 // returns false when the graph has to be redone with larger capacities (LDS only)
+using lds_u32 = __attribute__((address_space(3))) uint32_t;
+using lds_i32 = __attribute__((address_space(3))) int32_t;
+using lds_f32 = __attribute__((address_space(3))) float;
+struct PoaScratch {          // per-wave LDS of the second-generation path (2.3 KB)
+  volatile lds_u32* ops;     // [256] the chunk's ops: op | target base << 8
+  volatile lds_u32* stage;   // [64]  edge ids of the block being swept
+  volatile lds_f32* hw;      // [128] window of backbone weights ...
+  volatile lds_i32* pred;    // [128] ... and their sources (circular: node v at v & 127)
+};
+
+// exclusive prefix sum over the 64 lanes; *total = the sum (wave-uniform).  DPP row shifts + row broadcasts: no LDS round trips.
+__device__ __forceinline__ uint32_t poa_wave_excl_sum(uint32_t v, int lane, uint32_t* total)
+{
+  (void)lane;
+  int x = (int)v;
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);   // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);   // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);   // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);   // row_shr:8  -> inclusive within each row of 16
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1, 3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2, 3
+  *total = (uint32_t)__builtin_amdgcn_readlane(x, 63);
+  return (uint32_t)x - v;
+}
+// LDS written by some lanes, read by others of the same wave: LDS requests of a wave are served in order, so only the compiler has to keep
+// the order (the accesses are volatile); no wait on the outstanding global loads and stores, which a fence would add
+__device__ __forceinline__ void poa_lds_order() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+__device__ __forceinline__ float poa_readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+// Second generation (global-memory instantiation, `v2`): the two serial phases of the first are reorganised around one structural fact — an
+// alt node is created by exactly one predecessor (alt_step) and only backbone nodes ever get a second in-edge (insert_edge's sink is the
+// current backbone position), so the alt nodes form TREES hanging off the backbone node an op string left the backbone at (their ANCHOR),
+// and every edge of such a tree ends inside it or on a backbone node further right.
+//   * Threading.  A maximal run of non-'M' ops plus the 'M' that closes it only touches the subtree of its anchor, and along one op string
+//     every backbone node is left at most once: the runs of a member are independent.  A chunk of the op string is cut after its last
+//     'M'; ONE LANE PER RUN walks the existing subtree (its dependent loads overlap with those of 63 other runs), counts the nodes and
+//     edges it has to create from its first miss on, a wave prefix sum hands out node ids in op order — the reference's creation order,
+//     which its tie-breaks see — and the lanes then write their chains.  Anything irregular (the ops before a member's first 'M', a
+//     window of 64 ops without an 'M', positions beyond the backbone) takes the serial code of the first generation.
+//   * Heaviest path.  Anchors in backbone order are a topological order (a subtree is entered from its anchor and left to the right), and
+//     the edges of one subtree, kept in creation order in a per-anchor list, have every node's in-edge before its out-edges.  So the sweep
+//     walks the backbone once: a block of consecutive anchors with <= 64 subtree edges is gathered into registers (one lane per anchor
+//     follows its list; one lane per edge loads the record and finds the slot of its source's in-edge), then a wave-uniform loop relaxes
+//     them with every operand in registers or in a 128-node LDS window of backbone (weight, source) pairs — no load depends on a load.
+//     Same FP32 operations in the same order per path as the reference's push (weights add up along a path, never across), same
+//     tie-breaks; in-degrees and the work queue are not needed.
+// Graphs that break the tree property (op strings running past the backbone: the reference indexes out of range there) keep the Kahn sweep.
 template <bool LDS>
-__device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g, const PoaStore<LDS>& S, const uint32_t out_cap)
+__device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g, const PoaStore<LDS>& S, const uint32_t out_cap,
+                                               const PoaAux& X, const PoaScratch& L, const bool v2_in)
 {
   const int lane = threadIdx.x & 63;
   const otg_poa_graph G = P.graphs[g];
   const uint32_t node_cap = S.node_cap, edge_cap = S.edge_cap;
   auto nbase = S.nbase; auto isend = S.isend; auto bbc = S.bbc; auto queue = S.queue; auto starts = S.starts;
   const int B = (int)G.backbone_len;
+  const bool V2 = !LDS && v2_in && B >= 2;
+  // V2: a stretch of plain 'M' ops raises the counts of a RANGE of backbone edges by one; the lane-parallel threading only marks the two
+  // ends of each stretch (+1 / -1, atomics without a return value) and one prefix sum after the last member turns the marks into counts
+  int* bdiff = (int*)(void*)&queue[0];
   uint32_t n_nodes = (uint32_t)B, n_edges = 0, n_start = B >= 2 ? 1u : 0u;
   int status = 0;
+  bool tree_ok = true;                 // V2: every alt node has one in-edge and every edge list belongs to one anchor
   const unsigned long long lt = (1ull << lane) - 1ull;
   const unsigned long long t0 = P.prof ? wall_clock64() : 0ull;
 
@@ -159,7 +222,9 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
       NodeG n; n.hw = 0.0f; n.pred = -1; n.indeg = (isb && i >= 1) ? 1u : 0u; n.head = -1;
       S.stN(i, n);              // pred = -1: empty extra-edge list (tail) for now
       bbc[i] = 0;
+      if (V2) queue[i] = 0;     // V2: the work queue of the Kahn sweep doubles as the difference array of the backbone counts (bdiff below)
     }
+    if (V2) for (int i = lane; i <= B; i += 64) { X.ahead[i] = -1; X.atail[i] = -1; X.acnt[i] = 0u; }
     if (B >= 2) starts[0] = 0;
     poa_phase_fence<LDS>();
   }
@@ -168,6 +233,7 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
   // still in registers (cn_*: a fresh node has none, and an op string that leaves the known graph keeps creating nodes), and the
   // lists of the backbone node an op starts from are read for all 64 ops of a chunk at once (pf_* below).
   uint32_t cn_id = 0xffffffffu; int cn_head = -1, cn_tail = -1;
+  int cur_anc = 0;                     // V2, serial code: anchor of the subtree `prev` is in
   auto node_lists = [&](uint32_t x, int& head, int& tail) {
     if (x == cn_id) { head = cn_head; tail = cn_tail; }
     else { const NodeG n = S.ldN(x); head = n.head; tail = n.pred; }
@@ -175,6 +241,7 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
   auto new_node = [&](uint8_t base) -> uint32_t {
     if (n_nodes >= node_cap) { status = 1; return n_nodes - 1; }
     nbase[n_nodes] = base;
+    if (V2) X.inedge[n_nodes] = -1;
     cn_id = n_nodes; cn_head = -1; cn_tail = -1;
     return n_nodes++;
   };
@@ -186,6 +253,17 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
     if (src_tail >= 0) { S.stEnext(src_tail, e); S.stTail(src, e); } else { src_head = e; S.stList(src, e, e); }
     if (src == cn_id) { cn_head = src_head; cn_tail = e; }
     // the sink's in-degree is counted in one pass over the edge array before the sweep (no read-modify-write on this path)
+    if (V2) {
+      X.esrc[e] = src; X.anext[e] = -1;
+      if ((int)sink >= B) { if (X.inedge[sink] >= 0) tree_ok = false; X.inedge[sink] = e; }
+      if (cur_anc < -1 || cur_anc >= B || ((int)src < B && (int)src != cur_anc)) tree_ok = false;
+      else {
+        const int t = X.atail[cur_anc + 1];
+        if (t >= 0) X.anext[t] = e; else X.ahead[cur_anc + 1] = e;
+        X.atail[cur_anc + 1] = e;
+        X.acnt[cur_anc + 1] = X.acnt[cur_anc + 1] + 1u;
+      }
+    }
   };
   auto insert_edge = [&](uint32_t src, int src_head, int src_tail, uint32_t sink) {     // src/anppoa.hpp:96-110
     if ((int)src < B - 1 && sink == src + 1) { bbc[src] = bbc[src] + 1; return; }
@@ -194,6 +272,7 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
       if (x.sink == sink) { S.stEw(e, x.w + 1.0f); return; }
       e = x.next;
     }
+    if ((int)sink >= B) tree_ok = false;      // a second way into an alt node (only op strings that run past the backbone get here)
     append_edge(src, src_head, src_tail, sink, (int)sink >= B ? (uint32_t)nbase[sink] : 0u);
   };
   auto alt_step = [&](uint32_t prev, int prev_head, int prev_tail, uint8_t tc) -> uint32_t {   // :162-186 / :206-233
@@ -216,6 +295,7 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
     const bool spl = M.spanning_l != 0, spr = M.spanning_r != 0;
     int prev = 0, ref_i = 0, tgt = 0, ci = 0;
     bool first = true;
+    cur_anc = 0;
     if (!spl) {
       first = false;
       bool stop = false;
@@ -227,15 +307,214 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
         const unsigned long long below = upto >= 64 ? ~0ull : ((1ull << upto) - 1ull);
         const int nD = __builtin_popcountll(__ballot(c == 'D') & below), nI = __builtin_popcountll(__ballot(c == 'I') & below);
         ref_i += nD; tgt += nI;
-        if (nD) prev = ref_i;
+        if (nD) { prev = ref_i; cur_anc = prev; }
         ci += upto; stop = upto < 64;
       }
     }
+    // one lane per run (lead: this lane has one; p0 = its first op in L.ops, ref0 = the backbone position there, nv = ops in the chunk)
+    auto par_runs = [&](const bool lead, const int p0, const int ref0, const int nv) {
+        uint32_t n_newn = 0, n_newe = 0, pv = 0, last_ex = 0;
+        int ph = -1, pt = -1, ltl = -1, r = 0, r_miss = 0, jmiss = -1, r_close = -1, anc = 0;
+        bool missed = false, close_new = false, closed = false;
+        if (lead) {
+          // phase A: follow the run through the subtree that exists (weights of the edges it reuses go up), stop creating at the first miss
+          anc = ref0 - 1; pv = (uint32_t)anc; r = ref0;
+          { const NodeG na = S.ldN(pv); ph = na.head; pt = na.pred; }
+          for (int j = p0; j < nv; ++j) {
+            const uint32_t o = L.ops[j];
+            const int op = (int)(o & 0xffu);
+            const uint32_t tc = (o >> 8) & 0xffu;
+            if (op == 'M') { closed = true; r_close = r; break; }
+            if (op == 'D') { r += 1; if (!missed && B - r <= 10 && spr) isend[pv] = 1; continue; }
+            if (!missed) {
+              bool found = false;
+              for (int e = ph; e >= 0;) {
+                const EdgeG x = S.ldE(e);
+                if ((int)x.sink >= B && x.base == tc) { S.stEw(e, x.w + 1.0f); pv = x.sink; found = true; break; }
+                e = x.next;
+              }
+              if (found) { const NodeG nn = S.ldN(pv); ph = nn.head; pt = nn.pred; }
+              else { missed = true; jmiss = j; r_miss = r; last_ex = pv; ltl = pt; }
+            }
+            if (missed) ++n_newn;
+            if (op == 'X') r += 1;
+            if (!missed && B - r <= 10 && spr) isend[pv] = 1;
+          }
+          if (closed) {
+            if (!missed) {
+              if ((int)pv < B - 1 && r_close == (int)pv + 1) bbc[pv] = bbc[pv] + 1;
+              else {
+                bool found = false;
+                for (int e = ph; e >= 0;) {
+                  const EdgeG x = S.ldE(e);
+                  if ((int)x.sink == r_close) { S.stEw(e, x.w + 1.0f); found = true; break; }
+                  e = x.next;
+                }
+                if (!found) { close_new = true; last_ex = pv; ltl = pt; }
+              }
+            }
+            if (B - (r_close + 1) <= 10 && spr) isend[r_close] = 1;
+          }
+          n_newe = n_newn + ((closed && (missed || close_new)) ? 1u : 0u);
+        }
+        // phase B: ids in op order
+        uint32_t tot_n = 0, tot_e = 0;
+        const uint32_t nb = n_nodes + poa_wave_excl_sum(n_newn, lane, &tot_n);
+        const uint32_t eb = n_edges + poa_wave_excl_sum(n_newe, lane, &tot_e);
+        if (n_nodes + tot_n > node_cap) status = 1;
+        else if (n_edges + tot_e > edge_cap) status = 2;
+        if (!status) {
+          // phase C: the new chain of each run
+          if (lead && n_newe) {
+            uint32_t src = last_ex, k = 0;
+            if (missed) {
+              int r2 = r_miss;
+              for (int j = jmiss; j < nv; ++j) {
+                const uint32_t o = L.ops[j];
+                const int op = (int)(o & 0xffu);
+                const uint32_t tc = (o >> 8) & 0xffu;
+                if (op == 'M') break;
+                if (op == 'D') { r2 += 1; if (B - r2 <= 10 && spr) isend[src] = 1; continue; }
+                const uint32_t id = nb + k;
+                const int ein = (int)(eb + k);
+                const bool has_out = k + 1u < n_newe;
+                nbase[id] = (uint8_t)tc;
+                EdgeG x; x.sink = id; x.w = 1.0f; x.next = -1; x.base = tc;
+                S.stE(ein, x);
+                X.esrc[ein] = src; X.anext[ein] = has_out ? ein + 1 : -1; X.inedge[id] = ein;
+                NodeG nn; nn.hw = 0.0f; nn.pred = has_out ? ein + 1 : -1; nn.indeg = 0u; nn.head = has_out ? ein + 1 : -1;
+                S.stN(id, nn);
+                src = id; ++k;
+                if (op == 'X') r2 += 1;
+                if (B - r2 <= 10 && spr) isend[id] = 1;
+              }
+            }
+            if (closed && (missed || close_new)) {
+              const int ec = (int)(eb + k);
+              EdgeG x; x.sink = (uint32_t)r_close; x.w = 1.0f; x.next = -1; x.base = 0u;
+              S.stE(ec, x);
+              X.esrc[ec] = src; X.anext[ec] = -1;
+            }
+            if (ltl >= 0) { S.stEnext(ltl, (int)eb); S.stTail(last_ex, (int)eb); } else S.stList(last_ex, (int)eb, (int)eb);
+            const int t = X.atail[anc + 1];
+            if (t >= 0) X.anext[t] = (int)eb; else X.ahead[anc + 1] = (int)eb;
+            X.atail[anc + 1] = (int)(eb + n_newe - 1u);
+            X.acnt[anc + 1] = X.acnt[anc + 1] + n_newe;
+          }
+          n_nodes += tot_n; n_edges += tot_e;
+        }
+        cn_id = 0xffffffffu;
+    };
+    int pre_ci = -1; int pre_cc[4] = {0, 0, 0, 0};      // V2: ops read ahead for the chunk that starts at pre_ci
     int lastop = 0;                    // op just before position ci in the main phase (0 = none)
     while (ci < clen && !status) {
       const int i = ci + lane;
-      const bool valid = i < clen;
-      const int c = valid ? (int)cig[i] : 0;
+      const int rem = clen - ci;
+      if (V2 && lastop == 'M' && !first && rem > 64) {
+        // ---- wide chunk: four ops per lane (up to 256 ops; cut after the last 'M' like the narrow chunk below).  The round trips of a chunk
+        // (ops, target bases, backbone counts, the runs' subtrees) are what the threading waits for, so fewer, fuller chunks; more than 64
+        // runs in 256 ops (a member that disagrees with the backbone everywhere) or anything irregular leaves the chunk to the narrow code
+        const int rem4 = rem < 256 ? rem : 256;
+        const int o0 = 4 * lane;
+        int cc[4];
+        if (pre_ci == ci) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) cc[k] = o0 + k < rem4 ? pre_cc[k] : 0;
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) cc[k] = o0 + k < rem4 ? (int)cig[ci + o0 + k] : 0;
+        }
+        bool wide_ok = true;
+        int nv = rem4;
+        if (rem > 256) {
+          int lm = -1;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) if (cc[k] == 'M') lm = o0 + k;
+          lm = otg_wave_max_i32(lm);
+          if (lm < 0) wide_ok = false; else nv = lm + 1;
+        }
+        if (wide_ok) {
+          // the ops of the chunk after this one are asked for now: first-touch reads of the op string cost far more than a cache hit, and
+          // this one then overlaps with the rest of this chunk
+          pre_ci = ci + nv;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) pre_cc[k] = pre_ci + o0 + k < clen ? (int)cig[pre_ci + o0 + k] : 0;
+          uint32_t nref = 0, ntgt = 0;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const bool v = o0 + k < nv;
+            const int c4 = cc[k];
+            nref += (v && (c4 == 'M' || c4 == 'X' || c4 == 'D')) ? 1u : 0u;
+            ntgt += (v && (c4 == 'M' || c4 == 'X' || c4 == 'I')) ? 1u : 0u;
+          }
+          uint32_t totr = 0, tott = 0, totl = 0;
+          int ra = ref_i + (int)poa_wave_excl_sum(nref, lane, &totr), ta = tgt + (int)poa_wave_excl_sum(ntgt, lane, &tott);
+          int pcur = __shfl_up(cc[3], 1);
+          if (lane == 0) pcur = 'M';
+          int refk[4], tgtk[4]; bool simk[4], leadk[4];
+          bool irregular = false;
+          uint32_t nl = 0;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const bool v = o0 + k < nv;
+            const int c4 = cc[k];
+            const bool m = c4 == 'M', x = c4 == 'X', d = c4 == 'D', in = c4 == 'I';
+            refk[k] = ra; tgtk[k] = ta;
+            simk[k] = v && m && pcur == 'M' && ra < B;
+            leadk[k] = v && !m && pcur == 'M';
+            if (v && (!(m || x || d || in) || (m && ra >= B) || (!m && ra > B) || ((x || in) && ta >= slen))) irregular = true;
+            if (v) { ra += (m || x || d) ? 1 : 0; ta += (m || x || in) ? 1 : 0; pcur = c4; }
+            nl += leadk[k] ? 1u : 0u;
+          }
+          uint32_t li = poa_wave_excl_sum(nl, lane, &totl);
+          if (__ballot(irregular) || totl > 64u) wide_ok = false;
+          if (wide_ok) {
+            // every load of the chunk head first (backbone counts of the plain 'M' ops, target bases), then the stores: one round trip
+            int tbv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tbv[k] = (o0 + k < nv && (cc[k] == 'X' || cc[k] == 'I')) ? (int)seq[tgtk[k]] : 0;
+            {
+              const unsigned long long s3 = __ballot(simk[3]), s0 = __ballot(simk[0]);
+              const bool prev_s = lane > 0 && ((s3 >> (lane - 1)) & 1ull), next_s = lane < 63 && ((s0 >> (lane + 1)) & 1ull);
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                if (simk[k]) {
+                  const bool ps = k > 0 ? simk[k > 0 ? k - 1 : 0] : prev_s, ns = k < 3 ? simk[k < 3 ? k + 1 : 3] : next_s;
+                  if (!ps) atomicAdd(&bdiff[refk[k] - 1], 1);
+                  if (!ns) atomicAdd(&bdiff[refk[k]], -1);
+                  if (B - (refk[k] + 1) <= 10 && spr && (uint32_t)refk[k] < node_cap) isend[refk[k]] = 1;
+                }
+              }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              if (o0 + k < nv) L.ops[o0 + k] = (uint32_t)cc[k] | ((uint32_t)tbv[k] << 8);
+              if (leadk[k]) { L.stage[li] = (uint32_t)(o0 + k) | ((uint32_t)refk[k] << 8); ++li; }
+            }
+            poa_lds_order();
+            const bool lead = lane < (int)totl;
+            const uint32_t ld = lead ? L.stage[lane] : 0u;
+            par_runs(lead, (int)(ld & 0xffu), (int)(ld >> 8), nv);
+            lastop = (int)(L.ops[nv - 1] & 0xffu);
+            ref_i += (int)totr; tgt += (int)tott;
+            if (lastop == 'M') { prev = ref_i - 1; first = false; cur_anc = prev; }
+            ci += nv;
+            continue;
+          }
+        }
+      }
+      const int c = lane < rem ? (int)cig[i] : 0;
+      // V2: the chunk ends after the last 'M' of the 64-op window (the whole rest of the op string when that is shorter), so that the
+      // next chunk starts right after an 'M' and every run of non-'M' ops lies inside one chunk
+      int nvalid = rem < 64 ? rem : 64;
+      bool no_m = false;               // a window of 64 ops without an 'M' in the middle of the op string: serial code
+      if (V2 && rem > 64) {
+        const unsigned long long mm = __ballot(c == 'M');
+        if (!mm) no_m = true;
+        else if (lastop == 0) nvalid = (int)__builtin_ctzll(mm) + 1;     // a member's first chunk runs on the serial code: only as far as its first 'M'
+        else nvalid = 64 - (int)__builtin_clzll(mm);
+      }
+      const bool valid = lane < nvalid;
       int pc = __shfl_up(c, 1);
       if (lane == 0) pc = lastop;
       const bool isM = c == 'M', isX = c == 'X', isD = c == 'D', isI = c == 'I';
@@ -243,8 +522,13 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
       const int ref_at = ref_i + __builtin_popcountll(mMXD & lt), tgt_at = tgt + __builtin_popcountll(mMXI & lt);
       // 'M' after 'M': prev == ref-1, not the first op -> insert_edge(ref-1, ref) is the implicit backbone edge
       const bool simple = valid && isM && pc == 'M' && ref_at < B;
+      const unsigned long long simm = __ballot(simple);
       if (simple) {
-        bbc[ref_at - 1] = bbc[ref_at - 1] + 1;
+        if (V2) {
+          const bool ps = lane > 0 && ((simm >> (lane - 1)) & 1ull), ns = lane < 63 && ((simm >> (lane + 1)) & 1ull);
+          if (!ps) atomicAdd(&bdiff[ref_at - 1], 1);
+          if (!ns) atomicAdd(&bdiff[ref_at], -1);
+        } else bbc[ref_at - 1] = bbc[ref_at - 1] + 1;
         if (B - (ref_at + 1) <= 10 && spr && (uint32_t)ref_at < node_cap) isend[ref_at] = 1;
       }
       // the target base of every op travels with it (one coalesced read instead of a dependent load per serial op), and so do
@@ -252,6 +536,14 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
       // safe: along one op string every node is left at most once, and an op that leaves ref-1 earlier in this chunk (an 'I'
       // at the same ref) makes the op before this one a non-'M'.
       const int tb = (valid && (isX || isI) && tgt_at < slen) ? (int)seq[tgt_at] : 0;
+      // one lane per run when the chunk starts right after an 'M' and holds nothing out of the ordinary
+      bool par = V2 && lastop == 'M' && !first && !no_m;
+      if (par && __ballot(valid && (!(isM || isX || isD || isI) || (isM && ref_at >= B) || (!isM && ref_at > B) || ((isX || isI) && tgt_at >= slen)))) par = false;
+      if (par) {
+        L.ops[lane] = valid ? ((uint32_t)c | ((uint32_t)tb << 8)) : 0u;
+        poa_lds_order();
+        par_runs(valid && !isM && pc == 'M', lane, ref_at, nvalid);
+      } else {
       int pf_head = -1, pf_tail = -1;
       if (valid && !simple && pc == 'M' && ref_at >= 1 && ref_at <= B) { const NodeG n = S.ldN((uint32_t)(ref_at - 1)); pf_head = n.head; pf_tail = n.pred; }
       unsigned long long todo = __ballot(valid && !simple);
@@ -264,7 +556,7 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
         bool have_lists = false;
         int ph = -1, pt = -1;
         if (pop == 'M') {
-          prev = r - 1; first = false;
+          prev = r - 1; first = false; cur_anc = prev;
           if (r >= 1 && r <= B) { ph = __builtin_amdgcn_readlane(pf_head, l); pt = __builtin_amdgcn_readlane(pf_tail, l); have_lists = true; }
         }
         int ref_after = r;
@@ -275,12 +567,12 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
             if (!((int)prev < B - 1 && r == prev + 1) && !have_lists) node_lists((uint32_t)prev, ph, pt);
             insert_edge((uint32_t)prev, ph, pt, (uint32_t)r);
           }
-          prev = r; ref_after = r + 1;
+          prev = r; ref_after = r + 1; cur_anc = prev;
         } else if (op == 'X') {
           if (first) {
             bool need_new = true;
             for (uint32_t q = 0; q < n_start; ++q) if (nbase[starts[q]] == tc) { need_new = false; break; }
-            if (need_new) { prev = (int)new_node(tc); starts[n_start++] = (uint32_t)prev; }
+            if (need_new) { prev = (int)new_node(tc); starts[n_start++] = (uint32_t)prev; cur_anc = -1; }
             first = false;
           } else if ((uint32_t)prev >= n_nodes) { status = 3; break; }
           else {
@@ -290,9 +582,9 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
           ref_after = r + 1;
         } else if (op == 'D') {
           ref_after = r + 1;
-          if (first) prev = ref_after;
+          if (first) { prev = ref_after; cur_anc = prev; }
         } else if (op == 'I') {
-          if (first) { prev = (int)new_node(tc); starts[n_start++] = (uint32_t)prev; first = false; }
+          if (first) { prev = (int)new_node(tc); starts[n_start++] = (uint32_t)prev; first = false; cur_anc = -1; }
           else if ((uint32_t)prev >= n_nodes) { status = 3; break; }
           else {
             if (!have_lists) node_lists((uint32_t)prev, ph, pt);
@@ -301,19 +593,29 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
         }
         if (B - ref_after <= 10 && spr && (uint32_t)prev < node_cap) isend[prev] = 1;   // ids not yet created are remembered too
       }
-      const int nvalid = clen - ci < 64 ? clen - ci : 64;
+      }
       lastop = __builtin_amdgcn_readlane(c, nvalid - 1);
       ref_i += __builtin_popcountll(mMXD); tgt += __builtin_popcountll(mMXI);
-      if (lastop == 'M') { prev = ref_i - 1; first = false; }
-      ci += 64;
+      if (lastop == 'M') { prev = ref_i - 1; first = false; cur_anc = prev; }
+      ci += nvalid;
     }
   }
   poa_phase_fence<LDS>();
+  if (V2 && !status) {                  // the marks of the plain 'M' stretches become backbone counts
+    int carry = 0;
+    for (int b0 = 0; b0 < B; b0 += 64) {
+      const int i = b0 + lane;
+      const int d = i < B ? bdiff[i] : 0;
+      uint32_t tot = 0;
+      const int run = carry + (int)poa_wave_excl_sum((uint32_t)d, lane, &tot) + d;
+      if (i < B && run) bbc[i] = bbc[i] + (uint32_t)run;
+      carry += (int)tot;
+    }
+    poa_phase_fence<LDS>();
+  }
   if (LDS && S.reduced && (status == 1 || status == 2)) return false;     // outgrew the optimistic LDS capacities
   const unsigned long long t1 = P.prof ? wall_clock64() : 0ull;
 
-  // ---- heaviest path: Kahn sweep pushing (weight, source) along out-edges (wave-uniform).  The result does not depend on the
-  // order in which ready nodes are taken (max weight, ties to the lowest source id), so the queue is only a work list.
   const float c_ = G.c, t_ = G.t;
   auto damp = [&](float w) -> float {                      // adjust_weights :243-252
     const float t_applied = t_ * w;
@@ -321,7 +623,110 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
     return w - final_weight;
   };
   uint32_t qh = 0, qt = 0;
+  if (!status && V2 && tree_ok) {
+    // ---- heaviest path, second generation: one pass along the backbone, subtree edges from registers (see the head of this function)
+    for (uint32_t i = (uint32_t)lane; i < n_nodes; i += 64) {      // an alt node's source is the source of its one in-edge
+      int pr = -1;
+      if ((int)i >= B) { const int ie = X.inedge[i]; if (ie >= 0) pr = (int)X.esrc[ie]; }
+      NodeG n; n.hw = 0.0f; n.pred = pr; n.indeg = 0u; n.head = -1;
+      S.stN(i, n);
+    }
+    L.hw[lane] = 0.0f; L.hw[lane + 64] = 0.0f; L.pred[lane] = -1; L.pred[lane + 64] = -1;
+    poa_phase_fence<LDS>();
+    __builtin_amdgcn_wave_barrier();
+    int wb = 0;                                             // the LDS window holds backbone nodes [wb, wb + 128)
+    auto relax = [&](uint32_t v, float cand, int u) {       // wave-uniform; same acceptance rule as relax_into below
+      if ((int)v < wb + 128) {
+        const int ix = (int)(v & 127u);
+        const float h = L.hw[ix]; const int pr = L.pred[ix];
+        if (pr < 0 || cand > h || (cand == h && u < pr)) { L.hw[ix] = cand; L.pred[ix] = u; }
+      } else {                                              // a landing beyond the window (a deletion of more than 64 bases)
+        const NodeG nv = S.ldN(v);
+        if (nv.pred < 0 || cand > nv.hw || (cand == nv.hw && u < nv.pred)) S.stHwPred(v, cand, u);
+      }
+    };
+    auto window_to = [&](int u) {                            // slide so that u lies in the lower half
+      while (u >= wb + 64) {
+        const int i0 = wb + lane;
+        if (i0 < B) S.stHwPred((uint32_t)i0, L.hw[i0 & 127], L.pred[i0 & 127]);
+        wb += 64;
+        const int i1 = wb + 64 + lane;
+        float h = 0.0f; int pr = -1;
+        if (i1 < B) { const NodeG t = S.ldN((uint32_t)i1); h = t.hw; pr = t.pred; }
+        L.hw[i1 & 127] = h; L.pred[i1 & 127] = pr;
+        poa_lds_order();
+      }
+    };
+    // one block: anchors ai0 .. ai0 + nA - 1 (index = node + 1; 0 = subtrees of start nodes), T <= 64 edges staged in L.stage in list order,
+    // lane a < nA knows its anchor's slice [off, off + cnt); bb_step = also take the backbone edge of each anchor
+    auto sweep_block = [&](int ai0, int nA, int T, uint32_t off, uint32_t cnt, bool bb_step) {
+      uint32_t sink = 0, src = 0; float w = 0.0f, hsg = 0.0f, val = 0.0f; int sp = -1;
+      if (lane < T) { const int e = (int)L.stage[lane]; const EdgeG x = S.ldE(e); sink = x.sink; w = x.w; src = X.esrc[e]; if ((int)src >= B) sp = -2; }
+      for (int k = 0; k < T; ++k) {                          // where in the block does my source get its weight
+        const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)sink, k);
+        if (sp == -2 && src == sk && k < lane) sp = k;
+      }
+      if (lane < T && sp == -2) hsg = S.ldHw(src);           // a start node (weight 0) or a node of an earlier block of the same anchor
+      float bbw = 0.0f;
+      if (lane < nA) { const int u = ai0 + lane - 1; if (u >= 0 && u < B - 1) bbw = (float)bbc[u]; }
+      for (int a = 0; a < nA; ++a) {
+        const int u = ai0 + a - 1;
+        float hw_u = 0.0f;
+        if (u >= 0) {
+          window_to(u);
+          hw_u = L.hw[u & 127];
+          if (bb_step && u < B - 1) relax((uint32_t)(u + 1), hw_u + damp(1.0f + poa_readlane_f(bbw, a)), u);
+        }
+        const int o = __builtin_amdgcn_readlane((int)off, a), cn = __builtin_amdgcn_readlane((int)cnt, a);
+        for (int j = o; j < o + cn; ++j) {
+          const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)sink, j), sid = (uint32_t)__builtin_amdgcn_readlane((int)src, j);
+          const int spk = __builtin_amdgcn_readlane(sp, j);
+          const float wk = poa_readlane_f(w, j);
+          const float hs = spk == -1 ? hw_u : (spk >= 0 ? poa_readlane_f(val, spk) : poa_readlane_f(hsg, j));
+          const float cand = hs + damp(wk);
+          if (lane == j) val = cand;
+          if ((int)sk < B) relax(sk, cand, (int)sid);
+        }
+      }
+      if (lane < T && (int)sink >= B) S.stHw(sink, val);
+    };
+    int ai = 0;
+    while (ai <= B) {
+      const int aidx = ai + lane;
+      const uint32_t cnt = aidx <= B ? X.acnt[aidx] : 0u;
+      uint32_t tot = 0;
+      const uint32_t off = poa_wave_excl_sum(cnt, lane, &tot);
+      const unsigned long long fits = __ballot(aidx <= B && off + cnt <= 64u);
+      const int nA = (~fits) ? (int)__builtin_ctzll(~fits) : 64;
+      if (nA == 0) {
+        // one anchor with more than 64 subtree edges: its list in pieces of 64 (weights of nodes of earlier pieces come back from memory)
+        const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)cnt, 0);
+        int e = X.ahead[ai];
+        bool first_piece = true;
+        for (uint32_t done = 0; done < c0;) {
+          const uint32_t T = c0 - done < 64u ? c0 - done : 64u;
+          if (lane == 0) for (uint32_t k = 0; k < T; ++k) { L.stage[k] = (uint32_t)e; e = X.anext[e]; }
+          e = __builtin_amdgcn_readfirstlane(e);
+          poa_lds_order();
+          sweep_block(ai, 1, (int)T, 0u, lane == 0 ? T : 0u, first_piece);
+          __threadfence();
+          first_piece = false; done += T;
+        }
+        ai += 1;
+        continue;
+      }
+      const int T = __builtin_amdgcn_readlane((int)(off + cnt), nA - 1);
+      if (lane < nA) { int e = X.ahead[aidx]; for (uint32_t k = 0; k < cnt; ++k) { L.stage[off + k] = (uint32_t)e; e = X.anext[e]; } }
+      poa_lds_order();
+      sweep_block(ai, nA, T, off, cnt, true);
+      ai += nA;
+    }
+    // what is left of the window
+    for (int h2 = 0; h2 < 2; ++h2) { const int i0 = wb + 64 * h2 + lane; if (i0 < B) S.stHwPred((uint32_t)i0, L.hw[i0 & 127], L.pred[i0 & 127]); }
+  } else
   if (!status) {
+    // ---- heaviest path: Kahn sweep pushing (weight, source) along out-edges (wave-uniform).  The result does not depend on the
+    // order in which ready nodes are taken (max weight, ties to the lowest source id), so the queue is only a work list.
     for (uint32_t i = (uint32_t)lane; i < n_nodes; i += 64) S.stPred(i, -1);      // the list tails have done their job
     poa_phase_fence<LDS>();
     // in-degrees of the extra edges (the backbone in-edge was counted at init)
@@ -392,11 +797,26 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
       for (uint32_t j = (uint32_t)lane; j < k; j += 64) out[cap - 1 - j] = (uint8_t)queue[j];
       startpos = cap - k; len = k;
     } else {
+      // the path mostly runs down the backbone: (source, base) of 64 consecutive backbone nodes come with one round of loads and are
+      // followed through lanes; off the backbone (an alt node) it is one node per round trip
       uint32_t pos = cap;
       while (cur >= 0 && pos > 0) {
-        const uint8_t b = nbase[cur];
-        if (b) out[--pos] = b;
-        cur = S.ldPred((uint32_t)cur);
+        if (cur < B) {
+          const int base0 = cur >= 63 ? cur - 63 : 0;
+          const int my = base0 + lane;
+          int mypred = -1, myb = 0;
+          if (my <= cur) { mypred = S.ldPred((uint32_t)my); myb = (int)nbase[my]; }
+          while (cur >= base0 && cur < B && pos > 0) {
+            const int l = cur - base0;
+            const int b = __builtin_amdgcn_readlane(myb, l);
+            if (b) out[--pos] = (uint8_t)b;
+            cur = __builtin_amdgcn_readlane(mypred, l);
+          }
+        } else {
+          const uint8_t b = nbase[cur];
+          if (b) out[--pos] = b;
+          cur = S.ldPred((uint32_t)cur);
+        }
       }
       startpos = pos; len = cap - pos;
     }
@@ -453,7 +873,7 @@ __global__ __launch_bounds__(64) void poa_graph_lds_kernel(PoaDev P, uint32_t ld
   o = (o + 3u) & ~3u;
   S.starts = (OTG_LDS uint16_t*)(s_graph + o);
   S.node_cap = N; S.edge_cap = E; S.reduced = reduced;
-  if (!poa_graph_body<true>(P, g, S, ncap_true)) {
+  if (!poa_graph_body<true>(P, g, S, ncap_true, PoaAux{}, PoaScratch{}, false)) {
     if (lane == 0) { const uint32_t k = atomicAdd(P.fb_count, 1u); P.fb_list[k] = g; }
   }
 }
@@ -462,6 +882,9 @@ __global__ __launch_bounds__(64) void poa_graph_lds_kernel(PoaDev P, uint32_t ld
 __global__ __launch_bounds__(64, 8) void poa_graph_wave_kernel(PoaDev P, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count_ptr,
                                                                uint32_t count_imm)
 {
+  __shared__ uint32_t s_ops[256], s_stage[64];
+  __shared__ float s_hw[128];
+  __shared__ int32_t s_pred[128];
   const uint32_t n = count_ptr ? *count_ptr : count_imm;
   for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {
     const uint32_t g = list[k];
@@ -472,7 +895,12 @@ __global__ __launch_bounds__(64, 8) void poa_graph_wave_kernel(PoaDev P, const u
     S.nbase = P.node_base + no; S.isend = P.is_end + no; S.bbc = P.bb_cnt + no; S.queue = P.queue + no;
     S.starts = P.start_list + P.start_off[g];
     S.node_cap = (uint32_t)(P.node_off[g + 1] - no); S.edge_cap = (uint32_t)(P.edge_off[g + 1] - eo); S.reduced = false;
-    poa_graph_body<false>(P, g, S, S.node_cap);
+    PoaAux X;
+    X.esrc = P.esrc + eo; X.anext = P.anext + eo; X.inedge = P.inedge + no;
+    X.ahead = P.ahead + no + g; X.atail = P.atail + no + g; X.acnt = P.acnt + no + g;
+    PoaScratch L;
+    L.ops = (volatile lds_u32*)&s_ops[0]; L.stage = (volatile lds_u32*)&s_stage[0]; L.hw = (volatile lds_f32*)&s_hw[0]; L.pred = (volatile lds_i32*)&s_pred[0];
+    poa_graph_body<false>(P, g, S, S.node_cap, X, L, P.v2 != 0);
   }
 }
 
@@ -524,6 +952,18 @@ int otg_launch_poa(otg_ctx* ctx, const uint8_t* d_seq_arena, const uint8_t* d_ci
   P.out_arena = (uint8_t*)otg_slot(ctx, SLOT_P17, NN);
   P.out_start = (uint32_t*)otg_slot(ctx, SLOT_P29, (size_t)n_graphs * 4);
   P.status = (int32_t*)otg_slot(ctx, SLOT_P28, (size_t)n_graphs * 4);
+  static const bool poa_v1 = getenv("OTG_POA_V1") != nullptr;       // first generation only (serial threading, Kahn sweep)
+  P.v2 = poa_v1 ? 0 : 1;
+  P.esrc = nullptr; P.anext = nullptr; P.ahead = nullptr; P.atail = nullptr; P.acnt = nullptr; P.inedge = nullptr;
+  if (P.v2) {
+    P.esrc = (uint32_t*)otg_slot(ctx, SLOT_P5, NE * 4);
+    P.anext = (int32_t*)otg_slot(ctx, SLOT_P7, NE * 4);
+    P.ahead = (int32_t*)otg_slot(ctx, SLOT_P8, (NN + n_graphs + 1) * 4);
+    P.atail = (int32_t*)otg_slot(ctx, SLOT_P10, (NN + n_graphs + 1) * 4);
+    P.acnt = (uint32_t*)otg_slot(ctx, SLOT_P11, (NN + n_graphs + 1) * 4);
+    P.inedge = (int32_t*)otg_slot(ctx, SLOT_P14, NN * 4);
+    if (!P.esrc || !P.anext || !P.ahead || !P.atail || !P.acnt || !P.inedge) return OTG_ERR_HIP;
+  }
   if (!d_node_off || !d_edge_off || !d_start_off || !P.node_base || !P.is_end || !P.nodes || !P.bb_cnt || !P.queue ||
       !P.edges || !P.start_list || !P.out_arena || !P.out_start || !P.status)
     return OTG_ERR_HIP;

@@ -24,6 +24,8 @@ CASES = [
     ("OTG_NO_EDIT_SORT", ["tests/test_gpu_edit.py"]),
     ("OTG_NO_EDIT_SAMPLE", ["tests/test_gpu_edit.py"]),
     ("OTG_POA_NO_LDS", ["tests/test_gpu_poa.py"]),
+    ("OTG_POA_V1", ["tests/test_gpu_poa.py", "tests/test_gpu_pipeline.py::test_ont_kb"]),     # first-generation POA: serial threading, Kahn sweep
+    ("OTG_POA_V1 OTG_POA_NO_LDS", ["tests/test_gpu_poa.py"]),
     ("OTG_NO_REASSIGN_REV", ["tests/test_gpu_pipeline.py::test_haps_mode", "tests/test_gpu_pipeline.py::test_ont_kb"]),
 ]
 
