@@ -1274,8 +1274,16 @@ __global__ __launch_bounds__(NW * 64, WPEU) void wfa_affine_kernel_v4(
           int m = xx ? (int)(__builtin_ctzll(xx) >> 1) : 32;
           m = imin(m, imin(pl - p_v, tl - p_h));
           m = p_probe ? m : 0;
-          const int h = p_h + m, v = p_v + m;
-          const bool more = p_probe && m == 32 && v < pl && h < tl;
+          int h = p_h + m, v = p_v + m;
+          bool more = p_probe && m == 32 && v < pl && h < tl;
+          if (__ballot(more)) {      // a second probe where a run outlives the first (4 chunks in 10): the queue and its drain — a fixed cost per wave and score — are left to runs beyond 64 bases
+            const uint64_t x2 = ld32b(0, more ? v : 0) ^ ld32b(offT, more ? h : 0);
+            int m2 = x2 ? (int)(__builtin_ctzll(x2) >> 1) : 32;
+            m2 = imin(m2, imin(pl - v, tl - h));
+            m2 = more ? m2 : 0;
+            h += m2; v += m2;
+            more = more && m2 == 32 && v < pl && h < tl;
+          }
           Mn[p_in ? p_k - kbase : CAP - 1] = (int16_t)(p_valid ? h : NUL16);
           const unsigned long long mq = __ballot(more);
           const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mq, 0u));
