@@ -25,7 +25,7 @@ namespace {
 // node / edge records: everything the heaviest-path sweep and the list walks need about a node (or an edge) comes with ONE load
 struct NodeG { float hw; int32_t pred; uint32_t indeg; int32_t head; };          // best weight, its source (-1 = none yet), in-degree, first extra out-edge;
                                                                                   // while the graph is being built `pred` holds the LAST extra out-edge (list tail)
-struct EdgeG { uint32_t sink; float w; int32_t next; uint32_t base; };            // base = base of an alt-node sink (0 for backbone sinks)
+struct EdgeG { uint32_t sink; float w; int32_t next; uint32_t base; };            // base = base of an alt-node sink (0 for backbone sinks); second generation: bits 8.. = the edge's source
 struct NodeL { float hw; int16_t pred; uint16_t indeg; int16_t head; uint16_t pad; };
 struct EdgeL { uint16_t sink; uint16_t w; int16_t next; uint16_t base; };
 
@@ -50,13 +50,14 @@ struct PoaDev {
   unsigned long long* prof;   // OTG_POA_PROFILE: wall-clock ticks per phase, summed over graphs (null otherwise)
   uint32_t* fb_list;          // graphs left to the global-memory kernel by the LDS kernel (outgrew the optimistic capacities)
   uint32_t* fb_count;
-  // second generation of the global-memory path (v2 != 0): per edge its source and its successor in the edge list of its ANCHOR (the backbone
-  // node its subtree of alt nodes hangs off; -1 = subtrees of start nodes), per anchor (index anchor + 1, base node_off[g] + g) that list's
-  // head / tail / length, per alt node its one in-edge
+  // second generation of the global-memory path (v2 != 0): per edge its successor in the edge list of its ANCHOR (the backbone node its
+  // subtree of alt nodes hangs off; -1 = subtrees of start nodes) — its source shares a word with the sink base —, per anchor (index
+  // anchor + 1, base anch_off[g]) that list's head / tail / length; an alt node keeps its one in-edge (+ 1) in the in-degree field
   int v2;
-  uint32_t* esrc; int32_t* anext; int32_t* ahead; int32_t* atail; uint32_t* acnt; int32_t* inedge;
+  const uint64_t* anch_off;   // [n_graphs+1]
+  int32_t* anext; int32_t* ahead; int32_t* atail; uint32_t* acnt;
 };
-struct PoaAux { uint32_t* esrc; int32_t* anext; int32_t* ahead; int32_t* atail; uint32_t* acnt; int32_t* inedge; };
+struct PoaAux { int32_t* anext; int32_t* ahead; int32_t* atail; uint32_t* acnt; };
 
 // capacity bounds per member: alt = ops that can create a node (X, I); mrun = 'M' ops not preceded by an 'M' — with the X / I ops the
 // only ones that can create an edge outside the backbone (insert_edge from a non-'M' predecessor, src/anppoa.hpp:96-110)
@@ -117,6 +118,8 @@ template <> struct PoaStore<false> {
   __device__ __forceinline__ void stE(int e, const EdgeG& x) const { edges[e] = x; }
   __device__ __forceinline__ void stEw(int e, float w) const { edges[e].w = w; }
   __device__ __forceinline__ void stEnext(int e, int nx) const { edges[e].next = nx; }
+  __device__ __forceinline__ uint32_t ldEbase(int e) const { return edges[e].base; }
+  __device__ __forceinline__ void stIndeg(uint32_t i, uint32_t v) const { nodes[i].indeg = v; }
 };
 template <> struct PoaStore<true> {
   OTG_LDS NodeL* nodes; OTG_LDS EdgeL* edges;
@@ -137,6 +140,8 @@ template <> struct PoaStore<true> {
   __device__ __forceinline__ void stE(int e, const EdgeG& x) const { edges[e].sink = (uint16_t)x.sink; edges[e].w = (uint16_t)x.w; edges[e].next = (int16_t)x.next; edges[e].base = (uint16_t)x.base; }
   __device__ __forceinline__ void stEw(int e, float w) const { edges[e].w = (uint16_t)w; }
   __device__ __forceinline__ void stEnext(int e, int nx) const { edges[e].next = (int16_t)nx; }
+  __device__ __forceinline__ uint32_t ldEbase(int e) const { return edges[e].base; }
+  __device__ __forceinline__ void stIndeg(uint32_t i, uint32_t v) const { nodes[i].indeg = (uint16_t)v; }
 };
 
 template <bool LDS> __device__ __forceinline__ void poa_phase_fence()
@@ -241,21 +246,20 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
   auto new_node = [&](uint8_t base) -> uint32_t {
     if (n_nodes >= node_cap) { status = 1; return n_nodes - 1; }
     nbase[n_nodes] = base;
-    if (V2) X.inedge[n_nodes] = -1;
     cn_id = n_nodes; cn_head = -1; cn_tail = -1;
     return n_nodes++;
   };
   auto append_edge = [&](uint32_t src, int src_head, int src_tail, uint32_t sink, uint32_t sink_base) {
     if (n_edges >= edge_cap) { status = 2; return; }
     const int e = (int)n_edges++;
-    EdgeG x; x.sink = sink; x.w = 1.0f; x.next = -1; x.base = sink_base;
+    EdgeG x; x.sink = sink; x.w = 1.0f; x.next = -1; x.base = V2 ? (sink_base | (src << 8)) : sink_base;
     S.stE(e, x);
     if (src_tail >= 0) { S.stEnext(src_tail, e); S.stTail(src, e); } else { src_head = e; S.stList(src, e, e); }
     if (src == cn_id) { cn_head = src_head; cn_tail = e; }
     // the sink's in-degree is counted in one pass over the edge array before the sweep (no read-modify-write on this path)
     if (V2) {
-      X.esrc[e] = src; X.anext[e] = -1;
-      if ((int)sink >= B) { if (X.inedge[sink] >= 0) tree_ok = false; X.inedge[sink] = e; }
+      X.anext[e] = -1;
+      if ((int)sink >= B) S.stIndeg(sink, (uint32_t)(e + 1));      // the one in-edge of an alt node
       if (cur_anc < -1 || cur_anc >= B || ((int)src < B && (int)src != cur_anc)) tree_ok = false;
       else {
         const int t = X.atail[cur_anc + 1];
@@ -278,7 +282,7 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
   auto alt_step = [&](uint32_t prev, int prev_head, int prev_tail, uint8_t tc) -> uint32_t {   // :162-186 / :206-233
     for (int e = prev_head; e >= 0;) {
       const EdgeG x = S.ldE(e);
-      if ((int)x.sink >= B && x.base == (uint32_t)tc) { S.stEw(e, x.w + 1.0f); return x.sink; }
+      if ((int)x.sink >= B && (x.base & 0xffu) == (uint32_t)tc) { S.stEw(e, x.w + 1.0f); return x.sink; }
       e = x.next;
     }
     const uint32_t nn = new_node(tc);
@@ -330,7 +334,7 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
               bool found = false;
               for (int e = ph; e >= 0;) {
                 const EdgeG x = S.ldE(e);
-                if ((int)x.sink >= B && x.base == tc) { S.stEw(e, x.w + 1.0f); pv = x.sink; found = true; break; }
+                if ((int)x.sink >= B && (x.base & 0xffu) == tc) { S.stEw(e, x.w + 1.0f); pv = x.sink; found = true; break; }
                 e = x.next;
               }
               if (found) { const NodeG nn = S.ldN(pv); ph = nn.head; pt = nn.pred; }
@@ -379,10 +383,10 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
                 const int ein = (int)(eb + k);
                 const bool has_out = k + 1u < n_newe;
                 nbase[id] = (uint8_t)tc;
-                EdgeG x; x.sink = id; x.w = 1.0f; x.next = -1; x.base = tc;
+                EdgeG x; x.sink = id; x.w = 1.0f; x.next = -1; x.base = tc | (src << 8);
                 S.stE(ein, x);
-                X.esrc[ein] = src; X.anext[ein] = has_out ? ein + 1 : -1; X.inedge[id] = ein;
-                NodeG nn; nn.hw = 0.0f; nn.pred = has_out ? ein + 1 : -1; nn.indeg = 0u; nn.head = has_out ? ein + 1 : -1;
+                X.anext[ein] = has_out ? ein + 1 : -1;
+                NodeG nn; nn.hw = 0.0f; nn.pred = has_out ? ein + 1 : -1; nn.indeg = (uint32_t)(ein + 1); nn.head = has_out ? ein + 1 : -1;
                 S.stN(id, nn);
                 src = id; ++k;
                 if (op == 'X') r2 += 1;
@@ -391,9 +395,9 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
             }
             if (closed && (missed || close_new)) {
               const int ec = (int)(eb + k);
-              EdgeG x; x.sink = (uint32_t)r_close; x.w = 1.0f; x.next = -1; x.base = 0u;
+              EdgeG x; x.sink = (uint32_t)r_close; x.w = 1.0f; x.next = -1; x.base = src << 8;
               S.stE(ec, x);
-              X.esrc[ec] = src; X.anext[ec] = -1;
+              X.anext[ec] = -1;
             }
             if (ltl >= 0) { S.stEnext(ltl, (int)eb); S.stTail(last_ex, (int)eb); } else S.stList(last_ex, (int)eb, (int)eb);
             const int t = X.atail[anc + 1];
@@ -627,7 +631,7 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
     // ---- heaviest path, second generation: one pass along the backbone, subtree edges from registers (see the head of this function)
     for (uint32_t i = (uint32_t)lane; i < n_nodes; i += 64) {      // an alt node's source is the source of its one in-edge
       int pr = -1;
-      if ((int)i >= B) { const int ie = X.inedge[i]; if (ie >= 0) pr = (int)X.esrc[ie]; }
+      if ((int)i >= B) { const int ie = (int)S.ldN(i).indeg - 1; if (ie >= 0) pr = (int)(S.ldEbase(ie) >> 8); }
       NodeG n; n.hw = 0.0f; n.pred = pr; n.indeg = 0u; n.head = -1;
       S.stN(i, n);
     }
@@ -661,7 +665,7 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
     // lane a < nA knows its anchor's slice [off, off + cnt); bb_step = also take the backbone edge of each anchor
     auto sweep_block = [&](int ai0, int nA, int T, uint32_t off, uint32_t cnt, bool bb_step) {
       uint32_t sink = 0, src = 0; float w = 0.0f, hsg = 0.0f, val = 0.0f; int sp = -1;
-      if (lane < T) { const int e = (int)L.stage[lane]; const EdgeG x = S.ldE(e); sink = x.sink; w = x.w; src = X.esrc[e]; if ((int)src >= B) sp = -2; }
+      if (lane < T) { const int e = (int)L.stage[lane]; const EdgeG x = S.ldE(e); sink = x.sink; w = x.w; src = x.base >> 8; if ((int)src >= B) sp = -2; }
       for (int k = 0; k < T; ++k) {                          // where in the block does my source get its weight
         const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)sink, k);
         if (sp == -2 && src == sk && k < lane) sp = k;
@@ -727,7 +731,7 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
   if (!status) {
     // ---- heaviest path: Kahn sweep pushing (weight, source) along out-edges (wave-uniform).  The result does not depend on the
     // order in which ready nodes are taken (max weight, ties to the lowest source id), so the queue is only a work list.
-    for (uint32_t i = (uint32_t)lane; i < n_nodes; i += 64) S.stPred(i, -1);      // the list tails have done their job
+    for (uint32_t i = (uint32_t)lane; i < n_nodes; i += 64) { S.stPred(i, -1); if (V2 && (int)i >= B) S.stIndeg(i, 0u); }      // the list tails (and the in-edge notes of the second generation) have done their job
     poa_phase_fence<LDS>();
     // in-degrees of the extra edges (the backbone in-edge was counted at init)
     if (LDS) { for (uint32_t e = 0; e < n_edges; ++e) S.incIndeg(S.ldE((int)e).sink); }
@@ -896,8 +900,8 @@ __global__ __launch_bounds__(64, 8) void poa_graph_wave_kernel(PoaDev P, const u
     S.starts = P.start_list + P.start_off[g];
     S.node_cap = (uint32_t)(P.node_off[g + 1] - no); S.edge_cap = (uint32_t)(P.edge_off[g + 1] - eo); S.reduced = false;
     PoaAux X;
-    X.esrc = P.esrc + eo; X.anext = P.anext + eo; X.inedge = P.inedge + no;
-    X.ahead = P.ahead + no + g; X.atail = P.atail + no + g; X.acnt = P.acnt + no + g;
+    X.anext = P.anext + eo;
+    { const uint64_t ao = P.v2 ? P.anch_off[g] : 0ull; X.ahead = P.ahead + ao; X.atail = P.atail + ao; X.acnt = P.acnt + ao; }
     PoaScratch L;
     L.ops = (volatile lds_u32*)&s_ops[0]; L.stage = (volatile lds_u32*)&s_stage[0]; L.hw = (volatile lds_f32*)&s_hw[0]; L.pred = (volatile lds_i32*)&s_pred[0];
     poa_graph_body<false>(P, g, S, S.node_cap, X, L, P.v2 != 0);
@@ -954,15 +958,23 @@ int otg_launch_poa(otg_ctx* ctx, const uint8_t* d_seq_arena, const uint8_t* d_ci
   P.status = (int32_t*)otg_slot(ctx, SLOT_P28, (size_t)n_graphs * 4);
   static const bool poa_v1 = getenv("OTG_POA_V1") != nullptr;       // first generation only (serial threading, Kahn sweep)
   P.v2 = poa_v1 ? 0 : 1;
-  P.esrc = nullptr; P.anext = nullptr; P.ahead = nullptr; P.atail = nullptr; P.acnt = nullptr; P.inedge = nullptr;
+  P.anext = nullptr; P.ahead = nullptr; P.atail = nullptr; P.acnt = nullptr; P.anch_off = nullptr;
+  for (uint32_t g = 0; g < n_graphs && P.v2; ++g)      // node ids share a word with a base in the edge records
+    if (node_off[g + 1] - node_off[g] >= (1ull << 24) - 2) P.v2 = 0;
   if (P.v2) {
-    P.esrc = (uint32_t*)otg_slot(ctx, SLOT_P5, NE * 4);
+    std::vector<uint64_t> anch_off(n_graphs + 1);
+    anch_off[0] = 0;
+    for (uint32_t g = 0; g < n_graphs; ++g) anch_off[g + 1] = anch_off[g] + (((uint64_t)h_graphs[g].backbone_len + 2 + 3) & ~3ull);
+    const uint64_t NA = anch_off[n_graphs];
+    uint64_t* d_anch_off = (uint64_t*)otg_slot(ctx, SLOT_P5, (size_t)(n_graphs + 1) * sizeof(uint64_t));
     P.anext = (int32_t*)otg_slot(ctx, SLOT_P7, NE * 4);
-    P.ahead = (int32_t*)otg_slot(ctx, SLOT_P8, (NN + n_graphs + 1) * 4);
-    P.atail = (int32_t*)otg_slot(ctx, SLOT_P10, (NN + n_graphs + 1) * 4);
-    P.acnt = (uint32_t*)otg_slot(ctx, SLOT_P11, (NN + n_graphs + 1) * 4);
-    P.inedge = (int32_t*)otg_slot(ctx, SLOT_P14, NN * 4);
-    if (!P.esrc || !P.anext || !P.ahead || !P.atail || !P.acnt || !P.inedge) return OTG_ERR_HIP;
+    P.ahead = (int32_t*)otg_slot(ctx, SLOT_P8, NA * 4);
+    P.atail = (int32_t*)otg_slot(ctx, SLOT_P10, NA * 4);
+    P.acnt = (uint32_t*)otg_slot(ctx, SLOT_P11, NA * 4);
+    if (!d_anch_off || !P.anext || !P.ahead || !P.atail || !P.acnt) return OTG_ERR_HIP;
+    HIP_TRY(ctx, hipMemcpyAsync(d_anch_off, anch_off.data(), (size_t)(n_graphs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the host vector goes out of scope
+    P.anch_off = d_anch_off;
   }
   if (!d_node_off || !d_edge_off || !d_start_off || !P.node_base || !P.is_end || !P.nodes || !P.bb_cnt || !P.queue ||
       !P.edges || !P.start_list || !P.out_arena || !P.out_start || !P.status)
