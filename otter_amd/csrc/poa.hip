@@ -36,9 +36,11 @@ struct PoaDev {
   const otg_poa_graph* graphs;
   uint32_t n_graphs;
   // per-graph layout
-  const uint64_t* node_off;   // [n_graphs+1]
-  const uint64_t* edge_off;   // [n_graphs+1]
-  const uint64_t* start_off;  // [n_graphs+1]
+  const uint64_t* node_off;   // [n_graphs+1]  capacities (differences) and the place of graph g's consensus in out_arena
+  const uint64_t* edge_off;   // [n_graphs+1]  capacities
+  // where graph g's image lives in the work arrays below: the graphs of one launch (a bounded share of the batch, see otg_launch_poa) are
+  // packed from offset 0, the next launch reuses the arrays
+  const uint64_t* wnode_off; const uint64_t* wedge_off; const uint64_t* wstart_off; const uint64_t* wanch_off;
   // node arrays
   NodeG* nodes; uint8_t* node_base; uint8_t* is_end; uint32_t* bb_cnt; uint32_t* queue;
   // edge array
@@ -52,9 +54,8 @@ struct PoaDev {
   uint32_t* fb_count;
   // second generation of the global-memory path (v2 != 0): per edge its successor in the edge list of its ANCHOR (the backbone node its
   // subtree of alt nodes hangs off; -1 = subtrees of start nodes) — its source shares a word with the sink base —, per anchor (index
-  // anchor + 1, base anch_off[g]) that list's head / tail / length; an alt node keeps its one in-edge (+ 1) in the in-degree field
+  // anchor + 1, base wanch_off[g]) that list's head / tail / length; an alt node keeps its one in-edge (+ 1) in the in-degree field
   int v2;
-  const uint64_t* anch_off;   // [n_graphs+1]
   int32_t* anext; int32_t* ahead; int32_t* atail; uint32_t* acnt;
 };
 struct PoaAux { int32_t* anext; int32_t* ahead; int32_t* atail; uint32_t* acnt; };
@@ -838,11 +839,11 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
 // LDS instantiation: one single-wave block per graph (the dispatcher refills the slot as soon as its graph is done); a graph
 // that does not fit, or outgrows its optimistic capacities, goes onto the list of the global-memory kernel below.
 constexpr uint32_t POA_LDS_NODE_B = 18, POA_LDS_EDGE_B = 8;      // NodeL 12 + bbc 2 + queue 2 + base 1 + end 1; EdgeL 8
-__global__ __launch_bounds__(64) void poa_graph_lds_kernel(PoaDev P, uint32_t lds_bytes)
+__global__ __launch_bounds__(64) void poa_graph_lds_kernel(PoaDev P, const uint32_t* __restrict__ list, uint32_t lds_bytes)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t s_graph[];
   const int lane = threadIdx.x & 63;
-  const uint32_t g = P.order[blockIdx.x];
+  const uint32_t g = list[blockIdx.x];
   if (g >= P.n_graphs) return;
   const otg_poa_graph G = P.graphs[g];
   const uint32_t ncap_true = (uint32_t)(P.node_off[g + 1] - P.node_off[g]), ecap_true = (uint32_t)(P.edge_off[g + 1] - P.edge_off[g]);
@@ -893,15 +894,15 @@ __global__ __launch_bounds__(64, 8) void poa_graph_wave_kernel(PoaDev P, const u
   for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {
     const uint32_t g = list[k];
     if (g >= P.n_graphs) continue;
-    const uint64_t no = P.node_off[g], eo = P.edge_off[g];
+    const uint64_t no = P.wnode_off[g], eo = P.wedge_off[g];
     PoaStore<false> S;
     S.nodes = P.nodes + no; S.edges = P.edges + eo;
     S.nbase = P.node_base + no; S.isend = P.is_end + no; S.bbc = P.bb_cnt + no; S.queue = P.queue + no;
-    S.starts = P.start_list + P.start_off[g];
-    S.node_cap = (uint32_t)(P.node_off[g + 1] - no); S.edge_cap = (uint32_t)(P.edge_off[g + 1] - eo); S.reduced = false;
+    S.starts = P.start_list + P.wstart_off[g];
+    S.node_cap = (uint32_t)(P.node_off[g + 1] - P.node_off[g]); S.edge_cap = (uint32_t)(P.edge_off[g + 1] - P.edge_off[g]); S.reduced = false;
     PoaAux X;
     X.anext = P.anext + eo;
-    { const uint64_t ao = P.v2 ? P.anch_off[g] : 0ull; X.ahead = P.ahead + ao; X.atail = P.atail + ao; X.acnt = P.acnt + ao; }
+    { const uint64_t ao = P.v2 ? P.wanch_off[g] : 0ull; X.ahead = P.ahead + ao; X.atail = P.atail + ao; X.acnt = P.acnt + ao; }
     PoaScratch L;
     L.ops = (volatile lds_u32*)&s_ops[0]; L.stage = (volatile lds_u32*)&s_stage[0]; L.hw = (volatile lds_f32*)&s_hw[0]; L.pred = (volatile lds_i32*)&s_pred[0];
     poa_graph_body<false>(P, g, S, S.node_cap, X, L, P.v2 != 0);
@@ -930,7 +931,7 @@ int otg_launch_poa(otg_ctx* ctx, const uint8_t* d_seq_arena, const uint8_t* d_ci
     HIP_TRY(ctx, hipMemcpyAsync(h_nonm.data(), d_nonm, (size_t)n_members * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   }
-  std::vector<uint64_t> edge_off(n_graphs + 1), start_off(n_graphs + 1);
+  std::vector<uint64_t> edge_off(n_graphs + 1), start_off(n_graphs + 1);      // capacities as running sums
   node_off.assign(n_graphs + 1, 0);
   node_off[0] = edge_off[0] = start_off[0] = 0;
   for (uint32_t g = 0; g < n_graphs; ++g) {
@@ -940,54 +941,20 @@ int otg_launch_poa(otg_ctx* ctx, const uint8_t* d_seq_arena, const uint8_t* d_ci
     edge_off[g + 1] = edge_off[g] + ((alt + mrun + 2 + 1) & ~1ull);
     start_off[g + 1] = start_off[g] + h_graphs[g].n_members + 2;
   }
-  const uint64_t NN = node_off[n_graphs], NE = edge_off[n_graphs], NS = start_off[n_graphs];
+  const uint64_t NN = node_off[n_graphs];
   PoaDev P;
   P.seq_arena = d_seq_arena; P.cig_arena = d_cig_arena; P.members = d_members; P.graphs = d_graphs; P.n_graphs = n_graphs;
-  uint64_t* d_node_off = (uint64_t*)otg_slot(ctx, SLOT_P0, (size_t)(n_graphs + 1) * sizeof(uint64_t));
-  uint64_t* d_edge_off = (uint64_t*)otg_slot(ctx, SLOT_P1, (size_t)(n_graphs + 1) * sizeof(uint64_t));
-  uint64_t* d_start_off = (uint64_t*)otg_slot(ctx, SLOT_P2, (size_t)(n_graphs + 1) * sizeof(uint64_t));
-  P.node_base = (uint8_t*)otg_slot(ctx, SLOT_P3, NN);
-  P.is_end = (uint8_t*)otg_slot(ctx, SLOT_P4, NN);
-  P.nodes = (NodeG*)otg_slot(ctx, SLOT_P6, NN * sizeof(NodeG));
-  P.bb_cnt = (uint32_t*)otg_slot(ctx, SLOT_P9, NN * 4);
-  P.queue = (uint32_t*)otg_slot(ctx, SLOT_P12, NN * 4);
-  P.edges = (EdgeG*)otg_slot(ctx, SLOT_P13, NE * sizeof(EdgeG));
-  P.start_list = (uint32_t*)otg_slot(ctx, SLOT_P16, NS * 4);
-  P.out_arena = (uint8_t*)otg_slot(ctx, SLOT_P17, NN);
-  P.out_start = (uint32_t*)otg_slot(ctx, SLOT_P29, (size_t)n_graphs * 4);
-  P.status = (int32_t*)otg_slot(ctx, SLOT_P28, (size_t)n_graphs * 4);
   static const bool poa_v1 = getenv("OTG_POA_V1") != nullptr;       // first generation only (serial threading, Kahn sweep)
   P.v2 = poa_v1 ? 0 : 1;
-  P.anext = nullptr; P.ahead = nullptr; P.atail = nullptr; P.acnt = nullptr; P.anch_off = nullptr;
   for (uint32_t g = 0; g < n_graphs && P.v2; ++g)      // node ids share a word with a base in the edge records
     if (node_off[g + 1] - node_off[g] >= (1ull << 24) - 2) P.v2 = 0;
-  if (P.v2) {
-    std::vector<uint64_t> anch_off(n_graphs + 1);
-    anch_off[0] = 0;
-    for (uint32_t g = 0; g < n_graphs; ++g) anch_off[g + 1] = anch_off[g] + (((uint64_t)h_graphs[g].backbone_len + 2 + 3) & ~3ull);
-    const uint64_t NA = anch_off[n_graphs];
-    uint64_t* d_anch_off = (uint64_t*)otg_slot(ctx, SLOT_P5, (size_t)(n_graphs + 1) * sizeof(uint64_t));
-    P.anext = (int32_t*)otg_slot(ctx, SLOT_P7, NE * 4);
-    P.ahead = (int32_t*)otg_slot(ctx, SLOT_P8, NA * 4);
-    P.atail = (int32_t*)otg_slot(ctx, SLOT_P10, NA * 4);
-    P.acnt = (uint32_t*)otg_slot(ctx, SLOT_P11, NA * 4);
-    if (!d_anch_off || !P.anext || !P.ahead || !P.atail || !P.acnt) return OTG_ERR_HIP;
-    HIP_TRY(ctx, hipMemcpyAsync(d_anch_off, anch_off.data(), (size_t)(n_graphs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the host vector goes out of scope
-    P.anch_off = d_anch_off;
-  }
-  if (!d_node_off || !d_edge_off || !d_start_off || !P.node_base || !P.is_end || !P.nodes || !P.bb_cnt || !P.queue ||
-      !P.edges || !P.start_list || !P.out_arena || !P.out_start || !P.status)
-    return OTG_ERR_HIP;
-  P.node_off = d_node_off; P.edge_off = d_edge_off; P.start_off = d_start_off;
-  P.out_off = d_node_off;     // consensus g is written into [node_off[g], node_off[g+1]) of out_arena
-  P.out_len = d_out_len;
   // Graph slots without backbone and members (the pipeline keeps one slot per read) produce nothing: zero their outputs here and
   // leave them out of the launches.  The others are split by size: LDS bytes per graph block = the optimistic need (same formula
   // as poa_graph_lds_kernel) of 97 % of them; graphs within it go to the LDS kernel, the rest to the global-memory kernel.  Above
   // 16 KB per block too few graphs would be resident per CU to beat the 32 latency-bound waves of the global-memory kernel.
   static const bool no_lds = getenv("OTG_POA_NO_LDS") != nullptr;
   uint32_t lds_bytes = 0, n_lds = 0, n_glob = 0;
+  std::vector<uint32_t> order;
   {
     std::vector<uint32_t> est(n_graphs, 0u), live;
     live.reserve(n_graphs);
@@ -1010,7 +977,6 @@ int otg_launch_poa(otg_ctx* ctx, const uint8_t* d_seq_arena, const uint8_t* d_ci
       const uint64_t wa = (edge_off[a + 1] - edge_off[a]) + (node_off[a + 1] - node_off[a]), wb = (edge_off[b + 1] - edge_off[b]) + (node_off[b + 1] - node_off[b]);
       return wa != wb ? wa > wb : a < b;
     };
-    std::vector<uint32_t> order;
     order.reserve(live.size());
     for (uint32_t g : live) if (lds_bytes && est[g] <= lds_bytes) order.push_back(g);
     n_lds = (uint32_t)order.size();
@@ -1018,18 +984,75 @@ int otg_launch_poa(otg_ctx* ctx, const uint8_t* d_seq_arena, const uint8_t* d_ci
     n_glob = (uint32_t)order.size() - n_lds;
     std::sort(order.begin(), order.begin() + n_lds, heavier);
     std::sort(order.begin() + n_lds, order.end(), heavier);
-    uint32_t* d_order = (uint32_t*)otg_slot(ctx, SLOT_P18, (size_t)(n_graphs + 1) * sizeof(uint32_t));
-    if (!d_order) return OTG_ERR_HIP;
-    if (!order.empty()) HIP_TRY(ctx, hipMemcpyAsync(d_order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(d_out_len, 0, (size_t)n_graphs * sizeof(uint32_t), ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(P.out_start, 0, (size_t)n_graphs * sizeof(uint32_t), ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(P.status, 0, (size_t)n_graphs * sizeof(int32_t), ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    P.order = d_order;
   }
+  // The graph images are sized for the worst case (every X / I op a new node), ~0.5 MB per allele of a 3 kb locus: a batch of 100 000 regions
+  // would ask for 150 GB at once.  So the launch lists are cut into pieces whose images fit a fixed budget; the pieces run one after the
+  // other on the stream and reuse the same work arrays (a piece of 24 GB holds tens of thousands of graphs, several times what the device
+  // keeps in flight).  Only the consensus arena and the per-graph outputs span the whole batch.
+  static const size_t piece_budget = getenv("OTG_POA_PIECE_MB") ? (size_t)atoll(getenv("OTG_POA_PIECE_MB")) << 20 : (size_t)24 << 30;
+  struct Piece { uint32_t k0, k1; bool lds; };
+  std::vector<Piece> pieces;
+  std::vector<uint64_t> wnode(n_graphs + 1, 0), wedge(n_graphs + 1, 0), wstart(n_graphs + 1, 0), wanch(n_graphs + 1, 0);
+  uint64_t maxN = 0, maxE = 0, maxS = 0, maxA = 0;
+  {
+    auto cut = [&](uint32_t k0, uint32_t k1, bool lds) {
+      uint32_t p0 = k0;
+      uint64_t cn = 0, ce = 0, cs = 0, ca = 0;
+      for (uint32_t k = k0; k < k1; ++k) {
+        const uint32_t g = order[k];
+        const uint64_t nc = node_off[g + 1] - node_off[g], ec = edge_off[g + 1] - edge_off[g], sc = start_off[g + 1] - start_off[g];
+        const uint64_t ac = ((uint64_t)h_graphs[g].backbone_len + 2 + 3) & ~3ull;
+        const uint64_t bytes = (cn + nc) * (sizeof(NodeG) + 10) + (ce + ec) * (sizeof(EdgeG) + 4) + (cs + sc) * 4 + (ca + ac) * 12;
+        if (k > p0 && bytes > piece_budget) { pieces.push_back({p0, k, lds}); p0 = k; cn = ce = cs = ca = 0; }
+        wnode[g] = cn; wedge[g] = ce; wstart[g] = cs; wanch[g] = ca;
+        cn += nc; ce += ec; cs += sc; ca += ac;
+        maxN = std::max(maxN, cn); maxE = std::max(maxE, ce); maxS = std::max(maxS, cs); maxA = std::max(maxA, ca);
+      }
+      if (k1 > p0) pieces.push_back({p0, k1, lds});
+    };
+    cut(n_lds, n_lds + n_glob, false);
+    cut(0, n_lds, true);
+  }
+  uint64_t* d_node_off = (uint64_t*)otg_slot(ctx, SLOT_P0, (size_t)(n_graphs + 1) * sizeof(uint64_t));
+  uint64_t* d_edge_off = (uint64_t*)otg_slot(ctx, SLOT_P1, (size_t)(n_graphs + 1) * sizeof(uint64_t));
+  uint64_t* d_woff = (uint64_t*)otg_slot(ctx, SLOT_P2, (size_t)4 * (n_graphs + 1) * sizeof(uint64_t));
+  P.node_base = (uint8_t*)otg_slot(ctx, SLOT_P3, maxN);
+  P.is_end = (uint8_t*)otg_slot(ctx, SLOT_P4, maxN);
+  P.nodes = (NodeG*)otg_slot(ctx, SLOT_P6, maxN * sizeof(NodeG));
+  P.bb_cnt = (uint32_t*)otg_slot(ctx, SLOT_P9, maxN * 4);
+  P.queue = (uint32_t*)otg_slot(ctx, SLOT_P12, maxN * 4);
+  P.edges = (EdgeG*)otg_slot(ctx, SLOT_P13, maxE * sizeof(EdgeG));
+  P.start_list = (uint32_t*)otg_slot(ctx, SLOT_P16, maxS * 4);
+  P.out_arena = (uint8_t*)otg_slot(ctx, SLOT_P17, NN);
+  P.out_start = (uint32_t*)otg_slot(ctx, SLOT_P29, (size_t)n_graphs * 4);
+  P.status = (int32_t*)otg_slot(ctx, SLOT_P28, (size_t)n_graphs * 4);
+  P.anext = nullptr; P.ahead = nullptr; P.atail = nullptr; P.acnt = nullptr;
+  if (P.v2) {
+    P.anext = (int32_t*)otg_slot(ctx, SLOT_P7, maxE * 4);
+    P.ahead = (int32_t*)otg_slot(ctx, SLOT_P8, maxA * 4);
+    P.atail = (int32_t*)otg_slot(ctx, SLOT_P10, maxA * 4);
+    P.acnt = (uint32_t*)otg_slot(ctx, SLOT_P11, maxA * 4);
+    if (!P.anext || !P.ahead || !P.atail || !P.acnt) return OTG_ERR_HIP;
+  }
+  uint32_t* d_order = (uint32_t*)otg_slot(ctx, SLOT_P18, (size_t)(n_graphs + 1) * sizeof(uint32_t));
+  if (!d_node_off || !d_edge_off || !d_woff || !P.node_base || !P.is_end || !P.nodes || !P.bb_cnt || !P.queue ||
+      !P.edges || !P.start_list || !P.out_arena || !P.out_start || !P.status || !d_order)
+    return OTG_ERR_HIP;
+  P.node_off = d_node_off; P.edge_off = d_edge_off;
+  P.wnode_off = d_woff; P.wedge_off = d_woff + (n_graphs + 1); P.wstart_off = d_woff + 2 * (size_t)(n_graphs + 1); P.wanch_off = d_woff + 3 * (size_t)(n_graphs + 1);
+  P.out_off = d_node_off;     // consensus g is written into [node_off[g], node_off[g+1]) of out_arena
+  P.out_len = d_out_len;
+  P.order = d_order;
+  if (!order.empty()) HIP_TRY(ctx, hipMemcpyAsync(d_order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(d_out_len, 0, (size_t)n_graphs * sizeof(uint32_t), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(P.out_start, 0, (size_t)n_graphs * sizeof(uint32_t), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(P.status, 0, (size_t)n_graphs * sizeof(int32_t), ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(d_node_off, node_off.data(), (size_t)(n_graphs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(d_edge_off, edge_off.data(), (size_t)(n_graphs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(d_start_off, start_off.data(), (size_t)(n_graphs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_woff, wnode.data(), (size_t)(n_graphs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_woff + (n_graphs + 1), wedge.data(), (size_t)(n_graphs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_woff + 2 * (size_t)(n_graphs + 1), wstart.data(), (size_t)(n_graphs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_woff + 3 * (size_t)(n_graphs + 1), wanch.data(), (size_t)(n_graphs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // host vectors go out of scope after return
   static const bool profile = getenv("OTG_POA_PROFILE") != nullptr;
   P.prof = nullptr;
@@ -1041,13 +1064,14 @@ int otg_launch_poa(otg_ctx* ctx, const uint8_t* d_seq_arena, const uint8_t* d_ci
   P.fb_list = (uint32_t*)otg_slot(ctx, SLOT_P22, (size_t)(n_graphs + 1) * sizeof(uint32_t));
   if (!P.fb_list) return OTG_ERR_HIP;
   P.fb_count = P.fb_list + n_graphs;
-  {
+  for (const Piece& pc : pieces) {
+    const uint32_t n = pc.k1 - pc.k0;
     // one single-wave block per graph: the dispatcher refills a wave slot as soon as its graph is done
-    if (n_glob) hipLaunchKernelGGL(poa_graph_wave_kernel, dim3(n_glob), dim3(64), 0, ctx->stream, P, P.order + n_lds, (const uint32_t*)nullptr, n_glob);
-    if (n_lds) {
+    if (!pc.lds) hipLaunchKernelGGL(poa_graph_wave_kernel, dim3(n), dim3(64), 0, ctx->stream, P, P.order + pc.k0, (const uint32_t*)nullptr, n);
+    else {
       HIP_TRY(ctx, hipMemsetAsync(P.fb_count, 0, sizeof(uint32_t), ctx->stream));
-      hipLaunchKernelGGL(poa_graph_lds_kernel, dim3(n_lds), dim3(64), lds_bytes, ctx->stream, P, lds_bytes);
-      const uint32_t fg = n_lds < (uint32_t)ctx->n_cu * 32 ? n_lds : (uint32_t)ctx->n_cu * 32;
+      hipLaunchKernelGGL(poa_graph_lds_kernel, dim3(n), dim3(64), lds_bytes, ctx->stream, P, P.order + pc.k0, lds_bytes);
+      const uint32_t fg = n < (uint32_t)ctx->n_cu * 32 ? n : (uint32_t)ctx->n_cu * 32;
       hipLaunchKernelGGL(poa_graph_wave_kernel, dim3(fg), dim3(64), 0, ctx->stream, P, (const uint32_t*)P.fb_list, (const uint32_t*)P.fb_count, 0u);
     }
   }

@@ -26,6 +26,8 @@ CASES = [
     ("OTG_POA_NO_LDS", ["tests/test_gpu_poa.py"]),
     ("OTG_POA_V1", ["tests/test_gpu_poa.py", "tests/test_gpu_pipeline.py::test_ont_kb"]),     # first-generation POA: serial threading, Kahn sweep
     ("OTG_POA_V1 OTG_POA_NO_LDS", ["tests/test_gpu_poa.py"]),
+    ("OTG_POA_PIECE_MB=1", ["tests/test_gpu_poa.py", "tests/test_gpu_pipeline.py::test_ont_kb"]),         # graph images in many small pieces that reuse the work arrays
+    ("OTG_POA_PIECE_MB=1 OTG_POA_NO_LDS", ["tests/test_gpu_poa.py"]),
     ("OTG_NO_REASSIGN_REV", ["tests/test_gpu_pipeline.py::test_haps_mode", "tests/test_gpu_pipeline.py::test_ont_kb"]),
 ]
 
