@@ -1804,24 +1804,19 @@ __global__ __launch_bounds__(NW == 1 ? 256 : NW * 64, WPEU) void wfa_affine_kern
           // a second probe where a run outlives the first (one in 120 cells at ONT divergence, i.e. most slot visits have one): the queue, its
           // drain and the fold-back of the patch table — a fixed cost per score — are then left to runs beyond 64 bases (one slot visit in 100)
           if (__ballot(moreE || moreO)) {
-            {
-              const int v2 = hE - kE;
-              const uint64_t xx = ld32b(0, moreE ? v2 : 0) ^ ld32b(offT, moreE ? hE : 0);
-              int m = xx ? (int)(__builtin_ctzll(xx) >> 1) : 32;
-              m = imin(m, imin(pl - v2, tl - hE));
-              m = moreE ? m : 0;
-              hE += m;
-              moreE = moreE && m == 32 && v2 + m < pl && hE < tl;
-            }
-            {
-              const int v2 = hO - kE - 1;
-              const uint64_t xx = ld32b(0, moreO ? v2 : 0) ^ ld32b(offT, moreO ? hO : 0);
-              int m = xx ? (int)(__builtin_ctzll(xx) >> 1) : 32;
-              m = imin(m, imin(pl - v2, tl - hO));
-              m = moreO ? m : 0;
-              hO += m;
-              moreO = moreO && m == 32 && v2 + m < pl && hO < tl;
-            }
+            // one probe sequence for both cells of the lane: it extends the even cell if that one needs it, else the odd one (a lane where both do —
+            // one in 15 000 — leaves the odd cell to the queue)
+            const bool any = moreE || moreO, selO = !moreE && moreO;
+            int h2 = selO ? hO : hE;
+            const int v2 = h2 - (selO ? kE + 1 : kE);
+            const uint64_t xx = ld32b(0, any ? v2 : 0) ^ ld32b(offT, any ? h2 : 0);
+            int m = xx ? (int)(__builtin_ctzll(xx) >> 1) : 32;
+            m = imin(m, imin(pl - v2, tl - h2));
+            m = any ? m : 0;
+            h2 += m;
+            const bool more2 = any && m == 32 && v2 + m < pl && h2 < tl;
+            if (selO) { hO = h2; moreO = more2; }
+            else if (moreE) { hE = h2; moreE = more2; }
           }
           const int sE = validE ? hE : NUL16, sO = validO ? hO : NUL16;
           MC[0][i][0] = (mE >> 16) | ((uint32_t)sE << 16);
