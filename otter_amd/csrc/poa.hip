@@ -884,7 +884,7 @@ __global__ __launch_bounds__(64) void poa_graph_lds_kernel(PoaDev P, const uint3
 }
 
 // global-memory instantiation over a list of graphs: those too large for the LDS kernel, then what the LDS kernel left behind
-__global__ __launch_bounds__(64, 8) void poa_graph_wave_kernel(PoaDev P, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count_ptr,
+__global__ __launch_bounds__(64, 6) void poa_graph_wave_kernel(PoaDev P, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count_ptr,
                                                                uint32_t count_imm)
 {
   __shared__ uint32_t s_ops[256], s_stage[64];
