@@ -207,8 +207,11 @@ struct ShardOut {
 void shard_worker(Job& J, int device, uint32_t a, uint32_t bnd, int ingest_threads, ShardOut& out)
 {
   const uint32_t per = J.j->batch_regions ? J.j->batch_regions : 2048u;
-  BoundedQueue<BatchPtr> q_in(2);
-  double ms_ingest = 0, ms_gpu[2] = {0, 0}, ms_emit[2] = {0, 0};
+  // hot-path threads (one context each) per device: a batch of a few hundred regions cannot fill the device — its stages wait for their
+  // longest alignment / graph — so several batches are in flight; OTG_DISPATCH_CONTEXTS overrides (1..4)
+  const int n_gpu_threads = [] { const char* e = getenv("OTG_DISPATCH_CONTEXTS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
+  BoundedQueue<BatchPtr> q_in((size_t)n_gpu_threads);
+  double ms_ingest = 0, ms_gpu[4] = {0, 0, 0, 0}, ms_emit[4] = {0, 0, 0, 0};
   std::thread ingest([&] {
     try {
       uint32_t idx = 0;
@@ -242,11 +245,14 @@ void shard_worker(Job& J, int device, uint32_t a, uint32_t bnd, int ingest_threa
     if (J.rc.load() != OTG_OK) q_in.abort();               // whatever stopped the job: release the ingest thread
     if (ctx) pool_release(device, ctx);
   };
-  std::thread g0(gpu_thread, 0), g1(gpu_thread, 1);
-  ingest.join(); g0.join(); g1.join();
+  std::vector<std::thread> gts;
+  for (int t = 0; t < n_gpu_threads; ++t) gts.emplace_back(gpu_thread, t);
+  ingest.join();
+  for (auto& t : gts) t.join();
   out.cv.notify_all();
   std::lock_guard<std::mutex> lk(J.st_m);
-  J.st.ms_ingest += ms_ingest; J.st.ms_hot_path += ms_gpu[0] + ms_gpu[1]; J.st.ms_emit += ms_emit[0] + ms_emit[1];
+  J.st.ms_ingest += ms_ingest;
+  for (int t = 0; t < n_gpu_threads; ++t) { J.st.ms_hot_path += ms_gpu[t]; J.st.ms_emit += ms_emit[t]; }
 }
 
 } // namespace
