@@ -2221,7 +2221,7 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
         // alignments in flight per tier (blocks x alignments per block) size the workspaces
         const uint32_t ncu = (uint32_t)ctx->n_cu;
         const uint32_t bl0 = !(v5_mask & 1) ? 0 : (sh0 == 0 ? ncu * 4 : ncu * 8), al0 = sh0 == 0 ? bl0 * 4 : bl0;
-        const uint32_t bl1 = !(v5_mask & 2) ? 0 : (sh1 == 0 ? ncu * 3 : ncu * 8), al1 = sh1 == 0 ? bl1 * 4 : bl1;
+        const uint32_t bl1 = !(v5_mask & 2) ? 0 : (sh1 == 0 ? ncu * 4 : ncu * 8), al1 = sh1 == 0 ? bl1 * 4 : bl1;
         const uint32_t bl2 = !(v5_mask & 4) ? 0 : (sh2 == 0 ? ncu * 2 : (sh2 == 1 ? ncu * 8 : ncu * 4)), al2 = sh2 == 0 ? bl2 * 4 : bl2;
         uint32_t bl3 = !(v5_mask & 8) ? 0 : (sh3 == 0 ? ncu * 4 : ncu * 2), al3 = bl3;
         uint32_t bl4 = !(v5_mask & 16) ? 0 : ncu * 2, al4 = bl4;
@@ -2242,7 +2242,7 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
                            (const uint32_t*)sorted, (const uint32_t*)(seg + SEGI), g, d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, cnt + TICK, n_ovf5, ovf5, \
                            WS, (const int32_t*)d_bound, vis)
         if (bl0) { if (sh0 == 0) OTG_V5_LAUNCH(1, 8, 4096, 4, bl0, 0, 72, w0); else OTG_V5_LAUNCH(2, 4, 4096, 4, bl0, 0, 72, w0); }
-        if (bl1) { if (sh1 == 0) OTG_V5_LAUNCH(1, 12, 4608, 3, bl1, 1, 73, w1); else OTG_V5_LAUNCH(2, 6, 4608, 4, bl1, 1, 73, w1); }
+        if (bl1) { if (sh1 == 0) OTG_V5_LAUNCH(1, 12, 4608, 4, bl1, 1, 73, w1); else OTG_V5_LAUNCH(2, 6, 4608, 4, bl1, 1, 73, w1); }
         if (bl2) { if (sh2 == 0) OTG_V5_LAUNCH(1, 16, 6144, 2, bl2, 2, 74, w2); else if (sh2 == 1) OTG_V5_LAUNCH(2, 8, 6144, 4, bl2, 2, 74, w2); else OTG_V5_LAUNCH(4, 4, 6144, 4, bl2, 2, 74, w2); }
         if (bl3) { if (sh3 == 0) OTG_V5_LAUNCH(4, 8, 8192, 4, bl3, 3, 75, w3); else OTG_V5_LAUNCH(8, 4, 8192, 4, bl3, 3, 75, w3); }
         if (bl4) OTG_V5_LAUNCH(8, 8, 12288, 4, bl4, 4, 76, w4);
