@@ -1954,7 +1954,7 @@ __global__ __launch_bounds__(256) void K_asort_scatter(const uint32_t* __restric
 // ---- register-resident tiers (v5): which tier takes an alignment follows from its score bound and shape alone — the same window
 // arithmetic as the kernel — so one counting sort on (tier, bound) hands every tier its own list, longest alignments first
 #ifndef OTG_V5_DEFAULT_MASK
-#define OTG_V5_DEFAULT_MASK 27     /* measured: the one-wave 1024 and 1536 tiers (1, 2), the four-wave 4096 tier (8) and the eight-wave 8192 tier (16) beat the LDS tiers; the one-wave 2048 tier (2 waves per SIMD) does not */
+#define OTG_V5_DEFAULT_MASK 31     /* measured: every register tier beats the LDS tier of its window (one-wave 1024 / 1536 / 2048 at 4 / 4 / 3 waves per SIMD, four-wave 4096, eight-wave 8192) */
 #endif
 #ifndef OTG_V5_DEFAULT_SHAPE
 #define OTG_V5_DEFAULT_SHAPE 0
@@ -2222,7 +2222,7 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
         const uint32_t ncu = (uint32_t)ctx->n_cu;
         const uint32_t bl0 = !(v5_mask & 1) ? 0 : (sh0 == 0 ? ncu * 4 : ncu * 8), al0 = sh0 == 0 ? bl0 * 4 : bl0;
         const uint32_t bl1 = !(v5_mask & 2) ? 0 : (sh1 == 0 ? ncu * 4 : ncu * 8), al1 = sh1 == 0 ? bl1 * 4 : bl1;
-        const uint32_t bl2 = !(v5_mask & 4) ? 0 : (sh2 == 0 ? ncu * 2 : (sh2 == 1 ? ncu * 8 : ncu * 4)), al2 = sh2 == 0 ? bl2 * 4 : bl2;
+        const uint32_t bl2 = !(v5_mask & 4) ? 0 : (sh2 == 0 ? ncu * 3 : (sh2 == 1 ? ncu * 8 : ncu * 4)), al2 = sh2 == 0 ? bl2 * 4 : bl2;
         uint32_t bl3 = !(v5_mask & 8) ? 0 : (sh3 == 0 ? ncu * 4 : ncu * 2), al3 = bl3;
         uint32_t bl4 = !(v5_mask & 16) ? 0 : ncu * 2, al4 = bl4;
         AffWs w0 = v5_ws(1024, al0), w1 = v5_ws(1536, al1), w2 = v5_ws(2048, al2), w3 = v5_ws(4096, al3), w4 = v5_ws(8192, al4);
@@ -2243,7 +2243,7 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
                            WS, (const int32_t*)d_bound, vis)
         if (bl0) { if (sh0 == 0) OTG_V5_LAUNCH(1, 8, 4096, 4, bl0, 0, 72, w0); else OTG_V5_LAUNCH(2, 4, 4096, 4, bl0, 0, 72, w0); }
         if (bl1) { if (sh1 == 0) OTG_V5_LAUNCH(1, 12, 4608, 4, bl1, 1, 73, w1); else OTG_V5_LAUNCH(2, 6, 4608, 4, bl1, 1, 73, w1); }
-        if (bl2) { if (sh2 == 0) OTG_V5_LAUNCH(1, 16, 6144, 2, bl2, 2, 74, w2); else if (sh2 == 1) OTG_V5_LAUNCH(2, 8, 6144, 4, bl2, 2, 74, w2); else OTG_V5_LAUNCH(4, 4, 6144, 4, bl2, 2, 74, w2); }
+        if (bl2) { if (sh2 == 0) OTG_V5_LAUNCH(1, 16, 6144, 3, bl2, 2, 74, w2); else if (sh2 == 1) OTG_V5_LAUNCH(2, 8, 6144, 4, bl2, 2, 74, w2); else OTG_V5_LAUNCH(4, 4, 6144, 4, bl2, 2, 74, w2); }
         if (bl3) { if (sh3 == 0) OTG_V5_LAUNCH(4, 8, 8192, 4, bl3, 3, 75, w3); else OTG_V5_LAUNCH(8, 4, 8192, 4, bl3, 3, 75, w3); }
         if (bl4) OTG_V5_LAUNCH(8, 8, 12288, 4, bl4, 4, 76, w4);
 #undef OTG_V5_LAUNCH

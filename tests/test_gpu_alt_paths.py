@@ -14,7 +14,7 @@ CASES = [
     ("OTG_NO_AFFINE_BOUND", ["tests/test_gpu_affine.py"]),
     ("OTG_NO_AFFINE_V4", ["tests/test_gpu_affine.py"]),
     ("OTG_AFFINE_V5=0", ["tests/test_gpu_affine.py"]),                                   # LDS / HBM tiers only
-    ("OTG_AFFINE_V5=31", ["tests/test_gpu_affine.py", "tests/test_gpu_poa.py"]),         # every register tier (one-wave 1024 / 1536 / 2048, four- and eight-wave)
+    ("OTG_AFFINE_V5=25", ["tests/test_gpu_affine.py", "tests/test_gpu_poa.py"]),         # register tiers 1024 / 4096 / 8192 only: the 1472 / 2048 windows on the LDS tiers
     ("OTG_AFFINE_V5=31 OTG_V5_SHAPE=1121", ["tests/test_gpu_affine.py"]),                # the multi-wave shapes of the small tiers
     ("OTG_AFFINE_V5=31 OTG_NO_AFFINE_V4=1", ["tests/test_gpu_affine.py"]),               # register tiers in front of the HBM-row tiers
     ("OTG_AFFINE_BOUND_STATIC", ["tests/test_gpu_affine.py"]),
