@@ -2229,10 +2229,12 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
         w4.slab_bytes = std::min<size_t>(w4.slab_bytes, ((size_t)(0.2 * (double)maxlen * (double)maxlen) + (1 << 20)) & ~(size_t)255); w4.stride = w4.off_slab + w4.slab_bytes;
         // the same share of the device as the tiers behind: beyond it the two widest tiers keep fewer alignments in flight (reads beyond ~16 kb only)
         auto total5 = [&]() { return w0.stride * al0 + w1.stride * al1 + w2.stride * al2 + w3.stride * al3 + w4.stride * al4 + 256; };
-        while (total5() > budget && (bl4 > ncu / 4 || bl3 > ncu / 2)) {
+        const size_t budget5 = std::min<size_t>((size_t)(total_b * 0.25), (size_t)((free_b + ctx->pool[SLOT_REVOPS].cap) * 0.8));     // five tiers side by side: a quarter of the device
+        while (total5() > budget5 && (bl4 > ncu / 4 || bl3 > ncu / 2)) {
           if (bl4 > ncu / 4 && (w4.stride * al4 >= w3.stride * al3 || bl3 <= ncu / 2)) { bl4 /= 2; al4 = bl4; } else { bl3 /= 2; al3 = bl3; }
         }
         const size_t need5 = total5();
+        if (ws.dbg & 1) fprintf(stderr, "[otg] affine: register tiers keep %u / %u / %u / %u / %u alignments in flight, workspaces %.1f GB of a budget of %.1f GB\n", al0, al1, al2, al3, al4, (double)need5 / 1e9, (double)budget5 / 1e9);
         uint8_t* ws5 = (uint8_t*)otg_slot(ctx, SLOT_REVOPS, need5);
         if (!ws5) return OTG_ERR_HIP;
         w0.base = ws5; w1.base = w0.base + w0.stride * al0; w2.base = w1.base + w1.stride * al1; w3.base = w2.base + w2.stride * al2; w4.base = w3.base + w3.stride * al3;
