@@ -989,7 +989,14 @@ int otg_launch_poa(otg_ctx* ctx, const uint8_t* d_seq_arena, const uint8_t* d_ci
   // would ask for 150 GB at once.  So the launch lists are cut into pieces whose images fit a fixed budget; the pieces run one after the
   // other on the stream and reuse the same work arrays (a piece of 24 GB holds tens of thousands of graphs, several times what the device
   // keeps in flight).  Only the consensus arena and the per-graph outputs span the whole batch.
-  static const size_t piece_budget = getenv("OTG_POA_PIECE_MB") ? (size_t)atoll(getenv("OTG_POA_PIECE_MB")) << 20 : (size_t)24 << 30;
+  static const size_t piece_budget_cfg = getenv("OTG_POA_PIECE_MB") ? (size_t)atoll(getenv("OTG_POA_PIECE_MB")) << 20 : (size_t)24 << 30;
+  size_t piece_budget = piece_budget_cfg;
+  {   // ... and never more than half of what the device can still give (what the work arrays hold already counts as available)
+    size_t free_b = 0, total_b = 0, held = 0;
+    HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+    for (int sl : {SLOT_P3, SLOT_P4, SLOT_P6, SLOT_P7, SLOT_P8, SLOT_P9, SLOT_P10, SLOT_P11, SLOT_P12, SLOT_P13, SLOT_P16}) held += ctx->pool[sl].cap;
+    piece_budget = std::min(piece_budget, std::max<size_t>((size_t)1 << 30, (free_b + held) / 2));
+  }
   struct Piece { uint32_t k0, k1; bool lds; };
   std::vector<Piece> pieces;
   std::vector<uint64_t> wnode(n_graphs + 1, 0), wedge(n_graphs + 1, 0), wstart(n_graphs + 1, 0), wanch(n_graphs + 1, 0);
