@@ -110,3 +110,61 @@ def test_poa_lds_capacity_mix(gpu, oracle):
         n = len(mem)
         specs.append((bb, mem, np.float32(n * 0.4), np.float32(0.3)))
     _check(gpu, oracle, specs)
+
+
+def test_poa_crowded_anchors_and_long_jumps(gpu, oracle):
+    """Shapes the second-generation path handles apart: many members leaving the backbone at the SAME node with long, different
+    insertions (one anchor with hundreds of subtree edges: swept in pieces of 64), shared insertion prefixes (subtrees that branch),
+    deletions longer than the 128-node window of backbone weights (landings written straight to memory), members that start off
+    the backbone (start-node subtrees), and 300-op runs without an 'M' (serial threading in the middle of an op string).  Large
+    backbones so that the graphs stay out of LDS."""
+    from helpers import rand_seq
+    rng = np.random.default_rng(46)
+    specs = []
+    for g in range(12):
+        B = int(rng.integers(2600, 3400))
+        bb = rand_seq(rng, B)
+        pos = int(rng.integers(200, B - 900))
+        shared = rand_seq(rng, 40)
+        mem = []
+        nmem = int(rng.integers(6, 16))
+        for m in range(nmem):
+            kind = (g + m) % 6
+            ops = []
+            if kind == 5:                       # starts with insertions / mismatches: start nodes and their subtrees
+                ops.append("I" * int(rng.integers(1, 30)))
+                ops.append("X" * int(rng.integers(1, 4)))
+                ref = ops[-1].count("X")
+            else:
+                ref = 0
+            def M(n):
+                return "M" * n
+            ops.append(M(pos - ref)); ref = pos
+            if kind in (0, 1, 5):               # a long insertion at `pos`: own bases (0), a shared prefix then own bases (1)
+                ins = int(rng.integers(70, 320))
+                ops.append("I" * ins)
+            elif kind == 2:                     # a deletion beyond the window, then a mismatch run
+                d = int(rng.integers(140, 420))
+                ops.append("D" * d); ref += d
+                ops.append("X" * 3); ref += 3
+            elif kind == 3:                     # 300 ops without an 'M'
+                for _ in range(60):
+                    ops.append("X" * 2 + "I" * 2 + "D" * 1); ref += 3
+            rest = B - ref
+            while rest > 0:                     # the rest: ONT-like noise
+                k = rng.choice(["M", "X", "D", "I"], p=[0.9, 0.04, 0.03, 0.03])
+                run = int(rng.integers(1, 40)) if k == "M" else int(rng.integers(1, 3))
+                if k in "MXD":
+                    run = min(run, rest); rest -= run
+                ops.append(k * run)
+            cig = "".join(ops).encode()
+            tlen = cig.count(b"M") + cig.count(b"X") + cig.count(b"I")
+            seq = bytearray(rand_seq(rng, tlen))
+            if kind == 1:                       # the first 40 inserted bases are the same in every member of this kind
+                t0 = cig[:cig.index(b"I")].count(b"M") + cig[:cig.index(b"I")].count(b"X")
+                seq[t0:t0 + len(shared)] = shared
+            mem.append((bytes(seq), cig, bool(kind != 4 or rng.random() < 0.5), bool(rng.random() < 0.9)))
+        n = len(mem)
+        c = np.float32(n * 0.4) if n >= 4 else np.float32(1.0)
+        specs.append((bb, mem, c, np.float32(0.3)))
+    _check(gpu, oracle, specs)
