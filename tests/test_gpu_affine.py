@@ -186,3 +186,34 @@ def test_affine_packed_sequence_capacity_sweep(gpu, oracle):
     assert np.array_equal(gs, es), [(i, int(gs[i]), int(es[i]), len(pairs[i][0]), len(pairs[i][1])) for i in np.flatnonzero(gs != es)[:8]]
     bad = [(i, len(pairs[i][0]), len(pairs[i][1])) for i in range(len(pairs)) if gc[i] != ec[i]]
     assert not bad, bad[:8]
+
+
+def test_affine_probe_boundaries(gpu, oracle):
+    """Match runs whose lengths sit on the probe boundaries of the exact tiers (32 bases per probe, a second probe in the same slot visit,
+    the queue beyond 64 bases): a noisy stretch sets the score bound — and with it the tier: windows of 1024 / 1536 / 2048 / 4096 / 8192 —, the
+    rest of the pair is exact runs of 31 ... 130 and a few hundred bases between single substitutions, insertions and deletions."""
+    rng = np.random.default_rng(29)
+    runs = [31, 32, 33, 47, 62, 63, 64, 65, 66, 95, 96, 97, 127, 128, 129, 130, 257, 400]
+    pairs = []
+    for noisy_len in (1400, 2600, 4300, 6000, 12000):
+        for rep in range(6 if noisy_len < 12000 else 2):
+            base = rand_seq(rng, noisy_len)
+            a = bytearray(mutate(rng, base, 0.07)); b = bytearray(mutate(rng, base, 0.07))
+            order = list(rng.permutation(len(runs))) * 2
+            for j, ri in enumerate(order):
+                r = rand_seq(rng, runs[ri])
+                a += r; b += r
+                kind = (j + rep) % 3
+                if kind == 0:
+                    a += b"A"; b += b"C"
+                elif kind == 1:
+                    a += rand_seq(rng, 1 + j % 3)
+                else:
+                    b += rand_seq(rng, 1 + j % 2)
+            pairs.append((bytes(a), bytes(b)) if rep % 2 else (bytes(b), bytes(a)))
+    arena, tasks = pair_tasks(pairs)
+    gs, gc = gpu.affine_align_batch(arena, tasks)
+    es, ec = oracle.affine_align_batch(arena, tasks)
+    assert np.array_equal(gs, es), [(i, int(gs[i]), int(es[i])) for i in np.flatnonzero(gs != es)[:8]]
+    bad = [(i, len(pairs[i][0]), len(pairs[i][1])) for i in range(len(pairs)) if gc[i] != ec[i]]
+    assert not bad, bad[:8]
