@@ -321,7 +321,7 @@ def run_rank(args):
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "algorithmic_bytes_per_launch": kbytes // kl, "avg_launch_ms": round(kms / kl, 3),
                      "note": "achieved = SURVEY §8(d) algorithmic bytes (every cell of the reference's un-pruned, HBM-resident wavefronts) / "
-                             "HIP-event time of the kernel chain: a work-equivalent rate, NOT bytes moved — the kernels keep wavefronts in LDS "
+                             "HIP-event time of the kernel chain: a work-equivalent rate, NOT bytes moved — the kernels keep wavefronts in registers / LDS "
                              "and prune cells; the binding resource is in `physical` (PMC, profiles/)",
                      "physical": physical,
                      "other_kernel": {"edit_ms": round(ek, 2), "affine_ms": round(ak, 2)}},
