@@ -10,14 +10,18 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+# the chains whose difference lies outside the tier admission: a subset without the (oracle-heavy) admission sweep
+AFFINE_CORE = ["tests/test_gpu_affine.py::test_affine_small_mixed", "tests/test_gpu_affine.py::test_affine_long_ont",
+               "tests/test_gpu_affine.py::test_affine_probe_boundaries", "tests/test_gpu_affine.py::test_affine_packed_sequence_capacity_sweep"]
+
 CASES = [
     ("OTG_NO_AFFINE_BOUND", ["tests/test_gpu_affine.py"]),
     ("OTG_NO_AFFINE_V4", ["tests/test_gpu_affine.py"]),
     ("OTG_AFFINE_V5=0", ["tests/test_gpu_affine.py"]),                                   # LDS / HBM tiers only
     ("OTG_AFFINE_V5=25", ["tests/test_gpu_affine.py", "tests/test_gpu_poa.py"]),         # register tiers 1024 / 4096 / 8192 only: the 1472 / 2048 windows on the LDS tiers
     ("OTG_AFFINE_V5=31 OTG_V5_SHAPE=1121", ["tests/test_gpu_affine.py"]),                # the multi-wave shapes of the small tiers
-    ("OTG_AFFINE_V5=31 OTG_NO_AFFINE_V4=1", ["tests/test_gpu_affine.py"]),               # register tiers in front of the HBM-row tiers
-    ("OTG_AFFINE_BOUND_STATIC", ["tests/test_gpu_affine.py"]),
+    ("OTG_AFFINE_V5=31 OTG_NO_AFFINE_V4=1", AFFINE_CORE),               # register tiers in front of the HBM-row tiers
+    ("OTG_AFFINE_BOUND_STATIC", AFFINE_CORE),
     ("OTG_NO_AFFINE_SORT", ["tests/test_gpu_affine.py::test_affine_small_mixed", "tests/test_gpu_affine.py::test_affine_long_ont"]),
     ("OTG_NO_MYERS", ["tests/test_gpu_edit.py::test_edit_small_mixed", "tests/test_gpu_edit.py::test_edit_long_ont"]),
     ("OTG_NO_EDIT_ROUTE", ["tests/test_gpu_edit.py"]),
