@@ -78,7 +78,7 @@ def _parse_cigar(cigar):
 
 
 def write_bam(path, targets, records, level=1):
-    """targets: [(name, length)]; records: iterable of (tid, pos0, name, flag, mapq, cigar (str or [(len, opchar)]), seq (bytes or uint8 array), tags bytes)
+    """targets: [(name, length)]; records: iterable of (tid, pos0, name, flag, mapq, cigar (str, [(len, opchar)] or (lengths, BAM op codes) as arrays), seq (bytes or uint8 array), tags bytes)
     sorted by (tid, pos0).  Writes `path` and `path + '.bai'`.  Returns the number of records."""
     bg = _Bgzf(path, level)
     text = "@HD\tVN:1.4\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % (n, l) for n, l in targets)
@@ -92,10 +92,18 @@ def write_bam(path, targets, records, level=1):
     linear = [dict() for _ in targets]           # window -> min voffset
     count = 0
     for tid, pos, name, flag, mapq, cigar, seq, tags in records:
-        ops = _parse_cigar(cigar) if isinstance(cigar, str) else [(l, _CIGAR_OPS[o]) for l, o in cigar]
+        if isinstance(cigar, tuple):          # (lengths, BAM op codes) as arrays
+            cl, co = cigar
+            n_ops = int(len(cl))
+            ops_bytes = ((cl.astype(np.uint32) << 4) | co.astype(np.uint32)).astype("<u4").tobytes()
+            rlen = int(cl[np.isin(co, (0, 2, 3, 7, 8))].sum())
+        else:
+            ops = _parse_cigar(cigar) if isinstance(cigar, str) else [(l, _CIGAR_OPS[o]) for l, o in cigar]
+            n_ops = len(ops)
+            ops_bytes = b"".join(struct.pack("<I", (l << 4) | o) for l, o in ops)
+            rlen = sum(l for l, o in ops if o in (0, 2, 3, 7, 8))
         s = np.frombuffer(seq, dtype=np.uint8) if isinstance(seq, (bytes, bytearray)) else np.asarray(seq, dtype=np.uint8)
         lseq = int(s.size)
-        rlen = sum(l for l, o in ops if o in (0, 2, 3, 7, 8))
         end = pos + (rlen if rlen > 0 else 1)
         b = reg2bin(pos, end)
         codes = _NT16[s]
@@ -103,10 +111,10 @@ def write_bam(path, targets, records, level=1):
             codes = np.concatenate([codes, np.zeros(1, dtype=np.uint8)])
         packed = ((codes[0::2] << 4) | codes[1::2]).astype(np.uint8).tobytes()
         nb = name.encode() + b"\x00"
-        if len(ops) > 65535:
+        if n_ops > 65535:
             raise ValueError("more than 65535 CIGAR operations: not supported by this writer")
-        body = struct.pack("<iiBBHHHiiii", tid, pos, len(nb), mapq, b, len(ops), flag, lseq, -1, -1, 0) + nb + \
-            b"".join(struct.pack("<I", (l << 4) | o) for l, o in ops) + packed + b"\xff" * lseq + (tags or b"")
+        body = struct.pack("<iiBBHHHiiii", tid, pos, len(nb), mapq, b, n_ops, flag, lseq, -1, -1, 0) + nb + \
+            ops_bytes + packed + b"\xff" * lseq + (tags or b"")
         v0 = bg.tell()
         bg.write(struct.pack("<i", len(body)) + body)
         v1 = bg.tell()
@@ -147,35 +155,39 @@ def make_tr_fixture(dirname, n_regions, depth=30, len_range=(1000, 5000), seed=7
     ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
 
     def noisy(seq):
+        """ONT-like errors on `seq` with the op list that describes them, built without a Python loop over the bases: every reference
+        base contributes its inserted bases (0-3, op I) and then itself (op M) or nothing (op D)."""
         n = len(seq)
         kind = rng.random(n)
-        out, ops = [], []
-
-        def push(l, o):
-            if ops and ops[-1][1] == o:
-                ops[-1][0] += l
-            else:
-                ops.append([l, o])
         sub = kind < rate * 0.45
         ins = (kind >= rate * 0.45) & (kind < rate * 0.72)
         dele = (kind >= rate * 0.72) & (kind < rate)
         s2 = seq.copy()
         s2[sub] = ACGT[rng.integers(0, 4, int(sub.sum()))]
-        i = 0
-        for e in np.flatnonzero(ins | dele):
-            e = int(e)
-            if e > i:
-                out.append(s2[i:e]); push(e - i, "M")
-            if ins[e]:
-                k = int(rng.integers(1, 4))
-                out.append(ACGT[rng.integers(0, 4, k)]); push(k, "I")
-                out.append(s2[e:e + 1]); push(1, "M")
-            else:
-                push(1, "D")
-            i = e + 1
-        if i < n:
-            out.append(s2[i:]); push(n - i, "M")
-        return (np.concatenate(out) if out else np.zeros(0, np.uint8)), ops
+        ilen = np.zeros(n, dtype=np.int64)
+        ilen[ins] = rng.integers(1, 4, int(ins.sum()))
+        keep = ~dele
+        # read bases: per reference base `ilen` random bases, then the base itself unless deleted
+        cnt = ilen + keep
+        end = np.cumsum(cnt)
+        out = ACGT[rng.integers(0, 4, int(end[-1]) if n else 0)]
+        if n:
+            out[(end - 1)[keep]] = s2[keep]
+        # ops: per reference base `ilen` x I, then M or D; run-length encoded
+        ocnt = ilen + 1
+        oend = np.cumsum(ocnt)
+        codes = np.ones(int(oend[-1]) if n else 0, dtype=np.uint8)          # 1 = I
+        if n:
+            codes[oend - 1] = np.where(keep, 0, 2)                         # 0 = M, 2 = D
+        return out, codes
+
+    def rle(codes):
+        """(lengths, BAM op codes 0 = M, 1 = I, 2 = D) of a per-op code array."""
+        if codes.size == 0:
+            return np.zeros(0, dtype=np.uint32), np.zeros(0, dtype=np.uint8)
+        starts = np.concatenate(([0], np.flatnonzero(np.diff(codes)) + 1))
+        lens = np.diff(np.concatenate((starts, [codes.size]))).astype(np.uint32)
+        return lens, codes[starts]
 
     ref_parts, regions, recs = [], [], []
     pos = 0
@@ -192,23 +204,17 @@ def make_tr_fixture(dirname, n_regions, depth=30, len_range=(1000, 5000), seed=7
             a = d % 2
             lf, rf = int(rng.integers(200, 900)), int(rng.integers(200, 900))
             body = tr if delta[a] >= 0 else tr[:L + delta[a]]
-            left, ops_l = noisy(fl[flank - lf:])
-            mid, ops_m = noisy(body)
-            right, ops_r = noisy(fr[:rf])
-            ops = ops_l + ops_m
+            left, c_l = noisy(fl[flank - lf:])
+            mid, c_m = noisy(body)
+            right, c_r = noisy(fr[:rf])
             extra = np.zeros(0, np.uint8)
+            c_x = np.zeros(0, np.uint8)
             if delta[a] > 0:
                 extra = np.tile(motif, delta[a] // len(motif))
-                ops = ops + [[len(extra), "I"]]
+                c_x = np.full(len(extra), 1, dtype=np.uint8)
             elif delta[a] < 0:
-                ops = ops + [[-delta[a], "D"]]
-            merged = []
-            for l, o in ops + ops_r:
-                if merged and merged[-1][1] == o:
-                    merged[-1][0] += l
-                else:
-                    merged.append([l, o])
-            recs.append((0, start - lf, "r%d_%d" % (r, d), 0, 60, merged, np.concatenate([left, mid, extra, right]), b""))
+                c_x = np.full(-delta[a], 2, dtype=np.uint8)
+            recs.append((0, start - lf, "r%d_%d" % (r, d), 0, 60, rle(np.concatenate([c_l, c_m, c_x, c_r])), np.concatenate([left, mid, extra, right]), b""))
         pos += flank + L + flank
     recs.sort(key=lambda x: x[1])
     ref = np.concatenate(ref_parts)
