@@ -12,13 +12,14 @@ from test_gpu_pipeline import compare
 oracle_lib.lib()
 ctx = otter_amd.Context(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 96
+seed_off = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 cases = [dict(len_range=(1000, 5000), n_reads=30, err="ont", seed=101),
          dict(len_range=(1000, 5000), n_reads=30, err="ont", seed=102, realign=True),
          dict(len_range=(3000, 9000), n_reads=16, err="ont", seed=103),
          dict(len_range=(300, 1500), n_reads=40, err="hifi", seed=104)]
 nth = min(16, os.cpu_count() or 1)
 for c in cases:
-    kw = dict(c); realign = kw.pop("realign", False)
+    kw = dict(c); realign = kw.pop("realign", False); kw["seed"] += seed_off
     batch = synth.make_batch(n, realign=realign, **kw)
     P = abi.default_params(realign=1 if realign else 0)
     t0 = time.time()
