@@ -555,6 +555,11 @@ def assemble_files(bam, bed, fasta=None, read_group="", is_fasta=False, reads_on
     return b"".join(chunks), {k: getattr(st, k) for k, _ in abi.JobStats._fields_}
 
 
+def assemble_files_release():
+    """Frees the contexts (and their HBM workspaces) the dispatcher keeps for the next job of the process (otg_assemble_files_release)."""
+    load().otg_assemble_files_release()
+
+
 def wgat(bam, regions, read_group="", fasta=False, offset_l=1, offset_r=0):
     """otg_wgat: `otter wgat` on an open Bam handle; regions = list of (chr, start, end) or the (beds, chr_arena) pair.  Returns the text."""
     L = load()

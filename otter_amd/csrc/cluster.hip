@@ -190,18 +190,19 @@ struct Lds {
   int z1[NMAX], z2[NMAX], zrank[NMAX];
   int parent[2 * NMAX];
   int merge[2 * NMAX];
-  int labels[NMAX], labels2[NMAX], last_merge[NMAX], zz[NMAX + 1];
+  int labels[NMAX], labels2[NMAX];
+  int ct_up[NMAX + 1], ct_own[NMAX], ct_first[NMAX + 1], ct_lab[NMAX + 1];     // cutree_wave scratch
   int cnt[NMAX], maxsz[NMAX], req[NMAX], remap[NMAX];
   double total;
   int n_max, n_min, err;
   int do_hclust;
+  int cut_k, recut, ic, fc;
   double b0, b1, bc, dist_final, bandwidth;
 };
 
-// ---- The two functions below (cutree_k_dev, nn_chain_average) restate, operation for operation, the tree cutting and the NN-chain
-// average-linkage core of the vendored hclust-cpp / fastcluster the reference links (include/hclust-cpp/fastcluster.cpp:33-81,
-// fastcluster_dm.hpp:563-766): merge order, tie-breaks and the floating-point evaluation order of `s*a + t*b` decide the labels, so the
-// order of operations is kept.  That code carries this notice (BSD 2-clause, include/hclust-cpp/LICENSE):
+// ---- nn_chain_average below restates, operation for operation, the NN-chain average-linkage core of the vendored hclust-cpp / fastcluster
+// the reference links (include/hclust-cpp/fastcluster_dm.hpp:563-766): merge order, tie-breaks and the floating-point evaluation order of
+// `s*a + t*b` decide the labels, so the order of operations is kept.  That code carries this notice (BSD 2-clause, include/hclust-cpp/LICENSE):
 //
 //   fastcluster: Fast hierarchical clustering routines for R and Python.  Copyright (c) 2011 Daniel Müllner <http://danifold.net>.
 //   C++ standalone version (hclust-cpp): Copyright Christoph Dalitz, 2020; Daniel Müllner, 2011.  All rights reserved.
@@ -216,30 +217,53 @@ struct Lds {
 //   (INCLUDING, BUT NOT LIMITED TO, PROCUREMENT OF SUBSTITUTE GOODS OR SERVICES; LOSS OF USE, DATA, OR PROFITS; OR BUSINESS INTERRUPTION)
 //   HOWEVER CAUSED AND ON ANY THEORY OF LIABILITY, WHETHER IN CONTRACT, STRICT LIABILITY, OR TORT (INCLUDING NEGLIGENCE OR OTHERWISE)
 //   ARISING IN ANY WAY OUT OF THE USE OF THIS SOFTWARE, EVEN IF ADVISED OF THE POSSIBILITY OF SUCH DAMAGE.
-__device__ void cutree_k_dev(int n, const int* merge, int nclust, int* labels, int* last_merge, int* z)
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+// Tree cut into `nclust` clusters by ONE WAVE, with the numbering the reference's cutree_k produces (include/hclust-cpp/fastcluster.cpp:33-81:
+// clusters are numbered in the order in which their first observation appears, :69-80).  Own formulation: the first K = n - nclust rows of the
+// R-style merge matrix are a forest over the merge steps (a row names its two children: -j = observation j, +m = the cluster made by step m),
+//   1. every step scatters itself as the parent of its children (`up` for steps, `own` for observations) — one pass, all lanes;
+//   2. pointer jumping turns `up` into the root of every step's tree (a parent always has a larger step number: <= 8 rounds for 256 steps);
+//   3. every tree learns its lowest observation (LDS atomic min), observations that are that lowest one — or singletons — are the
+//      first appearances; a ballot + prefix count over them in index order hands out the labels; the rest copy their tree's label.
+// Call from all 64 lanes of a wave with uniform arguments.
+__device__ void cutree_wave(int n, const int* merge, int nclust, int* labels, int* up, int* own, int* firstobs, int* clab, int lane)
 {
-  if (nclust > n || nclust < 2) { for (int j = 0; j < n; j++) labels[j] = 0; return; }
-  for (int j = 0; j < n; ++j) last_merge[j] = 0;
-  for (int k = 1; k <= (n - nclust); k++) {
-    int m1 = merge[k - 1], m2 = merge[n - 1 + k - 1], j;
-    if (m1 < 0 && m2 < 0) { last_merge[-m1 - 1] = last_merge[-m2 - 1] = k; }
-    else if (m1 < 0 || m2 < 0) {
-      if (m1 < 0) { j = -m1; m1 = m2; } else j = -m2;
-      for (int l = 0; l < n; l++) if (last_merge[l] == m1) last_merge[l] = k;
-      last_merge[j - 1] = k;
-    } else {
-      for (int l = 0; l < n; l++) if (last_merge[l] == m1 || last_merge[l] == m2) last_merge[l] = k;
+  if (nclust > n || nclust < 2) { for (int j = lane; j < n; j += 64) labels[j] = 0; wave_sync(); return; }
+  const int K = n - nclust;
+  for (int k = lane; k <= K; k += 64) { up[k] = 0; firstobs[k] = n; }
+  for (int j = lane; j < n; j += 64) own[j] = 0;
+  wave_sync();
+  for (int k = lane + 1; k <= K; k += 64) {
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+      const int m = merge[(k - 1) + side * (n - 1)];
+      if (m < 0) own[-m - 1] = k; else up[m] = k;
     }
   }
-  int label = 0;
-  for (int j = 0; j <= n; ++j) z[j] = -1;
-  for (int j = 0; j < n; j++) {
-    if (last_merge[j] == 0) labels[j] = label++;
-    else {
-      if (z[last_merge[j]] < 0) z[last_merge[j]] = label++;
-      labels[j] = z[last_merge[j]];
-    }
+  wave_sync();
+  for (int d = 1; d < K; d <<= 1) {
+    for (int k = lane + 1; k <= K; k += 64) { const int u = up[k]; if (u) { const int uu = up[u]; if (uu) up[k] = uu; } }
+    wave_sync();
   }
+  for (int j = lane; j < n; j += 64) {
+    const int o = own[j];
+    if (o) { const int c = up[o] ? up[o] : o; own[j] = c; atomicMin(&firstobs[c], j); }
+  }
+  wave_sync();
+  int base = 0;
+  for (int j0 = 0; j0 < n; j0 += 64) {
+    const int j = j0 + lane;
+    const int c = j < n ? own[j] : 0;
+    const bool first = j < n && (c == 0 || firstobs[c] == j);
+    const unsigned long long fm = __ballot(first);
+    const int rank = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+    if (first) { if (c) clab[c] = rank; else labels[j] = rank; }
+    base += __builtin_popcountll(fm);
+  }
+  wave_sync();
+  for (int j = lane; j < n; j += 64) { const int c = own[j]; if (c) labels[j] = clab[c]; }
+  wave_sync();
 }
 
 // NN-chain average linkage run by ONE WAVE (64 lanes, uniform control flow; called by wave 0 of the block).  The chain logic is the
@@ -248,7 +272,6 @@ __device__ void cutree_k_dev(int n, const int* merge, int nclust, int* labels, i
 // ...  A nearest-neighbour search is a min-reduction over (distance, index) with ties to the LOWEST index, which is what the reference's
 // ascending strict-'<' scan returns (fastcluster_dm.hpp:612-640); the incumbent keeps its place on a tie, as there.  Same doubles, same
 // comparisons, same update expression per element => same merges.  L.pred doubles as the active flag here.
-__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 __device__ __forceinline__ double wave_min_f64(double v)
 {
 #pragma unroll
@@ -509,14 +532,19 @@ __global__ __launch_bounds__(256) void cluster_kernel(
     __syncthreads();
     hclust_to_merge(n, D, L, tid);
     if (tid == 0) {
-      // cutree_cdist (:185; fastcluster.cpp:95-105)
+      // cutree_cdist (:185; fastcluster.cpp:95-105): cut below the first merge whose height reaches dist_final
       int kc;
       for (kc = 0; kc < (n - 1); kc++) if (L.height[kc] >= L.dist_final) break;
-      cutree_k_dev(n, L.merge, n - kc, L.labels, L.last_merge, L.zz);
+      L.cut_k = n - kc;
+    }
+    __syncthreads();
+    if (tid < 64) cutree_wave(n, L.merge, L.cut_k, L.labels, L.ct_up, L.ct_own, L.ct_first, L.ct_lab, tid);
+    __syncthreads();
+    if (tid == 0) {
       int total_alleles = 0;
       for (int i = 0; i < n; ++i) if (L.labels[i] > total_alleles) total_alleles = L.labels[i];
       ++total_alleles;
-      int ic = total_alleles, fc = 0;
+      int ic = total_alleles, fc = 0, recut = 0;
       const int min_cov1 = (int)(n * A.min_cov_fraction + 0.5);
       const int min_cov2 = (int)(n * A.min_cov_fraction2_f + 0.5);
       if (A.max_alleles != 0) {
@@ -525,39 +553,40 @@ __global__ __launch_bounds__(256) void cluster_kernel(
         for (int l = 0; l < total_alleles; ++l) L.req[l] = (L.maxsz[l] < A.min_cov_fraction2_l) ? min_cov1 : min_cov2;
         bool only_single = true;
         for (int l = 0; l < total_alleles; ++l) if (L.cnt[l] >= L.req[l]) { only_single = false; break; }
-        if (only_single) {
-          cutree_k_dev(n, L.merge, A.max_alleles, L.labels2, L.last_merge, L.zz);
-          fc = A.max_alleles;
-          for (int i = 0; i < n; ++i) L.labels[i] = L.labels2[i];
+        int seeds = 0;
+        for (int l = 0; l < total_alleles; ++l) if (!(L.cnt[l] < L.req[l])) ++seeds;
+        if (only_single || seeds == 0 || seeds > A.max_alleles) {
+          recut = 1; fc = A.max_alleles;              // cutree_k(max_alleles) replaces the labels (:200-212, :243-249)
         } else {
-          int seeds = 0;
-          for (int l = 0; l < total_alleles; ++l) if (!(L.cnt[l] < L.req[l])) ++seeds;
-          if (seeds == 0 || seeds > A.max_alleles) {
-            cutree_k_dev(n, L.merge, A.max_alleles, L.labels, L.last_merge, L.zz);
-            fc = A.max_alleles;
-          } else {
-            int sj = 0;
-            for (int l = 0; l < total_alleles; ++l) L.remap[l] = (L.cnt[l] < L.req[l]) ? -1 : sj++;
-            for (int i = 0; i < n; ++i) L.labels[i] = L.remap[L.labels[i]];
-            for (int i = 0; i < n; ++i) {
-              if (L.labels[i] == -1) {
-                int closest_j = 0;
-                double min_dist = 100000.0;
-                for (int j = 0; j < n; ++j) {
-                  if (i != j && L.labels[j] != -1) {
-                    const double jd = dget(dv, n, i, j);
-                    if (jd < min_dist) { closest_j = j; min_dist = jd; }
-                  }
+          int sj = 0;
+          for (int l = 0; l < total_alleles; ++l) L.remap[l] = (L.cnt[l] < L.req[l]) ? -1 : sj++;
+          for (int i = 0; i < n; ++i) L.labels[i] = L.remap[L.labels[i]];
+          for (int i = 0; i < n; ++i) {
+            if (L.labels[i] == -1) {
+              int closest_j = 0;
+              double min_dist = 100000.0;
+              for (int j = 0; j < n; ++j) {
+                if (i != j && L.labels[j] != -1) {
+                  const double jd = dget(dv, n, i, j);
+                  if (jd < min_dist) { closest_j = j; min_dist = jd; }
                 }
-                L.labels[i] = L.labels[closest_j];
               }
+              L.labels[i] = L.labels[closest_j];
             }
-            fc = seeds;
           }
+          fc = seeds;
         }
       }
-      for (int i = 0; i < n; ++i) lab[i] = L.labels[i];
-      ic_out[r] = ic; fc_out[r] = fc;
+      L.ic = ic; L.fc = fc; L.recut = recut;
+    }
+    __syncthreads();
+    if (L.recut) {
+      if (tid < 64) cutree_wave(n, L.merge, A.max_alleles, L.labels, L.ct_up, L.ct_own, L.ct_first, L.ct_lab, tid);
+      __syncthreads();
+    }
+    for (int i = tid; i < n; i += blockDim.x) lab[i] = L.labels[i];
+    if (tid == 0) {
+      ic_out[r] = L.ic; fc_out[r] = L.fc;
       if (bounds_out) { bounds_out[3 * r] = L.b0; bounds_out[3 * r + 1] = L.b1; bounds_out[3 * r + 2] = L.bc; }
       if (err_out) err_out[r] = 0;
     }
@@ -636,20 +665,19 @@ __global__ __launch_bounds__(256) void genotype_kernel(
     __syncthreads();
     // length clustering
     hclust_to_merge(A, wk, L, tid);
-    if (tid == 0) {
-      int kc;
-      for (kc = 0; kc < (A - 1); kc++) if (L.height[kc] >= max_error_l) break;
-      cutree_k_dev(A, L.merge, A - kc, L.labels, L.last_merge, L.zz);
-      for (int a = 0; a < A; ++a) gt_l[f + a] = L.labels[a];
-    }
+    if (tid == 0) { int kc; for (kc = 0; kc < (A - 1); kc++) if (L.height[kc] >= max_error_l) break; L.cut_k = A - kc; }
     __syncthreads();
+    if (tid < 64) cutree_wave(A, L.merge, L.cut_k, L.labels, L.ct_up, L.ct_own, L.ct_first, L.ct_lab, tid);
+    __syncthreads();
+    for (int a = tid; a < A; a += blockDim.x) gt_l[f + a] = L.labels[a];
     for (size_t q = tid; q < (size_t)A * (A - 1) / 2; q += blockDim.x) wk[q] = dk[q];
     __syncthreads();
     hclust_to_merge(A, wk, L, tid);
+    if (tid == 0) { int kc; for (kc = 0; kc < (A - 1); kc++) if (L.height[kc] >= max_error_c) break; L.cut_k = A - kc; }
+    __syncthreads();
+    if (tid < 64) cutree_wave(A, L.merge, L.cut_k, L.labels2, L.ct_up, L.ct_own, L.ct_first, L.ct_lab, tid);
+    __syncthreads();
     if (tid == 0) {
-      int kc;
-      for (kc = 0; kc < (A - 1); kc++) if (L.height[kc] >= max_error_c) break;
-      cutree_k_dev(A, L.merge, A - kc, L.labels2, L.last_merge, L.zz);
       for (int a = 0; a < A; ++a) gt_k[f + a] = L.labels2[a];
       // final clusters: distinct (gt_l, gt_k) in first-seen order (:500-516)
       int ng = 0;

@@ -105,6 +105,28 @@ otg_ctx* pool_acquire(int device)
 }
 void pool_release(int device, otg_ctx* c) { std::lock_guard<std::mutex> lk(g_pool_m); g_pool.emplace_back(device, c); }
 
+int dispatch_contexts()
+{
+  const char* e = getenv("OTG_DISPATCH_CONTEXTS");
+  const int v = e ? atoi(e) : 2;
+  return v < 1 ? 1 : (v > 4 ? 4 : v);
+}
+// End of a job: the pool keeps what ONE shard per device needs for the next job and destroys the rest — contexts hold multi-gigabyte aligner
+// workspaces, and a caller that creates its own otg_ctx afterwards is budgeted against what is left of the device.
+void pool_trim(const std::vector<int>& devs)
+{
+  std::lock_guard<std::mutex> lk(g_pool_m);
+  const int keep = dispatch_contexts();
+  std::map<int, int> seen;
+  std::vector<std::pair<int, otg_ctx*>> kept;
+  for (auto& p : g_pool) {
+    if (++seen[p.first] <= keep) kept.push_back(p);
+    else otg_destroy(p.second);
+  }
+  (void)devs;
+  g_pool.swap(kept);
+}
+
 std::string last_err() { const char* e = otg_last_error(nullptr); return e ? std::string(e) : std::string(); }
 
 // ---- stage 1: one batch of regions from the BAM (and the FASTA flanks with -r), buffers grown on OTG_ERR_CAPACITY
@@ -202,21 +224,41 @@ struct ShardOut {
   std::condition_variable cv;
   std::map<uint32_t, std::string> ready;    // batch index -> text
   uint32_t n_batches = 0;
+  uint32_t next = 0;                        // the batch the writer takes next
+  size_t cap = 3;                           // finished batches a shard may hold back (the writer drains the shards one after the other)
+};
+
+// Batch objects cycle between the ingest thread and the hot-path threads of a shard: their vectors keep the capacity of the batches they
+// have carried (no 400 MB zero-fill per batch; at most 2 x contexts + 2 objects exist per shard).
+struct BatchPool {
+  std::mutex m;
+  std::vector<std::unique_ptr<Batch>> free_;
+  std::unique_ptr<Batch> get() {
+    std::lock_guard<std::mutex> lk(m);
+    if (free_.empty()) return std::unique_ptr<Batch>(new Batch());
+    std::unique_ptr<Batch> b = std::move(free_.back());
+    free_.pop_back();
+    return b;
+  }
+  void put(std::unique_ptr<Batch> b) { b->text.clear(); std::lock_guard<std::mutex> lk(m); free_.push_back(std::move(b)); }
 };
 
 void shard_worker(Job& J, int device, uint32_t a, uint32_t bnd, int ingest_threads, ShardOut& out)
 {
+  if (a >= bnd) return;                 // more devices than regions: nothing to do here (and no context to create)
   const uint32_t per = J.j->batch_regions ? J.j->batch_regions : 2048u;
   // hot-path threads (one context each) per device: a batch of a few hundred regions cannot fill the device — its stages wait for their
   // longest alignment / graph — so several batches are in flight; OTG_DISPATCH_CONTEXTS overrides (1..4)
-  const int n_gpu_threads = [] { const char* e = getenv("OTG_DISPATCH_CONTEXTS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
+  const int n_gpu_threads = dispatch_contexts();
   BoundedQueue<BatchPtr> q_in((size_t)n_gpu_threads);
+  BatchPool recycled;
+  { std::lock_guard<std::mutex> lk(out.m); out.cap = (size_t)n_gpu_threads + 1; }
   double ms_ingest = 0, ms_gpu[4] = {0, 0, 0, 0}, ms_emit[4] = {0, 0, 0, 0};
   std::thread ingest([&] {
     try {
       uint32_t idx = 0;
       for (uint32_t f = a; f < bnd && J.rc.load() == OTG_OK; f += per, ++idx) {
-        BatchPtr b(new Batch());
+        BatchPtr b = recycled.get();
         b->index = idx; b->first = f; b->n = std::min(per, bnd - f);
         const auto t0 = Clock::now();
         const int rc = ingest_batch(J, *b, ingest_threads);
@@ -238,8 +280,16 @@ void shard_worker(Job& J, int device, uint32_t a, uint32_t bnd, int ingest_threa
       while (J.rc.load() == OTG_OK && q_in.pop(b)) {
         const int rc = run_batch(J, ctx, *b, rr, al, seqs, &ms_gpu[slot], &ms_emit[slot]);
         if (rc != OTG_OK) { J.fail(rc, "hot path: " + (ctx && otg_last_error(ctx) ? std::string(otg_last_error(ctx)) : last_err())); q_in.abort(); break; }
-        { std::lock_guard<std::mutex> lk(out.m); out.ready.emplace(b->index, std::move(b->text)); }
+        {
+          // Back-pressure: the writer drains the shards strictly in order, so a shard it has not reached yet may hold back `cap` finished
+          // batches and no more (host memory stays bounded by the batch size, not by the shard).  The batch the writer wants next always
+          // gets in — the threads of a shard finish out of order, and that batch may be the last one to arrive.
+          std::unique_lock<std::mutex> lk(out.m);
+          while (!(out.ready.size() < out.cap || b->index == out.next || J.rc.load() != OTG_OK)) out.cv.wait_for(lk, std::chrono::milliseconds(50));
+          out.ready.emplace(b->index, std::move(b->text));
+        }
         out.cv.notify_all();
+        recycled.put(std::move(b));
       }
     } catch (const std::exception& e) { J.fail(OTG_ERR_ARG, std::string("hot path: ") + e.what()); }
     if (J.rc.load() != OTG_OK) q_in.abort();               // whatever stopped the job: release the ingest thread
@@ -329,7 +379,9 @@ int otg_assemble_files(const otg_assemble_job* job, otg_write_fn write, void* us
         if (!o.ready.count(k)) break;
         text = std::move(o.ready[k]);
         o.ready.erase(k);
+        o.next = k + 1;
       }
+      o.cv.notify_all();                    // room for the shard's hot-path threads
       if (!text.empty() && write(user, text.data(), text.size()) != 0) { J.fail(OTG_ERR_ARG, "the writer failed"); break; }
       J.st.output_bytes += text.size();
     }
@@ -337,6 +389,7 @@ int otg_assemble_files(const otg_assemble_job* job, otg_write_fn write, void* us
   }
   for (auto& t : workers) t.join();
   cleanup();
+  pool_trim(devs);
   J.st.ms_total = ms_since(t_all);
   J.st.n_devices = W;
   if (stats) *stats = J.st;

@@ -18,6 +18,12 @@ int otg_fail(otg_ctx* ctx, int code, const char* fmt, ...)
   return code;
 }
 
+std::mutex& otg_device_mutex(int device)
+{
+  static std::mutex m[64];
+  return m[(unsigned)device % 64u];
+}
+
 void* otg_slot(otg_ctx* ctx, int slot, size_t bytes)
 {
   if (bytes == 0) bytes = 16;

@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "../../include/otter_gpu.h"
@@ -57,6 +58,10 @@ enum {
 };
 
 void otg_pipeline_free(otg_ctx* ctx);
+
+// Contexts that share a device (the dispatcher runs 2-4 per GPU) size their multi-gigabyte workspaces from hipMemGetInfo; two of them doing so
+// at the same moment would both claim the same free bytes.  Every "measure free memory, then allocate" section holds this lock.
+std::mutex& otg_device_mutex(int device);
 
 #if defined(__HIPCC__)
 // One atomic add per WAVE, issued with exec forced to lane 0 and no divergent branch in the HIP source.

@@ -180,3 +180,53 @@ def test_dispatcher_reads_only(gpu, oracle, tmp_path):
             otter_amd.Fasta(fasta_ref).region_flanks(beds, carena, batch, flank=100, offset_l=1, offset_r=1)
             batch = dict(batch, reads=gpu.realign_reads(abi.default_params(realign=1), batch))
         assert whole == hdr + otter_amd.emit_reads(beds, carena, batch, read_group="s1", fasta=False, max_cov=200)
+
+
+@pytest.mark.gpu
+def test_dispatcher_shards_on_one_device(gpu, tmp_path):
+    """The dispatcher's multi-shard path (one contiguous BED shard per entry of the device list = the reference's static split over worker
+    threads, src/BS_thread_pool.hpp:183-198) exercised on ONE card by naming device 0 two and three times: every shard has its own ingest
+    thread, hot-path contexts and back-pressure bound, the writer drains the shards in order.  The text must be byte-identical to the
+    single-shard run whatever the number of shards and the batch size — also when there are fewer regions than shards (block == 0)."""
+    import os
+    from otter_amd import bamwrite
+    fx = bamwrite.make_tr_fixture(str(tmp_path), 23, depth=12, len_range=(300, 900), seed=5)
+    kw = dict(read_group="s1", offset_l=1, offset_r=1, mapq=10, threads=4)
+    gpu.trim()                              # the session context's aligner workspaces: room for the dispatcher's own contexts
+    one, st1 = otter_amd.assemble_files(fx["bam"], fx["bed"], batch_regions=0, **kw)
+    assert st1["n_regions"] == 23 and st1["n_regions_ok"] >= 20 and one.count(b"\n") > 23
+    for devs in ([0, 0], [0, 0, 0]):
+        for batch in (2, 5, 0):
+            text, st = otter_amd.assemble_files(fx["bam"], fx["bed"], batch_regions=batch, devices=devs, **kw)
+            assert text == one, (devs, batch)
+            assert st["n_devices"] == len(devs) and st["n_alleles"] == st1["n_alleles"] and st["n_regions_ok"] == st1["n_regions_ok"]
+    # fewer regions than shards: the first two regions alone, three shards
+    two_bed = os.path.join(str(tmp_path), "two.bed")
+    with open(fx["bed"]) as f:
+        lines = f.readlines()
+    with open(two_bed, "w") as f:
+        f.writelines(lines[:2])
+    a, _ = otter_amd.assemble_files(fx["bam"], two_bed, batch_regions=0, **kw)
+    b3, st3 = otter_amd.assemble_files(fx["bam"], two_bed, batch_regions=1, devices=[0, 0, 0], **kw)
+    assert a == b3 and st3["n_regions"] == 2
+    fa1, _ = otter_amd.assemble_files(fx["bam"], fx["bed"], batch_regions=0, is_fasta=True, **kw)
+    fa2, _ = otter_amd.assemble_files(fx["bam"], fx["bed"], batch_regions=3, is_fasta=True, devices=[0, 0], **kw)
+    assert fa1 == fa2 and fa1.startswith(b">")
+    otter_amd.assemble_files_release()
+
+
+@pytest.mark.gpu
+def test_dispatcher_two_devices(gpu, tmp_path):
+    """otg_assemble_files over two real devices (n_devices = 2: the C++ host's multi-GPU form, no collective — the writer thread orders the
+    shards as the reference's mutex section orders its threads' output, src/assemble.cpp:143-149): byte-identical to the one-device text.
+    Needs two visible devices; the round's box has one."""
+    import otter_amd
+    if otter_amd.device_count() < 2:
+        pytest.skip("one HIP device visible")
+    from otter_amd import bamwrite
+    fx = bamwrite.make_tr_fixture(str(tmp_path), 40, depth=14, len_range=(400, 1500), seed=6)
+    kw = dict(read_group="s1", offset_l=1, offset_r=1, mapq=10, threads=4)
+    one, _ = otter_amd.assemble_files(fx["bam"], fx["bed"], batch_regions=0, **kw)
+    two, st = otter_amd.assemble_files(fx["bam"], fx["bed"], batch_regions=7, devices=[0, 1], **kw)
+    assert one == two and st["n_devices"] == 2
+    otter_amd.assemble_files_release()

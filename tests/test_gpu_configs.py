@@ -79,7 +79,8 @@ def windows_with(score, width, count, n):
 
 def test_full_size_config2_realign_properties(gpu, oracle):
     """BASELINE configs[2]: 10 000 divergent-flank regions x 30 ONT reads of 1-5 kb with -r (local re-alignment triggered: a quarter of the
-    reads carry a soft-clipped flank of 150-400 bp, 60 % of them rescuable)."""
+    reads carry a soft-clipped flank of 150-400 bp; 60 % of those flanks are the true flank read with ONT errors, and at 7 % error about half of
+    them still reach min_sim 0.9 over the 100-bp flank: ~27 % of the clipped reads = 6.8 % of all reads are rescued, measured)."""
     b = synth.config_batch(2)
     N = len(b["regions"])
     assert N == synth.CONFIGS[2]["n_regions"] == 10000
@@ -87,7 +88,7 @@ def test_full_size_config2_realign_properties(gpu, oracle):
     # reads that local_realignment rescues, per region: windows are taken where most of them are
     trimmed = gpu.realign_reads(P, b)
     changed = (trimmed["seq_len"] != b["reads"]["seq_len"]) | (trimmed["seq_off"] != b["reads"]["seq_off"])
-    assert changed.sum() > 0.05 * len(changed)                     # 25 % clipped, 60 % of those rescuable, min_sim 0.9 over the flank
+    assert changed.sum() > 0.05 * len(changed)                     # measured share: 6.8 % of all reads (see the docstring); the floor only says the rescue is live
     assert (trimmed["spanning_l"][changed] == 1).all() and (trimmed["spanning_r"][changed] == 1).all()
     first = b["regions"]["first_read"].astype(np.int64)
     per_region = np.add.reduceat(changed.astype(np.int64), first)
@@ -95,6 +96,12 @@ def test_full_size_config2_realign_properties(gpu, oracle):
     assert per_region[windows[2][0]:windows[2][1]].sum() >= 12
     r1, st = full_size_properties(gpu, oracle, b, P, windows, (4000, 4064), 30)
     assert float(st["ms_realign"]) > 0 and int(st["n_regions_ok"]) > 0.99 * N
+    # the first 1 000 regions against the committed oracle digests (computed four regions at a time; here inside the 10 000-region batch)
+    import digests
+    from test_gpu_digests import load_digest
+    want = load_digest(2)
+    nd = int(want["n_regions"][0])
+    assert digests.compare(digests.digest(r1, b, 0, nd), want, "configs[2] inside the full batch")[0] == nd
     # the rescue matters: without -r the same batch gives different alleles somewhere in the windows' regions
     lo, hi = windows[2]
     r0 = gpu.assemble(abi.default_params(), b, region_range=(lo, hi))

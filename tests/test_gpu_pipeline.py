@@ -170,12 +170,20 @@ def test_full_size_config1_properties(gpu, oracle):
     """BASELINE configs[1] at full size (10 000 regions x 30 ONT reads of 1-5 kb, the bench workload), checked through what
     does not need the oracle on every region: two runs agree bit for bit; a shard run alone equals the same regions inside the whole
     batch; coverage / label / length invariants hold for every region; and three 16-region windows at the start, middle and end
-    equal the oracle record for record."""
+    equal the oracle record for record.  The batch is synth.config_batch(1) — the very bytes bench.py times — and its first 1 250 regions
+    must equal the committed oracle digests (tests/golden/digest_c1.npz) although they are computed inside the 10 000-region batch here
+    and were computed four regions at a time by the oracle: results do not depend on batch composition."""
     import threading
+    import digests
+    from test_gpu_digests import load_digest
     N = 10000
-    b = synth.make_batch(N, len_range=(1000, 5000), n_reads=30, err="ont", seed=synth.SEED)
+    b = synth.config_batch(1)
+    assert len(b["regions"]) == N == synth.CONFIGS[1]["n_regions"]
     P = abi.default_params()
     r1 = gpu.assemble(P, b)
+    want = load_digest(1)
+    nd = int(want["n_regions"][0])
+    assert digests.compare(digests.digest(r1, b, 0, nd), want, "configs[1] inside the full batch")[0] == nd
     r2 = gpu.assemble(P, b)
     for k in ("regions", "alleles", "labels"):
         assert r1[k].tobytes() == r2[k].tobytes(), k
