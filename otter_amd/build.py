@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libotter_gpu.so")
-SOURCES = ["otg_api.hip", "wfa_edit.hip", "myers_edit.hip", "wfa_affine.hip", "cluster.hip", "poa.hip", "pipeline.hip", "emit.hip", "ingest.hip", "bedfa.hip", "dispatch.hip"]
+SOURCES = ["otg_api.hip", "wfa_edit.hip", "myers_edit.hip", "wfa_affine.hip", "wfa_affine_reg.hip", "cluster.hip", "poa.hip", "pipeline.hip", "emit.hip", "ingest.hip", "bedfa.hip", "dispatch.hip"]
 # -ffp-contract=off: the reference's clustering decisions are FP64 comparisons made without FMA
 # contraction; fused operations are written explicitly where glibc uses them.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
@@ -40,9 +40,8 @@ def build(force=False, verbose=False, jobs=4):
         path = os.path.join(CSRC, src)
         obj = os.path.join(CSRC, "build", src.replace(".hip", ".o"))
         objs.append(obj)
-        if (not force) and os.path.exists(obj) and os.path.getmtime(obj) > max(
-                os.path.getmtime(path), os.path.getmtime(os.path.join(CSRC, "otg_common.hpp")),
-                os.path.getmtime(os.path.join(HERE, "..", "include", "otter_gpu.h"))):
+        headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc"))] + [os.path.join(HERE, "..", "include", "otter_gpu.h")]
+        if (not force) and os.path.exists(obj) and os.path.getmtime(obj) > max([os.path.getmtime(path)] + [os.path.getmtime(h) for h in headers]):
             continue
         cmd = [cc] + FLAGS + ["-c", path, "-o", obj]
         if verbose:

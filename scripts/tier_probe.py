@@ -1,5 +1,5 @@
-"""One batch of same-sized gap-affine alignments through whichever exact tier the environment switches select (OTG_AFFINE_V5 mask,
-OTG_V5_SHAPE): times the second call of otg_affine_align_batch.  Used to compare tiers on identical work.
+"""One batch of same-sized gap-affine alignments through whichever exact tier the environment switches select (OTG_AFFINE_REG mask,
+OTG_REG_SHAPE): times the second call of otg_affine_align_batch.  Used to compare tiers on identical work.
 usage: python scripts/tier_probe.py [read_len] [n_pairs] [error_rate]"""
 import os
 import sys
@@ -29,4 +29,4 @@ t0 = time.time()
 sc, _ = gpu.affine_align_batch(arena, tasks)
 dt = time.time() - t0
 print("len %d x %d pairs, rate %.2f: mean score %.0f (reduced %.0f), mask %s shape %s: %.1f ms" % (
-    L, N, rate, sc.mean(), sc.mean() / 2, os.environ.get("OTG_AFFINE_V5", "default"), os.environ.get("OTG_V5_SHAPE", "0"), dt * 1e3))
+    L, N, rate, sc.mean(), sc.mean() / 2, os.environ.get("OTG_AFFINE_REG", "default"), os.environ.get("OTG_REG_SHAPE", "0"), dt * 1e3))

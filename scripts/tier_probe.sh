@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp
 L=$1; N=$2; R=$3
 for ms in $4; do
-  export OTG_AFFINE_V5=${ms%%:*} OTG_V5_SHAPE=${ms##*:}
+  export OTG_AFFINE_REG=${ms%%:*} OTG_REG_SHAPE=${ms##*:}
   rm -rf /tmp/tp_prof
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tp_prof -- python3 $GRAFT_REPO_ROOT/scripts/tier_probe.py $L $N $R > /tmp/tp.log 2>&1 || { tail -5 /tmp/tp.log; exit 1; }
   grep "^len" /tmp/tp.log

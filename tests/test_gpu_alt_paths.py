@@ -1,5 +1,5 @@
 """GPU parity of the alternative kernel paths.  The library picks its tier chains by itself; environment switches
-(read once per process) force the fallback chains — un-bounded affine pass, HBM-ring affine tiers, wavefront-only edit
+(read once per process) force the fallback chains — un-bounded affine pass, HBM-row affine tiers, the generic affine kernel, wavefront-only edit
 distance, un-routed / un-sorted bit-parallel tiers, POA graphs in global memory only.  Every chain must be bit-exact, so the
 aligner / POA parity tests are re-run in a child process per switch."""
 import os
@@ -10,28 +10,20 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-# the chains whose difference lies outside the tier admission: a subset without the (oracle-heavy) admission sweep
+# a subset of the aligner tests without the (oracle-heavy) admission sweep, for the chains whose difference lies outside the tier admission
 AFFINE_CORE = ["tests/test_gpu_affine.py::test_affine_small_mixed", "tests/test_gpu_affine.py::test_affine_long_ont",
                "tests/test_gpu_affine.py::test_affine_probe_boundaries", "tests/test_gpu_affine.py::test_affine_packed_sequence_capacity_sweep"]
 
 CASES = [
-    ("OTG_NO_AFFINE_BOUND", ["tests/test_gpu_affine.py"]),
-    ("OTG_NO_AFFINE_V4", ["tests/test_gpu_affine.py"]),
-    ("OTG_AFFINE_V5=0", ["tests/test_gpu_affine.py"]),                                   # LDS / HBM tiers only
-    ("OTG_AFFINE_V5=25", ["tests/test_gpu_affine.py", "tests/test_gpu_poa.py"]),         # register tiers 1024 / 4096 / 8192 only: the 1472 / 2048 windows on the LDS tiers
-    ("OTG_AFFINE_V5=31 OTG_V5_SHAPE=1121", ["tests/test_gpu_affine.py"]),                # the multi-wave shapes of the small tiers
-    ("OTG_AFFINE_V5=31 OTG_NO_AFFINE_V4=1", AFFINE_CORE),               # register tiers in front of the HBM-row tiers
-    ("OTG_AFFINE_BOUND_STATIC", AFFINE_CORE),
-    ("OTG_NO_AFFINE_SORT", ["tests/test_gpu_affine.py::test_affine_small_mixed", "tests/test_gpu_affine.py::test_affine_long_ont"]),
+    ("OTG_NO_AFFINE_BOUND", ["tests/test_gpu_affine.py"]),                               # no score bound: everything on the HBM-row tiers, un-pruned
+    ("OTG_AFFINE_REG=0", ["tests/test_gpu_affine.py"]),                                  # bound + HBM-row tiers only (what the register tiers fall back to)
+    ("OTG_AFFINE_REG=25", ["tests/test_gpu_affine.py", "tests/test_gpu_poa.py"]),        # register tiers 1024 / 4096 / 8192 only: the 1536 / 2048 windows on the multi-wave tier
+    ("OTG_NO_AFFINE_V3", AFFINE_CORE),                                                   # generic kernel only
     ("OTG_NO_MYERS", ["tests/test_gpu_edit.py::test_edit_small_mixed", "tests/test_gpu_edit.py::test_edit_long_ont"]),
-    ("OTG_NO_EDIT_ROUTE", ["tests/test_gpu_edit.py"]),
-    ("OTG_NO_EDIT_SORT", ["tests/test_gpu_edit.py"]),
+    ("OTG_NO_EDIT_ROUTE OTG_NO_EDIT_SORT", ["tests/test_gpu_edit.py"]),
     ("OTG_NO_EDIT_SAMPLE", ["tests/test_gpu_edit.py"]),
-    ("OTG_POA_NO_LDS", ["tests/test_gpu_poa.py"]),
-    ("OTG_POA_V1", ["tests/test_gpu_poa.py", "tests/test_gpu_pipeline.py::test_ont_kb"]),     # first-generation POA: serial threading, Kahn sweep
-    ("OTG_POA_V1 OTG_POA_NO_LDS", ["tests/test_gpu_poa.py"]),
+    ("OTG_POA_V1 OTG_POA_NO_LDS", ["tests/test_gpu_poa.py", "tests/test_gpu_pipeline.py::test_ont_kb"]),   # first-generation POA (serial threading, Kahn sweep), global memory only
     ("OTG_POA_PIECE_MB=1", ["tests/test_gpu_poa.py", "tests/test_gpu_pipeline.py::test_ont_kb"]),         # graph images in many small pieces that reuse the work arrays
-    ("OTG_POA_PIECE_MB=1 OTG_POA_NO_LDS", ["tests/test_gpu_poa.py"]),
     ("OTG_NO_REASSIGN_REV", ["tests/test_gpu_pipeline.py::test_haps_mode", "tests/test_gpu_pipeline.py::test_ont_kb"]),
 ]
 
