@@ -2,18 +2,23 @@
 """bench.py — regions/sec of the otter assemble hot path on MI355X (contract in the task brief).
 
 A step = one pass of the whole hot path ([local_realignment] -> fill_dist_matrix -> otter_hclust ->
-invalid_reassignment -> rapid_consensus) over one batch of synthetic TR regions that is already resident in HBM
+invalid_reassignment -> rapid_consensus; src/assemble.cpp:71-150) over one batch of synthetic TR regions that is already resident in HBM
 (otg_assemble_submit ran before the timed region), INCLUDING the hand-over of the allele records to the host:
 otg_assemble_collect at N=1, the RCCL gather to rank 0 + its one device-to-host copy at N>1.
 
-Workloads come from otter_amd.synth.CONFIGS (= BASELINE.json configs): --config 1 (default at every N: 10 000 regions x 1-5 kb,
-30x ONT per GPU), --config 2 (the same with -r and soft-clipped divergent flanks), --config 4 (1-10 kb regions, 12 500 per GPU = the
-per-GPU shard of the 100 000-region 8-GPU job).  N>1: static contiguous BED split (rank r owns the
-r-th shard, weak scaling), no data-path collective, end-of-run gather of the records over RCCL as north_star specifies.
+`value` is BASELINE configs[1] (10 000 regions x 1-5 kb, 30x ONT per GPU; weak scaling over identical per-GPU shards at every N).  At N = 1 the
+line also carries, under `config`:
+  host_to_host   the same batch from host memory to records in host memory (SURVEY §8d's kernel-path metric: submit + run + collect);
+  legs           configs[2] (the same with -r and soft-clipped divergent flanks), configs[4] (north_star's shape: 1-10 kb regions, the
+                 12 500-region shard one GPU owns of the 100 000-region 8-GPU job) and configs[3] (otter genotype's allele clustering,
+                 5 000 regions x 101 alleles), each with value / ms_per_step / stage_ms / roofline (/ cpu_baseline);
+  e2e            BED + BAM -> SAM text through the library's dispatcher on 10 000 loci of configs[1]'s shape.
+--config N makes another configuration the timed one; --no-legs / --e2e-regions 0 / --no-cpu-baseline switch the extras off.
 
 `python bench.py --gpus N` without a launcher starts the N ranks itself: the parent never imports torch or touches the
 GPU, it starts N fresh child processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set before anything is imported) and
-relays rank 0's line; under torchrun (WORLD_SIZE set) it is simply one rank.
+relays rank 0's line; under torchrun (WORLD_SIZE set) it is simply one rank.  Every batch is generated (worker processes) BEFORE torch is
+imported or a context exists: nothing forks from a process that has initialised the GPU.
 
 Prints ONE JSON line on rank 0."""
 import argparse
@@ -31,6 +36,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "pmc_summary.json")   # written by scripts/pmc_bench.sh + scripts/pmc_summarize.py
+METRIC = "regions/sec (otter assemble) on synthetic TR BED+BAM, 1/2/4/8 MI355X"      # BASELINE.json's metric, verbatim
 
 
 def parse_args():
@@ -38,11 +44,13 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", type=int, default=None, choices=(1, 2, 4), help="BASELINE.json configs index (default 1 at every N: weak scaling over identical per-GPU shards)")
+    ap.add_argument("--config", type=int, default=None, choices=(1, 2, 3, 4), help="BASELINE.json configs index of the timed workload (default 1 at every N)")
     ap.add_argument("--regions", type=int, default=None, help="regions per GPU (default: the config's own count; config 4: 100000/8)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU work per cpu_baseline run (3 runs per kind)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--e2e-regions", type=int, default=4000, help="regions of the file-to-text leg (BED + BAM -> SAM text through otg_assemble_files); 0: skip")
+    ap.add_argument("--no-legs", action="store_true", help="skip the configs[2] / [3] / [4] legs (N = 1 only has them)")
+    ap.add_argument("--leg-steps", type=int, default=3)
+    ap.add_argument("--e2e-regions", type=int, default=10000, help="regions of the file-to-text leg (BED + BAM -> SAM text through otg_assemble_files); 0: skip")
     return ap.parse_args()
 
 
@@ -80,13 +88,13 @@ def spawn_ranks(n):
 
 
 # ------------------------------------------------------------------------------------------------ CPU baselines
-def cpu_baseline(batch, params, seconds, n_threads):
+def cpu_baseline(batch, params, seconds, n_threads, runs=3, with_reference_consensus=True):
     """The CPU oracle (oracle/libotter_oracle.so, a port of the reference algorithm) on a bounded sample of the same workload, all host
-    threads (ctypes releases the GIL; static contiguous split as the reference's thread pool).  Two kinds, three runs each, median:
+    threads (ctypes releases the GIL; static contiguous split as the reference's thread pool).  Two kinds, `runs` runs each, median:
       port                 — the port as it is (O(N+E) consensus): BASELINE.md §3 baseline B
       reference_consensus  — the same regions with every consensus computed by the REFERENCE'S OWN PPOA (src/anppoa.hpp, quadratic
                              heaviest path :254-288) compiled into oracle/_ref/libotter_ref.so: baseline A.  Neither is the reference
-                             binary (WFA2-lib is absent); alignment and clustering are the port in both."""
+                             binary: WFA2-lib is absent from the reference tree, so BASELINE.md §3.2's calibration against one cannot be made."""
     import ctypes as C
     import numpy as np
     import oracle_lib
@@ -110,74 +118,140 @@ def cpu_baseline(batch, params, seconds, n_threads):
     def measure(label):
         ok, dt = run(n_threads)                                   # pilot: one region per thread sizes the sample
         n = int(min(n_regions, max(n_threads, n_threads * round(seconds / max(dt, 1e-3)))))
-        rates, times = [], []
-        for _ in range(3):
-            ok, dt = run(n)
-            rates.append(ok / dt); times.append(dt)
+        rates, times = [(ok / dt)], [dt]
+        if runs > 1 or n > n_threads:
+            rates, times = [], []
+            for _ in range(runs):
+                ok, dt = run(n)
+                rates.append(ok / dt); times.append(dt)
         return {"value": round(float(np.median(rates)), 4), "unit": "regions/s", "cores": n_threads, "runs": [round(x, 4) for x in rates],
-                "sample": "first %d regions of the same synthetic workload, %d threads, %s; 3 runs of %.1f-%.1f s, median" % (
-                    n, n_threads, label, min(times), max(times))}
+                "sample": "first %d regions, %d threads, %s; %d run(s) of %.1f-%.1f s" % (n if (runs > 1 or n > n_threads) else n_threads, n_threads, label, len(rates), min(times), max(times))}
 
-    out = dict(measure("oracle/libotter_oracle.so: scalar C++ WFA + O(N+E) consensus (BASELINE.md baseline B)"), kind="port")
+    out = dict(measure("oracle port (scalar C++ WFA, O(N+E) consensus)"), kind="port")
     refp = os.path.join(ROOT, "oracle", "_ref", "libotter_ref.so")
-    if os.path.exists(refp):
+    if with_reference_consensus and os.path.exists(refp):
         R = C.CDLL(refp)
         L.oto_set_poa_hook.argtypes = [C.c_void_p]
         L.oto_set_poa_hook(C.cast(R.ref_poa_consensus_one, C.c_void_p))
         try:
-            a = measure("the same port with every consensus through the reference's own PPOA (oracle/_ref/libotter_ref.so, quadratic "
-                        "heaviest path of src/anppoa.hpp:254-288; BASELINE.md baseline A)")
+            a = measure("port + the reference's own PPOA (quadratic consensus)")
             out["reference_consensus"] = dict(a, kind="port + reference PPOA")
         finally:
             L.oto_set_poa_hook(None)
-    else:
-        out["reference_consensus"] = None
     return out
 
 
 # ------------------------------------------------------------------------------------------------ file-to-text leg
-def e2e_leg(n_regions, threads):
-    """BASELINE.json quotes the metric "on synthetic TR BED+BAM": the same path from files — BED + BAM/BAI -> otg_assemble_files (the library's
-    dispatcher: BAM ingest on host threads, batches through the GPU hot path, SAM text) — on a fixture of configs[1]'s shape written by
-    otter_amd/bamwrite.py.  Ingest-bound on the host; reported beside `value`, never as `value`."""
-    import shutil
+FIXTURE_CODE = ("import sys, json, time; sys.path.insert(0, %r); from otter_amd import bamwrite; t0 = time.time(); "
+                "fx = bamwrite.make_tr_fixture(sys.argv[1], int(sys.argv[2]), depth=30, len_range=(1000, 5000), seed=7); "
+                "json.dump({'bam': fx['bam'], 'bed': fx['bed'], 'build_s': time.time() - t0}, open(sys.argv[1] + '/fixture.json', 'w'))")
+
+
+def start_fixture(n_regions):
+    """The BED + BAM fixture of the file-to-text leg is written by a child process (started before this process touches the GPU) while the
+    resident-batch legs run."""
     import tempfile
-    import otter_amd
-    from otter_amd import bamwrite
     tmp = tempfile.mkdtemp(prefix="otg_e2e_")
+    p = subprocess.Popen([sys.executable, "-c", FIXTURE_CODE % ROOT, tmp, str(n_regions)], stdin=subprocess.DEVNULL)
+    return tmp, p
+
+
+def e2e_leg(tmp, proc, n_regions, threads):
+    """BASELINE.json quotes the metric "on synthetic TR BED+BAM": the same path from files — BED + BAM/BAI -> otg_assemble_files (the library's
+    dispatcher: BAM ingest on host threads, batches through the GPU hot path, SAM text) — on a fixture of configs[1]'s shape and size written
+    by otter_amd/bamwrite.py.  Reported beside `value`, never as `value`."""
+    import shutil
+    import otter_amd
     try:
-        t0 = time.perf_counter()
-        fx = bamwrite.make_tr_fixture(tmp, n_regions, depth=30, len_range=(1000, 5000), seed=7)
-        build_s = time.perf_counter() - t0
+        if proc.wait(timeout=900) != 0:
+            raise RuntimeError("fixture writer failed")
+        fx = json.load(open(os.path.join(tmp, "fixture.json")))
+        batch = 1000
         best = None
         for _ in range(3):
             t1 = time.perf_counter()
-            text, st = otter_amd.assemble_files(fx["bam"], fx["bed"], read_group="s1", batch_regions=max(64, n_regions // 4), offset_l=1, offset_r=1, mapq=10, threads=threads)
+            text, st = otter_amd.assemble_files(fx["bam"], fx["bed"], read_group="s1", batch_regions=batch, offset_l=1, offset_r=1, mapq=10, threads=threads)
             dt = time.perf_counter() - t1
             if best is None or dt < best[0]:
                 best = (dt, st, len(text))
         dt, st, nbytes = best
         # the same job on the first half of the BED: the difference of the two walls is what the second half cost once the pipeline was full
-        # (a job of a few thousand loci is short against ingest of its first batch and the drain of its last)
         half_bed = os.path.join(tmp, "half.bed")
         with open(fx["bed"]) as f:
             lines = f.readlines()
         with open(half_bed, "w") as f:
             f.writelines(lines[:n_regions // 2])
         half = None
-        for _ in range(3):
+        for _ in range(2):
             t1 = time.perf_counter()
-            otter_amd.assemble_files(fx["bam"], half_bed, read_group="s1", batch_regions=max(64, n_regions // 4), offset_l=1, offset_r=1, mapq=10, threads=threads)
+            otter_amd.assemble_files(fx["bam"], half_bed, read_group="s1", batch_regions=batch, offset_l=1, offset_r=1, mapq=10, threads=threads)
             h = time.perf_counter() - t1
             half = h if half is None or h < half else half
         marginal = (n_regions - n_regions // 2) / (dt - half) if dt > half else None
-        return {"regions_per_s": round(n_regions / dt, 1), "marginal_regions_per_s": round(marginal, 1) if marginal else None, "half_job_wall_ms": round(half * 1000.0, 1), "regions": n_regions, "reads": int(st["n_reads"]), "alleles": int(st["n_alleles"]), "sam_bytes": nbytes,
-                "bam_bytes": os.path.getsize(fx["bam"]), "host_threads": threads, "batch_regions": max(64, n_regions // 4), "wall_ms": round(dt * 1000.0, 1),
+        return {"regions_per_s": round(n_regions / dt, 1), "marginal_regions_per_s": round(marginal, 1) if marginal else None, "regions": n_regions,
+                "reads": int(st["n_reads"]), "alleles": int(st["n_alleles"]), "sam_bytes": nbytes, "bam_bytes": os.path.getsize(fx["bam"]),
+                "host_threads": threads, "batch_regions": batch, "wall_ms": round(dt * 1000.0, 1), "half_job_wall_ms": round(half * 1000.0, 1),
                 "stage_busy_ms": {"ingest": round(st["ms_ingest"], 1), "hot_path": round(st["ms_hot_path"], 1), "emit": round(st["ms_emit"], 1)},
-                "what": "BED file + BAM/BAI -> otg_assemble_files -> SAM text (header + allele records), best of 3; fixture: %d two-allele TR loci x 30 ONT-like reads of "
-                        "1-5 kb written by otter_amd/bamwrite.py in %.0f s" % (n_regions, build_s)}
+                "what": "BED + BAM/BAI -> otg_assemble_files -> SAM text, best of 3", "fixture_build_s": round(fx["build_s"], 1)}
     finally:
+        try:
+            otter_amd.assemble_files_release()
+        except Exception:
+            pass
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+# ------------------------------------------------------------------------------------------------ roofline of an assemble workload
+def pmc_for(cfg, n_regions):
+    """PMC-derived figures of profiles/pmc_summary.json, only when it was measured on exactly this workload."""
+    if not os.path.exists(PMC_SUMMARY):
+        return None
+    try:
+        pm = json.load(open(PMC_SUMMARY)).get("config%d" % cfg)
+        if pm and int(pm.get("regions", -1)) == n_regions:
+            return pm
+    except Exception:
+        pass
+    return None
+
+
+def roofline(kstats, cfg, n_regions):
+    """The dominant kernel chain by HIP-event time (events on the library's own stream).  `frac` = SURVEY §8(d)'s algorithmic bytes / time against
+    the HBM peak, as the contract defines it — a work-equivalent rate: the kernels keep wavefronts in registers and visit a fraction of the
+    counted cells.  Beside it what the implementation must move at least (`impl_min_bytes`: sequences + one provenance byte per VISITED cell
+    + op strings + records), what it does move (`traffic`, PMC) and the resource that binds (`binding`: VALU issue, PMC)."""
+    import numpy as np
+    st = kstats[-1]
+    ek = float(np.mean([s["ms_edit_kernel"] for s in kstats])); el = max(1, int(st["edit_kernel_launches"]))
+    ak = float(np.mean([s["ms_affine_kernel"] for s in kstats])); al = max(1, int(st["affine_kernel_launches"]))
+    e_bytes = int(st["edit_seq_bytes"]) + 4 * int(st["edit_cells"])
+    a_bytes = int(st["affine_seq_bytes"]) + 4 * int(st["affine_cells"]) + (int(st["affine_cells"]) + 1) // 2
+    kname, kbytes, kms, kl = ("wfa_edit_kernel", e_bytes, ek, el) if ek >= ak else ("wfa_affine_kernel", a_bytes, ak, al)
+    achieved = (kbytes / kl) / (kms / kl * 1e-3) / 1e9 if kms > 0 else 0.0
+    visited = int(st["affine_visited_cells"])
+    out = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+           "traffic": None, "algorithmic_bytes_per_launch": kbytes // kl, "avg_launch_ms": round(kms / kl, 3),
+           "chain_ms": {"edit": round(ek, 2), "affine": round(ak, 2)},
+           "note": "frac = SURVEY 8(d) bytes of the reference's un-pruned wavefronts / time: work-equivalent, not bytes moved"}
+    if kname == "wfa_affine_kernel":
+        impl_min = int(st["affine_seq_bytes"]) + visited + int(st["affine_seq_bytes"]) // 2 + int(st["allele_bytes"])
+        out["impl_min_bytes"] = impl_min // kl
+        out["affine_visited_cells"] = visited
+        out["affine_visited_cells_per_s"] = round(visited / (ak * 1e-3), 1) if ak > 0 else None
+    pm = pmc_for(cfg, n_regions)
+    if pm:
+        out["traffic"] = pm.get("traffic_bytes_per_launch", {}).get(kname)
+        ph = pm.get("physical", {}).get(kname, {})
+        out["binding"] = {"resource": "valu", "valu_busy": ph.get("valu_busy"), "wait_any_frac": ph.get("wait_any_frac"),
+                          "valu_insts_per_visited_cell": ph.get("valu_insts_per_visited_cell"), "lds_bank_conflict_rate": ph.get("lds_bank_conflict_rate"),
+                          "source": pm.get("source")}
+        if out.get("impl_min_bytes") and out["traffic"]:
+            out["traffic_over_impl_min"] = round(float(out["traffic"]) / out["impl_min_bytes"], 2)
+    return out
+
+
+def stage_ms(st):
+    return {k: round(float(st[k]), 2) for k in ("ms_realign", "ms_edit", "ms_cluster", "ms_reassign", "ms_affine", "ms_poa", "ms_total")}
 
 
 # ------------------------------------------------------------------------------------------------ one rank
@@ -190,6 +264,28 @@ def run_rank(args):
                          "or under torchrun with --nproc-per-node equal to --gpus\n" % (args.gpus, world))
         return 2
     import numpy as np
+    from otter_amd import abi, synth          # numpy only: nothing here touches the GPU
+
+    # ---- every synthetic input first, by worker processes, before torch / HIP are initialised in this process
+    cfg = args.config if args.config is not None else 1
+    n_regions = args.regions if args.regions is not None else (synth.CONFIGS[cfg]["n_regions"] // 8 if cfg == 4 else synth.CONFIGS[cfg]["n_regions"])
+    if n_regions % synth.CHUNK and world > 1:
+        sys.stderr.write("bench.py: --regions must be a multiple of %d for N>1\n" % synth.CHUNK)
+        return 2
+    workers = max(1, min(16, (os.cpu_count() or 1) // max(1, world)))
+    t_gen = time.perf_counter()
+    # static BED split: rank r owns the r-th contiguous shard of world * n_regions regions (chunk-seeded generator: the shard is the
+    # same bytes whatever the world size)
+    batch = synth.config_batch(cfg, n_regions, first_chunk=rank * (n_regions // synth.CHUNK) if world > 1 else 0, workers=workers)
+    legs_in = {}
+    want_legs = world == 1 and not args.no_legs and args.config is None and args.regions is None
+    if want_legs:
+        legs_in[2] = synth.config_batch(2, workers=workers)
+        legs_in[4] = synth.config_batch(4, synth.CONFIGS[4]["n_regions"] // 8, workers=workers)
+        legs_in[3] = synth.config_batch(3, workers=workers)
+    gen_s = time.perf_counter() - t_gen
+    fixture = start_fixture(args.e2e_regions) if (args.e2e_regions > 0 and world == 1) else None
+
     import torch
     dist = None
     if world > 1:
@@ -197,26 +293,10 @@ def run_rank(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-
     import otter_amd
-    from otter_amd import abi, synth, parallel
-
-    # Same per-GPU workload at every N (weak scaling): the driver derives scaling efficiency from the per-N values, so N = 1 and N > 1 must run the
-    # same shape — configs[1], the configuration the metric is quoted on.  `--config 4` selects the 1-10 kb shard of the 8-GPU configs[4] at any N.
-    cfg = args.config if args.config is not None else 1
-    n_regions = args.regions if args.regions is not None else (synth.CONFIGS[cfg]["n_regions"] // 8 if cfg == 4 else synth.CONFIGS[cfg]["n_regions"])
+    from otter_amd import parallel
     ctx = otter_amd.Context(local_rank)
-    params = abi.default_params(realign=1 if synth.CONFIGS[cfg].get("realign") else 0)
-    # static BED split: rank r owns the r-th contiguous shard of world * n_regions regions (chunk-seeded generator: the shard is the
-    # same bytes whatever the world size)
-    if n_regions % synth.CHUNK and world > 1:
-        sys.stderr.write("bench.py: --regions must be a multiple of %d for N>1\n" % synth.CHUNK)
-        return 2
-    batch = synth.config_batch(cfg, n_regions, first_chunk=rank * (n_regions // synth.CHUNK) if world > 1 else 0,
-                               workers=max(1, min(16, (os.cpu_count() or 1) // max(1, world))))
-    t_sub = time.perf_counter()
-    ctx.assemble_submit(params, batch)       # H2D: inputs are resident in HBM from here on
-    submit_ms = (time.perf_counter() - t_sub) * 1000.0
+    nth = max(1, min(32, os.cpu_count() or 1))       # the reference caps -t at 32 (src/otter_opts.cpp:93)
 
     def sync():
         torch.cuda.synchronize()
@@ -224,38 +304,99 @@ def run_rank(args):
             dist.barrier()
             torch.cuda.synchronize()
 
-    info = {}
+    # ---- configs[3]: otter genotype's allele clustering (operator-level entry: host buffers in, host buffers out)
+    def genotype_run(gb, steps, warmup):
+        P = abi.default_params()
+        ga = (gb["arena"], gb["seq_off"], gb["seq_len"], np.ascontiguousarray(gb["first_allele"][:-1]), gb["n_alleles"])
+        for _ in range(warmup):
+            ctx.genotype_cluster_batch(P, *ga)
+        kms = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = ctx.genotype_cluster_batch(P, *ga)
+            kms.append(ctx.last_kernel_ms())
+        dt = time.perf_counter() - t0
+        nreg = len(gb["n_alleles"])
+        nbytes = int(gb["seq_len"].astype(np.int64).sum()) + 65 * 8 * len(gb["seq_len"])        # allele bytes + one 65-bin usage vector per allele
+        k = float(np.mean(kms))
+        achieved = nbytes / (k * 1e-3) / 1e9 if k > 0 else 0.0
+        out = {"value": round(nreg * steps / dt, 2), "unit": "regions/s", "ms_per_step": round(dt * 1000.0 / steps, 3), "steps": steps,
+               "timed_region": "otg_genotype_cluster_batch: allele sequences in host memory -> genotypes in host memory (H2D + kernel + D2H)",
+               "kernel_ms": round(k, 3), "genotypes": int(res[4].sum()), "input_bytes": int(gb["arena"].size),
+               "roofline": {"bound": "hbm", "kernel": "genotype_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": round(k, 3)}}
+        return out, P, ga
 
-    def step():
-        ctx.assemble_run()
-        if dist is not None:
-            # end-of-run gather of the per-region allele records to rank 0 (RCCL over xGMI), straight from the library's
-            # device-resident result buffers: GPU -> GPU, one device-to-host copy on rank 0
-            t0 = time.perf_counter()
-            res = ctx.assemble_device_results()
-            g = parallel.gather_records(res, dist, rank, world, torch.device("cuda", local_rank))
-            info["gather_ms"] = (time.perf_counter() - t0) * 1000.0
-            if rank == 0:
-                info["records"] = len(g["alleles"])
-                info["gather_bytes"] = int(g["alleles"].nbytes + g["seqs"].nbytes + g["regions"].nbytes)
-        else:
-            t0 = time.perf_counter()
-            res = ctx.assemble_collect()       # allele records + sequences + region results to host memory
-            info["collect_ms"] = (time.perf_counter() - t0) * 1000.0
-            info["records"] = len(res["alleles"])
+    def genotype_cpu(P, ga):
+        import oracle_lib
+        n = min(len(ga[4]), 1000)
+        first, na = ga[3][:n], ga[4][:n]
+        t0 = time.perf_counter()
+        oracle_lib.genotype_cluster_batch(P, ga[0], ga[1], ga[2], first, na)
+        dt = time.perf_counter() - t0
+        return {"value": round(n / dt, 2), "unit": "regions/s", "cores": 1, "kind": "port", "sample": "first %d regions, 1 thread, oracle anallele_cluster, %.1f s" % (n, dt)}
 
-    for _ in range(args.warmup):
-        step()
-    sync()
-    t0 = time.perf_counter()
-    kstats = []
-    for _ in range(args.steps):
-        step()
-        kstats.append(ctx.assemble_stats().copy())
-    sync()
-    dt = time.perf_counter() - t0
-    st = kstats[-1]
+    if cfg == 3:          # --config 3: the genotype leg as the timed workload
+        out3, P3, ga3 = genotype_run(batch, args.steps, args.warmup)
+        line = {"metric": "regions/sec (otter genotype allele clustering) on synthetic allele sets", "value": out3["value"], "unit": "regions/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": out3["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f64", "data": "synthetic", "config": dict(workload=synth.config_workload(3, n_regions, world), **{k: v for k, v in out3.items() if k not in ("roofline", "value", "unit", "ms_per_step", "steps")}),
+                "roofline": out3["roofline"]}
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = genotype_cpu(P3, ga3)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        return 0
+
+    # ---- an assemble workload resident in HBM: K timed steps (+ the host-to-host passes)
+    def assemble_run(c, b, steps, warmup, h2h_passes):
+        params = abi.default_params(realign=1 if synth.CONFIGS[c].get("realign") else 0)
+        t_sub = time.perf_counter()
+        ctx.assemble_submit(params, b)       # H2D: inputs are resident in HBM from here on
+        submit_ms = (time.perf_counter() - t_sub) * 1000.0
+        info = {}
+
+        def step():
+            ctx.assemble_run()
+            if dist is not None:
+                # end-of-run gather of the per-region allele records to rank 0 (RCCL over xGMI), straight from the library's
+                # device-resident result buffers: GPU -> GPU, one device-to-host copy on rank 0
+                t0 = time.perf_counter()
+                res = ctx.assemble_device_results()
+                g = parallel.gather_records(res, dist, rank, world, torch.device("cuda", local_rank))
+                info["gather_ms"] = (time.perf_counter() - t0) * 1000.0
+                if rank == 0:
+                    info["records"] = len(g["alleles"])
+                    info["gather_bytes"] = int(g["alleles"].nbytes + g["seqs"].nbytes + g["regions"].nbytes)
+            else:
+                t0 = time.perf_counter()
+                res = ctx.assemble_collect()       # allele records + sequences + region results to host memory
+                info["collect_ms"] = (time.perf_counter() - t0) * 1000.0
+                info["records"] = len(res["alleles"])
+
+        for _ in range(warmup):
+            step()
+        sync()
+        t0 = time.perf_counter()
+        kstats = []
+        for _ in range(steps):
+            step()
+            kstats.append(ctx.assemble_stats().copy())
+        sync()
+        dt = time.perf_counter() - t0
+        # host memory -> host memory (upload + run + download), untimed for `value`
+        h2h = None
+        if h2h_passes > 0:
+            t1 = time.perf_counter()
+            for _ in range(h2h_passes):
+                ctx.assemble_submit(params, b); ctx.assemble_run(); ctx.assemble_collect()
+            h2h = (time.perf_counter() - t1) / h2h_passes
+        return {"dt": dt, "kstats": kstats, "info": info, "submit_ms": submit_ms, "h2h_s": h2h, "params": params}
+
+    r = assemble_run(cfg, batch, args.steps, args.warmup, min(3, max(1, args.steps)))
+    st = r["kstats"][-1]
     regions_ok = int(st["n_regions_ok"])
+    dt = r["dt"]
     tt = torch.tensor([dt, float(regions_ok)], dtype=torch.float64, device="cuda")
     world_seen = 1
     if dist is not None:
@@ -265,87 +406,74 @@ def run_rank(args):
         world_seen = dist.get_world_size()
     else:
         total_regions = float(regions_ok)
-    # host memory -> host memory (SURVEY §8d's kernel-path metric: upload + run + download), one extra untimed-for-`value` pass per rank
-    t1 = time.perf_counter()
-    ctx.assemble_submit(params, batch); ctx.assemble_run(); ctx.assemble_collect()
-    h2h_s = time.perf_counter() - t1
     if rank != 0:
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
         return 0
 
-    ms_per_step = dt * 1000.0 / args.steps
-    value = total_regions * args.steps / dt
-    # dominant kernel group: the WFA kernel chain (edit or affine) with the larger HIP-event time (events on the library's own stream);
-    # algorithmic bytes per launch = Σ(a+b) + 4·W (+ W/2 for the CIGAR-scope aligner), SURVEY.md §8d / DESIGN.md §6
-    ek = float(np.mean([s["ms_edit_kernel"] for s in kstats])); el = max(1, int(st["edit_kernel_launches"]))
-    ak = float(np.mean([s["ms_affine_kernel"] for s in kstats])); al = max(1, int(st["affine_kernel_launches"]))
-    e_bytes = int(st["edit_seq_bytes"]) + 4 * int(st["edit_cells"])
-    a_bytes = int(st["affine_seq_bytes"]) + 4 * int(st["affine_cells"]) + (int(st["affine_cells"]) + 1) // 2
-    if ek >= ak:
-        kname, kbytes, kms, kl = "wfa_edit_kernel", e_bytes, ek, el
-    else:
-        kname, kbytes, kms, kl = "wfa_affine_kernel", a_bytes, ak, al
-    achieved = (kbytes / kl) / (kms / kl * 1e-3) / 1e9 if kms > 0 else 0.0
-    workload = synth.config_workload(cfg, n_regions, world)
-    # PMC-derived figures are only attached when the committed summary was taken on exactly this workload
-    traffic, physical = None, None
-    if os.path.exists(PMC_SUMMARY):
-        try:
-            pm = json.load(open(PMC_SUMMARY)).get("config%d" % cfg)
-            if pm and int(pm.get("regions", -1)) == n_regions:
-                traffic = pm.get("traffic_bytes_per_launch", {}).get(kname)
-                physical = dict(pm.get("physical", {}).get(kname, {}), source=pm.get("source"), workload=pm.get("workload"))
-        except Exception as e:
-            physical = {"error": "profiles/pmc_summary.json unreadable: %r" % (e,)}
-    visited = int(st["affine_visited_cells"]) if "affine_visited_cells" in st.dtype.names else 0
+    info = r["info"]
     out = {
-        "metric": "regions/sec (otter assemble hot path) on synthetic TR regions",
-        "value": round(value, 3), "unit": "regions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "i32", "data": "synthetic",
-        "config": {"workload": workload, "baseline_config": cfg,
+        "metric": METRIC, "value": round(total_regions * args.steps / dt, 3), "unit": "regions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt * 1000.0 / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "i16", "data": "synthetic",
+        "config": {"workload": synth.config_workload(cfg, n_regions, world), "baseline_config": cfg,
                    "regions_per_gpu": n_regions, "reads_per_region": synth.CONFIGS[cfg]["n_reads"],
                    "parallelism": "static BED shard x%d + RCCL gather" % world, "world_size_rccl": world_seen,
-                   "timed_region": "otg_assemble_run + " + ("RCCL gather of the records to rank 0 (device buffers) + one D2H" if world > 1 else "otg_assemble_collect (D2H of the records)") + "; inputs resident in HBM",
-                   "stage_ms": {k: round(float(st[k]), 2) for k in ("ms_realign", "ms_edit", "ms_cluster", "ms_reassign", "ms_affine", "ms_poa", "ms_total")},
+                   "timed_region": "otg_assemble_run + " + ("RCCL gather to rank 0 + one D2H" if world > 1 else "otg_assemble_collect (D2H of the records)") + "; inputs resident in HBM",
+                   "stage_ms": stage_ms(st),
                    "edit_pairs": int(st["edit_tasks"]), "affine_alignments": int(st["affine_tasks"]),
                    "wavefront_cells": int(st["edit_cells"]) + int(st["affine_cells"]),
                    "exp_variant": "glibc-fma" if ctx.exp_variant else "glibc-nofma",
-                   "h2d_submit_ms": round(submit_ms, 2), "input_bytes": int(batch["arena"].size + batch["reads"].nbytes + batch["regions"].nbytes),
-                   "allele_records": info.get("records"),
-                   "host_to_host": {"regions_per_s": round(regions_ok / h2h_s, 2), "ms": round(h2h_s * 1000.0, 2),
-                                    "what": "otg_assemble_submit (H2D) + otg_assemble_run + otg_assemble_collect (D2H), one pass on rank 0's shard"}},
-        "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "algorithmic_bytes_per_launch": kbytes // kl, "avg_launch_ms": round(kms / kl, 3),
-                     "note": "achieved = SURVEY §8(d) algorithmic bytes (every cell of the reference's un-pruned, HBM-resident wavefronts) / "
-                             "HIP-event time of the kernel chain: a work-equivalent rate, NOT bytes moved — the kernels keep wavefronts in registers / LDS "
-                             "and prune cells; the binding resource is in `physical` (PMC, profiles/)",
-                     "physical": physical,
-                     "other_kernel": {"edit_ms": round(ek, 2), "affine_ms": round(ak, 2)}},
+                   "h2d_submit_ms": round(r["submit_ms"], 2), "input_bytes": int(batch["arena"].size + batch["reads"].nbytes + batch["regions"].nbytes),
+                   "allele_records": info.get("records"), "synthetic_input_generation_s": round(gen_s, 1),
+                   "host_to_host": {"regions_per_s": round(regions_ok / r["h2h_s"], 2), "ms": round(r["h2h_s"] * 1000.0, 2),
+                                    "what": "SURVEY 8(d): otg_assemble_submit (H2D) + run + collect (D2H), mean of %d passes" % min(3, max(1, args.steps))}},
+        "roofline": roofline(r["kstats"], cfg, n_regions),
     }
-    if visited:
-        out["roofline"]["affine_visited_cells_per_s"] = round(visited / (float(st["ms_affine_kernel"]) * 1e-3), 1) if float(st["ms_affine_kernel"]) > 0 else None
-        out["roofline"]["affine_visited_cells"] = visited
     if world > 1:
-        out["config"]["gather"] = {"path": "device buffers (otg_assemble_device_results) -> RCCL gather -> one D2H on rank 0",
-                                   "bytes": info.get("gather_bytes"), "ms_last_step": round(info.get("gather_ms", 0.0), 2)}
+        out["config"]["gather"] = {"path": "device buffers -> RCCL gather -> one D2H on rank 0", "bytes": info.get("gather_bytes"), "ms_last_step": round(info.get("gather_ms", 0.0), 2)}
     else:
         out["config"]["collect_ms_last_step"] = round(info.get("collect_ms", 0.0), 2)
     if not args.no_cpu_baseline and world == 1:        # rank 0 at N=1 only
-        nth = max(1, min(32, os.cpu_count() or 1))       # the reference caps -t at 32 (src/otter_opts.cpp:93)
         try:
-            out["cpu_baseline"] = cpu_baseline(batch, params, args.cpu_seconds, nth)
+            out["cpu_baseline"] = cpu_baseline(batch, r["params"], args.cpu_seconds, nth)
         except Exception as e:  # the oracle is only a reported baseline; never fail the bench line on it
             out["cpu_baseline"] = {"value": None, "unit": "regions/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
-    if args.e2e_regions > 0 and world == 1:
+    # ---- the other BASELINE configurations (N = 1): same timed region, fewer steps
+    if want_legs:
+        legs = {}
+        for c in (2, 4):
+            try:
+                b = legs_in[c]
+                nr = len(b["regions"])
+                lr = assemble_run(c, b, args.leg_steps, 1, 1)
+                ls = lr["kstats"][-1]
+                leg = {"workload": synth.config_workload(c, nr, 1), "value": round(int(ls["n_regions_ok"]) * args.leg_steps / lr["dt"], 2), "unit": "regions/s",
+                       "ms_per_step": round(lr["dt"] * 1000.0 / args.leg_steps, 2), "steps": args.leg_steps, "stage_ms": stage_ms(ls),
+                       "host_to_host_regions_per_s": round(int(ls["n_regions_ok"]) / lr["h2h_s"], 2), "allele_records": lr["info"].get("records"),
+                       "roofline": roofline(lr["kstats"], c, nr)}
+                if c == 4 and not args.no_cpu_baseline:
+                    leg["cpu_baseline"] = cpu_baseline(b, lr["params"], 0.0, nth, runs=1, with_reference_consensus=False)
+                legs["configs[%d]" % c] = leg
+            except Exception as e:
+                legs["configs[%d]" % c] = {"error": repr(e)}
+            legs_in[c] = None
+        try:
+            g3, P3, ga3 = genotype_run(legs_in[3], args.leg_steps, 1)
+            g3["workload"] = synth.config_workload(3, len(legs_in[3]["n_alleles"]), 1)
+            if not args.no_cpu_baseline:
+                g3["cpu_baseline"] = genotype_cpu(P3, ga3)
+            legs["configs[3]"] = g3
+        except Exception as e:
+            legs["configs[3]"] = {"error": repr(e)}
+        out["config"]["legs"] = legs
+    if fixture is not None:
         try:
             ctx.close()                       # the dispatcher creates its own contexts
-            out["e2e"] = e2e_leg(args.e2e_regions, max(1, min(16, os.cpu_count() or 1)))
+            out["config"]["e2e"] = e2e_leg(fixture[0], fixture[1], args.e2e_regions, max(1, min(16, os.cpu_count() or 1)))
         except Exception as e:
-            out["e2e"] = {"error": repr(e)}
+            out["config"]["e2e"] = {"error": repr(e)}
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -176,6 +176,10 @@ int otg_genotype_cluster_batch(otg_ctx* ctx, const otg_params* params,
                                int32_t* gt_out, int32_t* gt_l_out, int32_t* gt_k_out, double* hsd_out,
                                int32_t* n_gt_out, int32_t* reps_out);
 
+/* HIP-event time (ms, events on the context's own stream) of the device kernels of the latest otg_genotype_cluster_batch on this context:
+ * what a roofline figure divides by; host copies excluded.  The reference has no counterpart (measurement hook).        */
+int otg_last_kernel_ms(otg_ctx* ctx, double* ms);
+
 /* ================================================================= L3: region-batch pipeline
  * SoA image of std::vector<ANREAD> (src/anseqs.hpp:56-76) for a batch of regions.               */
 typedef struct otg_read {

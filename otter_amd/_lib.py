@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(HERE, "libotter_gpu.so")
 EXPORTS = [
     "otg_params_default", "otg_create", "otg_destroy", "otg_trim", "otg_last_error", "otg_device_count", "otg_exp_variant",
     "otg_edit_distance_batch", "otg_affine_align_batch", "otg_cluster_batch", "otg_poa_consensus_batch",
-    "otg_genotype_cluster_batch", "otg_assemble_submit", "otg_assemble_run", "otg_assemble_result_sizes",
+    "otg_genotype_cluster_batch", "otg_last_kernel_ms", "otg_assemble_submit", "otg_assemble_run", "otg_assemble_result_sizes",
     "otg_assemble_collect", "otg_assemble_device_results", "otg_assemble_stats", "otg_assemble_realign", "otg_assemble_collect_reads",
     "otg_emit_alleles", "otg_emit_sam_header",
     "otg_bam_open", "otg_bam_close", "otg_bam_n_targets", "otg_bam_target", "otg_ingest_regions",
@@ -158,6 +158,12 @@ class Context:
                                                 abi.ptr(gt), abi.ptr(gl), abi.ptr(gk), abi.ptr(hsd), abi.ptr(ngt), abi.ptr(reps))
         self._check(rc, "otg_genotype_cluster_batch")
         return gt, gl, gk, hsd, ngt, reps
+
+    def last_kernel_ms(self):
+        """HIP-event time of the kernels of the latest genotype_cluster_batch (otg_last_kernel_ms)."""
+        ms = C.c_double(0.0)
+        self._check(self._L.otg_last_kernel_ms(self._h, C.byref(ms)), "otg_last_kernel_ms")
+        return float(ms.value)
 
     # ------------------------------------------------------------------ L3
     def assemble_submit(self, params, batch, region_range=None):

@@ -389,9 +389,11 @@ int otg_genotype_cluster_batch(otg_ctx* ctx, const otg_params* params, const uin
   HIP_TRY(ctx, hipMemcpyAsync(d_n, n_alleles, (size_t)n_regions * 4, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(d_poff, pair_off.data(), (size_t)(n_regions + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(d_gt, 0xff, (na + 1) * 4 * 4, ctx->stream));
+  HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   int rc = otg_launch_genotype(ctx, params, d_arena, d_off, d_len, d_first, d_n, n_regions, d_poff, pair_off[n_regions], na,
                                d_gt, d_gtl, d_gtk, d_hsd, d_ngt, d_reps, d_err);
   if (rc) return rc;
+  HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   std::vector<int32_t> h_err(n_regions);
   HIP_TRY(ctx, hipMemcpyAsync(gt_out, d_gt, na * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(gt_l_out, d_gtl, na * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -401,7 +403,15 @@ int otg_genotype_cluster_batch(otg_ctx* ctx, const otg_params* params, const uin
   HIP_TRY(ctx, hipMemcpyAsync(n_gt_out, d_ngt, (size_t)n_regions * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(h_err.data(), d_err, (size_t)n_regions * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  { float ms = 0; HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1)); ctx->last_kernel_ms = ms; }
   for (uint32_t r = 0; r < n_regions; ++r) if (h_err[r]) return otg_fail(ctx, OTG_ERR_CAPACITY, "region %u: more than 256 alleles", r);
+  return OTG_OK;
+}
+
+int otg_last_kernel_ms(otg_ctx* ctx, double* ms)
+{
+  if (!ctx || !ms) return otg_fail(ctx, OTG_ERR_ARG, "otg_last_kernel_ms: NULL argument");
+  *ms = ctx->last_kernel_ms;
   return OTG_OK;
 }
 

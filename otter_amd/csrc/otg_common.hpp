@@ -29,6 +29,7 @@ struct otg_ctx {
   // resident batch of the L3 pipeline
   struct Pipeline* pipe = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double last_kernel_ms = 0.0;                    // HIP-event time of the kernels of the latest operator-level call that reports one (otg_last_kernel_ms)
   unsigned long long* affine_visited = nullptr;   // device counter: (score, diagonal) cells the exact gap-affine tiers visited (wfa_affine.hip)
 };
 

@@ -142,8 +142,63 @@ CONFIGS = {
     0: dict(n_regions=100, len_range=(500, 500), n_reads=10, err="hifi", frac_partial=0.0),
     1: dict(n_regions=10000, len_range=(1000, 5000), n_reads=30, err="ont"),
     2: dict(n_regions=10000, len_range=(1000, 5000), n_reads=30, err="ont", realign=True),
+    3: dict(kind="genotype", n_regions=5000, len_range=(1000, 5000), n_samples=50),
     4: dict(n_regions=100000, len_range=(1000, 10000), n_reads=30, err="ont"),
 }
+
+
+def make_genotype_batch(n_regions, n_samples=50, len_range=(1000, 5000), seed=SEED, pop_alleles=4, err=0.003):
+    """Inputs of `otter genotype` (BASELINE configs[3]: 50-sample merged allele BAM, anallele_cluster over A = 2 x samples + 1 alleles per
+    region, src/genotype.cpp:85-138): per TR locus `pop_alleles` population alleles (copy-number variants of one motif), every sample's two
+    alleles drawn from them and carrying consensus-level errors (what `otter assemble` writes per sample), and the reference allele
+    (population allele 0, exact) that genotype_process appends last (src/genotype.cpp:92-101).
+    Returns dict(arena, seq_off, seq_len, first_allele [n_regions + 1], n_alleles, sample) — the arguments of otg_genotype_cluster_batch."""
+    rng = np.random.default_rng(seed)
+    chunks, off, ln, sample, first = [], [], [], [], [0]
+    pos = 0
+    for r in range(n_regions):
+        L = int(rng.integers(len_range[0], len_range[1] + 1))
+        m = int(rng.integers(2, 7))
+        motif = rng.integers(0, 4, m, dtype=np.uint8)
+        while m > 1 and np.all(motif == motif[0]):
+            motif = rng.integers(0, 4, m, dtype=np.uint8)
+        lead = rng.integers(0, 4, 1, dtype=np.uint8)
+        copies = max(1, (L - 1) // m)
+        pop = [np.concatenate([lead, np.tile(motif, copies)])]
+        for _ in range(pop_alleles - 1):
+            kc = max(1, int(round(rng.uniform(0.02, 0.3) * copies)))
+            c2 = copies + kc if (rng.random() < 0.5 or copies - kc < 1) else copies - kc
+            pop.append(np.concatenate([lead, np.tile(motif, c2)]))
+        freq = rng.dirichlet(np.ones(pop_alleles) * 1.5)
+        for smp in range(n_samples):
+            for a in rng.choice(pop_alleles, 2, p=freq):
+                seq = _mutate(rng, pop[int(a)], err, ERR["hifi"][1])
+                if seq.size == 0:
+                    seq = np.zeros(1, dtype=np.uint8)
+                b = _ACGT[seq]
+                chunks.append(b); off.append(pos); ln.append(b.size); sample.append(smp); pos += b.size
+        b = _ACGT[pop[0]]
+        chunks.append(b); off.append(pos); ln.append(b.size); sample.append(n_samples); pos += b.size
+        first.append(len(off))
+    arena = np.concatenate(chunks + [np.zeros(64, dtype=np.uint8)]) if chunks else np.zeros(64, dtype=np.uint8)
+    first = np.asarray(first, dtype=np.uint32)
+    return {"arena": arena, "seq_off": np.asarray(off, dtype=np.uint64), "seq_len": np.asarray(ln, dtype=np.uint32), "first_allele": first,
+            "n_alleles": np.diff(first.astype(np.int64)).astype(np.uint32), "sample": np.asarray(sample, dtype=np.int32)}
+
+
+def concat_genotype_batches(parts):
+    arenas, off, ln, smp, na = [], [], [], [], []
+    abase = 0
+    for p in parts:
+        a = p["arena"][:-64] if p["arena"].size >= 64 else p["arena"]
+        arenas.append(a); off.append(p["seq_off"] + np.uint64(abase)); ln.append(p["seq_len"]); smp.append(p["sample"]); na.append(p["n_alleles"])
+        abase += a.size
+    arenas.append(np.zeros(64, dtype=np.uint8))
+    n_alleles = np.concatenate(na) if na else np.zeros(0, dtype=np.uint32)
+    first = np.concatenate([[0], np.cumsum(n_alleles.astype(np.int64))]).astype(np.uint32)
+    return {"arena": np.concatenate(arenas), "seq_off": np.concatenate(off) if off else np.zeros(0, np.uint64),
+            "seq_len": np.concatenate(ln) if ln else np.zeros(0, np.uint32), "first_allele": first, "n_alleles": n_alleles,
+            "sample": np.concatenate(smp) if smp else np.zeros(0, np.int32)}
 
 
 def shard_bounds(n_regions, world, rank):
@@ -161,9 +216,16 @@ def shard_bounds(n_regions, world, rank):
 CHUNK = 250
 
 
+def _make_chunk(n, seed, kw):
+    kw = dict(kw)
+    if kw.pop("kind", None) == "genotype":
+        return make_genotype_batch(n, seed=seed, **kw)
+    return make_batch(n, seed=seed, **kw)
+
+
 def _chunk_job(args):
     c, n, seed, kw = args
-    return make_batch(n, seed=seed * 1000003 + c, **kw)
+    return _make_chunk(n, seed * 1000003 + c, kw)
 
 
 def concat_batches(parts):
@@ -193,8 +255,8 @@ def _worker_main(argv):
     for c, n, seed, kw in jobs:
         if "len_range" in kw:
             kw["len_range"] = tuple(kw["len_range"])
-        p = make_batch(n, seed=seed * 1000003 + c, **kw)
-        np.savez(os.path.join(out_dir, "c%d.npz" % c), arena=p["arena"], reads=p["reads"], regions=p["regions"], truth=p["truth"])
+        p = _make_chunk(n, seed * 1000003 + c, kw)
+        np.savez(os.path.join(out_dir, "c%d.npz" % c), **p)
 
 
 def make_batch_chunked(n_regions, seed=SEED, workers=None, first_chunk=0, **kw):
@@ -210,8 +272,9 @@ def make_batch_chunked(n_regions, seed=SEED, workers=None, first_chunk=0, **kw):
         c += 1; left -= n
     if workers is None:
         workers = min(len(jobs), max(1, min(16, (os.cpu_count() or 1))))
+    cat = concat_genotype_batches if kw.get("kind") == "genotype" else concat_batches
     if workers <= 1 or len(jobs) <= 1:
-        return concat_batches([_chunk_job(j) for j in jobs])
+        return cat([_chunk_job(j) for j in jobs])
     import json
     import shutil
     import subprocess
@@ -233,8 +296,8 @@ def make_batch_chunked(n_regions, seed=SEED, workers=None, first_chunk=0, **kw):
         parts = []
         for c, n, _, _ in jobs:
             with np.load(os.path.join(tmp, "c%d.npz" % c)) as z:
-                parts.append({k: z[k] for k in ("arena", "reads", "regions", "truth")})
-        return concat_batches(parts)
+                parts.append({k: z[k] for k in z.files})
+        return cat(parts)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
@@ -250,6 +313,9 @@ def config_workload(idx, n_regions, world=1):
     """Human-readable workload string for bench.py's config.workload, derived from CONFIGS (never hand-written)."""
     kw = CONFIGS[idx]
     lo, hi = kw["len_range"]
+    if kw.get("kind") == "genotype":
+        return "BASELINE configs[%d]: otter genotype allele clustering (anallele_cluster), %d regions%s x %d alleles (%d samples x 2 + reference) of %d-%d bp" % (
+            idx, n_regions, "/GPU" if world > 1 else "", 2 * kw["n_samples"] + 1, kw["n_samples"], lo, hi)
     return "BASELINE configs[%d]: otter assemble%s hot path, %d regions%s x %d-%d bp TR, %dx %s-error reads" % (
         idx, " -r (local re-alignment, divergent soft-clipped flanks)" if kw.get("realign") else "", n_regions,
         "/GPU (static BED shard of %d)" % (n_regions * world) if world > 1 else "", lo, hi, kw["n_reads"], kw["err"].upper())
