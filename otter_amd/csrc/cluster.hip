@@ -284,7 +284,8 @@ __device__ __forceinline__ int wave_min_i32(int v)
   for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(v, off); v = o < v ? o : v; }
   return v;
 }
-__device__ void nn_chain_average(int N, double* D, Lds& L, int lane)
+template <class S>
+__device__ void nn_chain_average(int N, double* D, S& L, int lane)
 {
 #define D_(r_, c_) (D[didx(N, (r_), (c_))])
   constexpr double INF = 1.0e300;
@@ -348,7 +349,8 @@ __device__ void nn_chain_average(int N, double* D, Lds& L, int lane)
 // hclust_fast(AVERAGE): NN-chain (wave 0) + generate_R_dendrogram<false> (stable sort by height = rank by
 // (dist, position), computed in parallel; union-find relabel by thread 0).  Block-cooperative: call from all
 // threads.  Leaves L.merge (R convention, column-major) and L.height.
-__device__ void hclust_to_merge(int n, double* D, Lds& L, int tid)
+template <class S>
+__device__ void hclust_to_merge(int n, double* D, S& L, int tid)
 {
   if (tid < 64) nn_chain_average(n, D, L, tid);
   __syncthreads();
@@ -597,7 +599,68 @@ __global__ __launch_bounds__(256) void cluster_kernel(
 // anallele_cluster (reference: src/otterclust.cpp:463-527) for `otter genotype`: length-ratio matrix
 // (:322-327,367-382) and 3-mer-usage cosine matrix rounded to 3 decimals (:384-420; KUSAGE src/anseqs.cpp:111-147,
 // seq2kcounts :149-166), two average-linkage cuts (cluter_to_e :329-349), genotype = distinct (gt_l, gt_k) pairs in
-// first-seen order, representative = medoid under the LENGTH matrix (:517-524).  One workgroup per region.
+// first-seen order, representative = medoid under the LENGTH matrix (:517-524).  One 256-thread workgroup per region, every
+// phase spread over the block; what the reference sums in a fixed order (the 65-term norm and dot products, the Hill-Shannon sum, a
+// medoid's row sum) is summed in that order by ONE thread per output element, and different elements run in parallel:
+//   1. 3-mer counts: one WAVE per allele (alleles dealt round-robin to the four waves), lanes stride the sequence (coalesced byte
+//      loads), every lane counts into its own column of an LDS histogram [bin][lane] (16-bit, conflict-free), a rotated column walk
+//      sums the 64 columns per bin;
+//   2. frequencies, norm, Hill-Shannon diversity: one thread per allele;
+//   3. the two matrices: the A(A-1)/2 pairs dealt to the threads (flat pair index);
+//   4. the two clusterings one after the other: NN-chain by wave 0 on an LDS working copy of the matrix (regions of up to 102 alleles), rank
+//      sort of the merges by all threads, union-find relabel by one thread, tree cut by wave 0;
+//   5. genotypes = first appearances of (gt_l, gt_k): one thread per allele looks for an earlier allele with its pair, ballot + prefix
+//      count numbers the first appearances; medoids: one thread per allele sums its row over its genotype (ascending, as the reference),
+//      one thread per genotype takes the first strict minimum.
+constexpr int GT_DLDS = 5152;      // 102 alleles: BASELINE configs[3] has 101
+struct HcScratch {
+  double members[NMAX], zdist[NMAX], height[NMAX];
+  int nn_chain[NMAX], pred[NMAX + 1];
+  int z1[NMAX], z2[NMAX], zrank[NMAX];
+  int parent[2 * NMAX], merge[2 * NMAX];
+  int labels[NMAX];
+  int ct_up[NMAX + 1], ct_own[NMAX], ct_first[NMAX + 1], ct_lab[NMAX + 1];
+  int cut_k;
+};
+struct GLds {
+  union {
+    uint16_t hist[4][65 * 64];      // phase 1: per wave, [bin][lane]
+    HcScratch hc;                   // phase 4
+  } u;
+  int lab_l[NMAX], lab_k[NMAX], gtlab[NMAX], firstof[NMAX], nfirst[8];
+  double rowsum[NMAX];
+  double dmat[GT_DLDS];             // working copy of a condensed matrix while the NN-chain runs on it (regions of up to 102 alleles)
+};
+
+// union-find relabel of the NN-chain output into R's merge matrix (generate_R_dendrogram<false>, fastcluster_R_dm.hpp:68-115), one thread
+template <class S>
+__device__ void dendrogram_relabel(int n, S& L)
+{
+  for (int i = 0; i < 2 * n - 1; ++i) L.parent[i] = 0;
+  int nextparent = n;
+  for (int k = 0; k < n - 1; ++k) {
+    const int src = L.zrank[k];
+    int a = L.z1[src], b = L.z2[src];
+    for (int w = 0; w < 2; ++w) {      // union_find::Find with path compression (fastcluster_dm.hpp:366-383)
+      int idx = w ? b : a;
+      if (L.parent[idx] != 0) {
+        int p = idx;
+        idx = L.parent[idx];
+        if (L.parent[idx] != 0) {
+          do { idx = L.parent[idx]; } while (L.parent[idx] != 0);
+          do { int tmp = L.parent[p]; L.parent[p] = idx; p = tmp; } while (L.parent[p] != idx);
+        }
+      }
+      if (w) b = idx; else a = idx;
+    }
+    L.parent[a] = L.parent[b] = nextparent++;
+    if (a > b) { int t = a; a = b; b = t; }
+    L.merge[k] = (a < n) ? -a - 1 : a - n + 1;
+    L.merge[k + n - 1] = (b < n) ? -b - 1 : b - n + 1;
+    L.height[k] = L.zdist[src];
+  }
+}
+
 __global__ __launch_bounds__(256) void genotype_kernel(
     double max_error_l, double max_error_c, const uint8_t* __restrict__ arena, const uint64_t* __restrict__ seq_off,
     const uint32_t* __restrict__ seq_len, const uint32_t* __restrict__ first_allele, const uint32_t* __restrict__ n_alleles,
@@ -606,8 +669,8 @@ __global__ __launch_bounds__(256) void genotype_kernel(
     int32_t* __restrict__ gt, int32_t* __restrict__ gt_l, int32_t* __restrict__ gt_k, double* __restrict__ hsd,
     int32_t* __restrict__ n_gt, int32_t* __restrict__ reps, int32_t* __restrict__ err_out)
 {
-  __shared__ Lds L;
-  const int tid = threadIdx.x;
+  __shared__ GLds L;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   for (uint32_t r = blockIdx.x; r < n_regions; r += gridDim.x) {
     const int A = (int)n_alleles[r];
     const uint32_t f = first_allele[r];
@@ -616,24 +679,59 @@ __global__ __launch_bounds__(256) void genotype_kernel(
     if (A > NMAX) { if (tid == 0) { n_gt[r] = 0; err_out[r] = 10; } continue; }
     double* dl = g_dl + pair_off[r]; double* dk = g_dk + pair_off[r]; double* wk = g_work + pair_off[r];
     double* kv = g_kvec + (size_t)f * 65; double* vn = g_vnorm + f;
-    // KUSAGE per allele (3-mers: 64 bins + 1 "invalid" bin)
+    const size_t npairs = (size_t)A * (A - 1) / 2;
+    const bool in_lds = npairs <= (size_t)GT_DLDS;
+    // ---- 1. 3-mer counts (seq2kcounts, src/anseqs.cpp:149-166): 64 bins + one bin for 3-mers holding a byte outside ACGT (either case)
+    {
+      uint16_t* H = &L.u.hist[wv][0];
+      for (int a = wv; a < A; a += 4) {
+        for (int q = lane; q < 65 * 32; q += 64) ((uint32_t*)H)[q] = 0u;
+        wave_sync();
+        const uint8_t* s = arena + seq_off[f + a];
+        const int n = (int)seq_len[f + a];
+        // tiles of 1024 bases: a lane takes 16 consecutive positions + the two bases after them from ONE 16-byte load and one 2-byte load
+        // (the arena ends in 64 bytes of slack), i.e. 16 three-mers per round trip instead of one
+        for (int t0 = 0; t0 + 3 <= n; t0 += 1024) {
+          const int j0 = t0 + 16 * lane;
+          if (j0 + 3 <= n) {
+            uint8_t b[18];
+            __builtin_memcpy(b, s + j0, 16);
+            __builtin_memcpy(b + 16, s + j0 + 16, 2);
+            int code[18];
+#pragma unroll
+            for (int q = 0; q < 18; ++q) {
+              const uint8_t ch = b[q];
+              code[q] = (ch == 'A' || ch == 'a') ? 0 : (ch == 'C' || ch == 'c') ? 1 : (ch == 'G' || ch == 'g') ? 2 : (ch == 'T' || ch == 't') ? 3 : 4;
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+              if (j0 + q + 3 <= n) {
+                const bool ok = code[q] != 4 && code[q + 1] != 4 && code[q + 2] != 4;
+                const int idx = 16 * (code[q] & 3) + 4 * (code[q + 1] & 3) + (code[q + 2] & 3);
+                H[(ok ? idx : 64) * 64 + lane] += 1;        // the lane's own column: no atomics, no bank conflicts (two lanes share a dword)
+              }
+            }
+          }
+        }
+        wave_sync();
+        // column sums: lane q walks the 64 columns of bin q starting at its own index (rotated: distinct banks across the lanes)
+        {
+          uint32_t c0 = 0, c64 = 0;
+          for (int j = 0; j < 64; ++j) c0 += H[lane * 64 + ((j + lane) & 63)];
+          c64 = H[64 * 64 + lane];
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) c64 += __shfl_xor(c64, off);
+          double* v = kv + (size_t)a * 65;
+          v[lane] = (double)c0;
+          if (lane == 0) v[64] = (double)c64;
+        }
+        wave_sync();
+      }
+    }
+    __syncthreads();
+    // ---- 2. KUSAGE per allele (src/anseqs.cpp:111-147): frequencies, norm, Hill-Shannon diversity — sequential over the 65 bins
     for (int a = tid; a < A; a += blockDim.x) {
       double* v = kv + (size_t)a * 65;
-      for (int q = 0; q < 65; ++q) v[q] = 0.0;
-      const uint8_t* s = arena + seq_off[f + a];
-      const uint32_t n = seq_len[f + a];
-      if (n >= 3) {
-        for (uint32_t j = 0; j + 3 <= n; ++j) {
-          int idx = 0; bool ok = true;
-          for (int hh = 0; hh < 3; ++hh) {
-            const uint8_t ch = s[j + hh];
-            int c = (ch == 'A' || ch == 'a') ? 0 : (ch == 'C' || ch == 'c') ? 1 : (ch == 'G' || ch == 'g') ? 2 : (ch == 'T' || ch == 't') ? 3 : 4;
-            if (c == 4) { ok = false; break; }
-            idx = 4 * idx + c;
-          }
-          v[ok ? idx : 64] += 1.0;
-        }
-      }
       int total_counts = 0;
       for (int q = 0; q < 65; ++q) total_counts += v[q];            // int += double (src/anseqs.cpp:113-114)
       double norm = 0;
@@ -646,61 +744,99 @@ __global__ __launch_bounds__(256) void genotype_kernel(
     }
     __syncthreads();
     if (A == 1) { if (tid == 0) { gt[f] = gt_l[f] = gt_k[f] = 0; reps[f] = 0; n_gt[r] = 1; err_out[r] = 0; } continue; }
-    // the two matrices
-    for (int i = 0; i < A - 1; ++i) {
-      for (int j = i + 1 + tid; j < A; j += blockDim.x) {
-        const uint32_t x = seq_len[f + i], y = seq_len[f + j];
-        const bool xs = x < y;
-        double d = xs ? (double)(y - x) : (double)(x - y);
-        d = xs ? d / y : d / x;
-        dl[didx(A, i, j)] = d; wk[didx(A, i, j)] = d;
-        const double* vi = kv + (size_t)i * 65; const double* vj = kv + (size_t)j * 65;
-        double dot = 0;
-        for (int q = 0; q < 65; ++q) dot += vi[q] * vj[q];
-        const double cs = dot / (vn[i] * vn[j]);
-        const bool nan_norm = (vn[i] != vn[i]) || (vn[j] != vn[j]);
-        dk[didx(A, i, j)] = 1.0 - (nan_norm ? 0 : (round(cs * 1000.0) / 1000.0));
-      }
+    // ---- 3. the two matrices, one pair per thread and pass
+    for (size_t p = tid; p < npairs; p += blockDim.x) {
+      // row i of the condensed index p: off(i) = i (2A - i - 1) / 2 <= p < off(i + 1)
+      int i = (int)((2.0 * A - 1.0 - sqrt((2.0 * A - 1.0) * (2.0 * A - 1.0) - 8.0 * (double)p)) * 0.5);
+      if (i < 0) i = 0;
+      if (i > A - 2) i = A - 2;
+      while (i > 0 && (size_t)i * (2 * A - i - 1) / 2 > p) --i;
+      while ((size_t)(i + 1) * (2 * A - i - 2) / 2 <= p) ++i;
+      const int j = (int)(p - (size_t)i * (2 * A - i - 1) / 2) + i + 1;
+      const uint32_t x = seq_len[f + i], y = seq_len[f + j];
+      const bool xs = x < y;
+      double d = xs ? (double)(y - x) : (double)(x - y);
+      d = xs ? d / y : d / x;
+      dl[p] = d;
+      if (in_lds) L.dmat[p] = d; else wk[p] = d;
+      const double* vi = kv + (size_t)i * 65; const double* vj = kv + (size_t)j * 65;
+      double dot = 0;
+      for (int q = 0; q < 65; ++q) dot += vi[q] * vj[q];
+      const double cs = dot / (vn[i] * vn[j]);
+      const bool nan_norm = (vn[i] != vn[i]) || (vn[j] != vn[j]);
+      dk[p] = 1.0 - (nan_norm ? 0 : (round(cs * 1000.0) / 1000.0));
     }
     __syncthreads();
-    // length clustering
-    hclust_to_merge(A, wk, L, tid);
-    if (tid == 0) { int kc; for (kc = 0; kc < (A - 1); kc++) if (L.height[kc] >= max_error_l) break; L.cut_k = A - kc; }
-    __syncthreads();
-    if (tid < 64) cutree_wave(A, L.merge, L.cut_k, L.labels, L.ct_up, L.ct_own, L.ct_first, L.ct_lab, tid);
-    __syncthreads();
-    for (int a = tid; a < A; a += blockDim.x) gt_l[f + a] = L.labels[a];
-    for (size_t q = tid; q < (size_t)A * (A - 1) / 2; q += blockDim.x) wk[q] = dk[q];
-    __syncthreads();
-    hclust_to_merge(A, wk, L, tid);
-    if (tid == 0) { int kc; for (kc = 0; kc < (A - 1); kc++) if (L.height[kc] >= max_error_c) break; L.cut_k = A - kc; }
-    __syncthreads();
-    if (tid < 64) cutree_wave(A, L.merge, L.cut_k, L.labels2, L.ct_up, L.ct_own, L.ct_first, L.ct_lab, tid);
-    __syncthreads();
-    if (tid == 0) {
-      for (int a = 0; a < A; ++a) gt_k[f + a] = L.labels2[a];
-      // final clusters: distinct (gt_l, gt_k) in first-seen order (:500-516)
-      int ng = 0;
-      for (int a = 0; a < A; ++a) L.cnt[a] = -1;
-      for (int a = 0; a < A; ++a) {
-        if (L.cnt[a] >= 0) continue;
-        for (int b = a; b < A; ++b) if (L.cnt[b] < 0 && L.labels[b] == L.labels[a] && L.labels2[b] == L.labels2[a]) L.cnt[b] = ng;
-        ++ng;
+    // ---- 4. the two clusterings, one after the other on one scratch: NN-chain on wave 0 (for regions of up to 102 alleles on the LDS working copy:
+    // every nearest-neighbour scan and update at LDS latency), rank sort of the merges by all threads, union-find relabel by one thread, tree
+    // cut by wave 0
+    auto cluster_one = [&](double* D, double cut, int* labels_out) {
+      HcScratch& S = L.u.hc;
+      if (wv == 0) nn_chain_average(A, D, S, lane);
+      __syncthreads();
+      for (int i = tid; i < A - 1; i += blockDim.x) {        // stable sort by height = rank by (distance, position) (fastcluster_R_dm.hpp:74)
+        int rank = 0;
+        const double di = S.zdist[i];
+        for (int j = 0; j < A - 1; ++j) { const double dj = S.zdist[j]; if (dj < di || (dj == di && j < i)) ++rank; }
+        S.zrank[rank] = i;
       }
-      for (int a = 0; a < A; ++a) { gt[f + a] = L.cnt[a]; reps[f + a] = -1; }
-      for (int g = 0; g < ng; ++g) {                                  // medoid under the length matrix (:517-524)
-        int min_i = -1; double min_sum = 100000000.0;
-        for (int a = 0; a < A; ++a) {
-          if (L.cnt[a] != g) continue;
-          if (min_i < 0) min_i = a;
-          double sm = 0.0;
-          for (int b = 0; b < A; ++b) if (L.cnt[b] == g && a != b) sm += dget(dl, A, a, b);
-          if (sm < min_sum) { min_i = a; min_sum = sm; }
-        }
-        reps[f + g] = min_i;
+      __syncthreads();
+      if (tid == 0) {
+        dendrogram_relabel(A, S);
+        int kc;                                              // cutree_cdist: below the first merge whose height reaches the threshold
+        for (kc = 0; kc < (A - 1); kc++) if (S.height[kc] >= cut) break;
+        S.cut_k = A - kc;
       }
-      n_gt[r] = ng; err_out[r] = 0;
+      __syncthreads();
+      if (wv == 0) cutree_wave(A, S.merge, S.cut_k, S.labels, S.ct_up, S.ct_own, S.ct_first, S.ct_lab, lane);
+      __syncthreads();
+      for (int a2 = tid; a2 < A; a2 += blockDim.x) labels_out[a2] = S.labels[a2];
+      __syncthreads();
+    };
+    cluster_one(in_lds ? L.dmat : wk, max_error_l, L.lab_l);
+    if (in_lds) { for (size_t q = tid; q < npairs; q += blockDim.x) L.dmat[q] = dk[q]; __syncthreads(); }
+    cluster_one(in_lds ? L.dmat : dk, max_error_c, L.lab_k);
+    // ---- 5. genotypes: distinct (gt_l, gt_k) pairs numbered by first appearance (:500-516)
+    const int* lab_l = L.lab_l; const int* lab_k = L.lab_k;
+    for (int a = tid; a < A; a += blockDim.x) {
+      gt_l[f + a] = lab_l[a]; gt_k[f + a] = lab_k[a];
+      int fo = a;
+      for (int b2 = 0; b2 < a; ++b2) if (lab_l[b2] == lab_l[a] && lab_k[b2] == lab_k[a]) { fo = b2; break; }
+      L.firstof[a] = fo;
     }
+    __syncthreads();
+    {   // number the first appearances in index order: per 64-chunk ballot + prefix count, chunk totals through LDS
+      const bool isf = tid < A && L.firstof[tid < A ? tid : 0] == tid;
+      const unsigned long long fm = __ballot(isf);
+      if (lane == 0) L.nfirst[wv] = __builtin_popcountll(fm);
+      __syncthreads();
+      int base = 0;
+      for (int w = 0; w < wv; ++w) base += L.nfirst[w];
+      if (isf) L.gtlab[tid] = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+      __syncthreads();
+    }
+    const int ng = L.nfirst[0] + L.nfirst[1] + L.nfirst[2] + L.nfirst[3];
+    for (int a = tid; a < A; a += blockDim.x) { const int g2 = L.gtlab[L.firstof[a]]; gt[f + a] = g2; reps[f + a] = -1; }
+    __syncthreads();
+    // medoid of every genotype under the length matrix (:517-524): row sums over the genotype in ascending order, first strict minimum
+    for (int a = tid; a < A; a += blockDim.x) {
+      const int fa = L.firstof[a];
+      double sm = 0.0;
+      for (int b2 = 0; b2 < A; ++b2) if (b2 != a && L.firstof[b2] == fa) sm += dget(dl, A, a, b2);
+      L.rowsum[a] = sm;
+    }
+    __syncthreads();
+    for (int a = tid; a < A; a += blockDim.x) {
+      if (L.firstof[a] != a) continue;                        // one thread per genotype: the one of its first allele
+      int min_i = -1; double min_sum = 100000000.0;
+      for (int b2 = a; b2 < A; ++b2) {
+        if (L.firstof[b2] != a) continue;
+        if (min_i < 0) min_i = b2;
+        if (L.rowsum[b2] < min_sum) { min_i = b2; min_sum = L.rowsum[b2]; }
+      }
+      reps[f + L.gtlab[a]] = min_i;
+    }
+    if (tid == 0) { n_gt[r] = ng; err_out[r] = 0; }
   }
 }
 
