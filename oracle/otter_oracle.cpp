@@ -46,6 +46,49 @@ struct Form {
 };
 
 /* ------------------------------------------------------------------------------------------
+ * WFA2-lib's adaptive wavefront reduction, `wf_heuristic_wfadaptive(min_wavefront_length, max_distance_threshold, steps_between_cutoffs)`
+ * (wavefront_heuristic_cufoff, wavefront_heuristic.c:470 in the author's build) — OFF by default: the exact
+ * aligner is the contract.  It exists to SIZE a risk: otter never calls setHeuristic* (src/assemble.cpp:49-50), and whether the author's
+ * WFA2-lib build defaulted to `none` or to wfadaptive(10, 50, 1) cannot be read off the debug bundle.  scripts/heuristic_risk.py runs both modes
+ * over the bench workloads and counts what changes.  Restated from the published WFA2-lib v2.3 behaviour (recalled; unverifiable offline):
+ * after the M wavefront of a score is extended and the end test has failed, every `steps` scores, if it spans at least `min_wf_len`
+ * diagonals: distance(k) = what is left to align from its offset (end-to-end: max(plen - v, tlen - h); ends-free: the smaller of the two
+ * free-end variants), and diagonals whose distance exceeds the smallest by more than `max_dist` are dropped from both ends — never past the
+ * end diagonal(s); the I / D wavefronts of that score are cut to the same range.
+ * ------------------------------------------------------------------------------------------ */
+struct Heuristic { int on = 0, min_wf_len = 10, max_dist = 50, steps = 1; };
+static Heuristic g_heur;
+
+/* trims [lo, hi] of an extended M wavefront; off(k) = offset (h) of diagonal k or negative */
+template <class Off>
+static void wfadaptive_cut(const Heuristic& H, int& steps_wait, int pl, int tl, const Form& f, int& lo, int& hi, Off off)
+{
+  --steps_wait;
+  if (steps_wait > 0) return;
+  if (hi - lo + 1 < H.min_wf_len) return;
+  const int big = 1 << 30;
+  auto dist = [&](int k) -> int {
+    const int h = off(k);
+    if (h < 0) return big;
+    const int v = h - k, left_v = pl - v, left_h = tl - h;
+    if (!f.endsfree) return std::max(left_v, left_h);
+    const int up = std::max(left_h, left_v - f.pef), down = std::max(left_v, left_h - f.tef);
+    return std::min(up, down);
+  };
+  int mind = big;
+  for (int k = lo; k <= hi; ++k) mind = std::min(mind, dist(k));
+  const int kend = tl - pl;
+  const int min_k = f.endsfree ? kend - f.tef : kend, max_k = f.endsfree ? kend + f.pef : kend;
+  const int top_limit = std::min(min_k - 1, hi);
+  int nlo = lo, nhi = hi;
+  for (int k = lo; k < top_limit; ++k) { if (dist(k) - mind <= H.max_dist) break; ++nlo; }
+  const int bottom_limit = std::max(max_k + 1, nlo);
+  for (int k = hi; k > bottom_limit; --k) { if (dist(k) - mind <= H.max_dist) break; --nhi; }
+  lo = nlo; hi = nhi;
+  steps_wait = H.steps;
+}
+
+/* ------------------------------------------------------------------------------------------
  * WFA, unit-cost edit distance, score only.  Replaces WFAlignerEdit(Score, MemoryMed)
  * (constructed src/assemble.cpp:49; called src/analignments.cpp:70-71,88-97).
  * Algorithm: WFA2-lib wavefront_compute_edit + wavefront_extend_* (SURVEY Appendix A.3 items 1,2,4):
@@ -66,6 +109,7 @@ int wfa_edit(const uint8_t* p, int pl, const uint8_t* t, int tl, const Form& f, 
   const int B = pl + 1;
   for (int k = lo; k <= hi; ++k) cur[k + B] = k > 0 ? k : 0;
   uint64_t W = 0;
+  int steps_wait = 0;
   for (int s = 0;; ++s) {
     W += (uint64_t)(hi - lo + 1);
     for (int k = lo; k <= hi; ++k) {
@@ -84,6 +128,12 @@ int wfa_edit(const uint8_t* p, int pl, const uint8_t* t, int tl, const Form& f, 
     if (!f.endsfree && kend >= lo && kend <= hi && cur[kend + B] >= tl) {
       if (cells) *cells = W;
       return s;
+    }
+    if (g_heur.on) {
+      const int olo = lo, ohi = hi;
+      wfadaptive_cut(g_heur, steps_wait, pl, tl, f, lo, hi, [&](int k) { return cur[k + B]; });
+      for (int k = olo; k < lo; ++k) cur[k + B] = NULL_OFF;
+      for (int k = hi + 1; k <= ohi; ++k) cur[k + B] = NULL_OFF;
     }
     int nlo = lo - 1 < -pl ? -pl : lo - 1, nhi = hi + 1 > tl ? tl : hi + 1;
     for (int k = nlo; k <= nhi; ++k) {
@@ -128,6 +178,7 @@ int wfa_affine(const uint8_t* p, int pl, const uint8_t* t, int tl, int x, int o,
   const int kend = tl - pl;
   uint64_t W = 0;
   int s_end = -1, k_end = 0;
+  int steps_wait = 0;
   for (int s = 0;; ++s) {
     M.emplace_back(); I.emplace_back(); D.emplace_back(); BT.emplace_back();
     WF& m = M[s]; WF& iw = I[s]; WF& dw = D[s];
@@ -195,6 +246,22 @@ int wfa_affine(const uint8_t* p, int pl, const uint8_t* t, int tl, int x, int o,
     }
     if (!f.endsfree && kend >= m.lo && kend <= m.hi && m.off[kend - m.lo] >= tl) { done = true; s_end = s; k_end = kend; }
     if (done) break;
+    if (g_heur.on && !m.null()) {
+      int lo = m.lo, hi = m.hi;
+      wfadaptive_cut(g_heur, steps_wait, pl, tl, f, lo, hi, [&](int k) { return m.get(k); });
+      if (lo != m.lo || hi != m.hi) {
+        auto trim = [&](WF& w, std::vector<uint8_t>* bt) {      /* wavefront_heuristic_equate: the same range for the score's I / D wavefronts */
+          if (w.null()) return;
+          const int nlo = std::max(w.lo, lo), nhi = std::min(w.hi, hi);
+          if (nhi < nlo) { w.lo = 1; w.hi = 0; w.off.clear(); if (bt) bt->clear(); return; }
+          w.off.erase(w.off.begin(), w.off.begin() + (nlo - w.lo));
+          w.off.resize(nhi - nlo + 1);
+          if (bt) { bt->erase(bt->begin(), bt->begin() + (nlo - w.lo)); bt->resize(nhi - nlo + 1); }
+          w.lo = nlo; w.hi = nhi;
+        };
+        trim(iw, nullptr); trim(dw, nullptr); trim(m, &BT[s]);
+      }
+    }
   }
   if (cells) *cells = W;
   if (!cigar) return s_end;
@@ -306,6 +373,79 @@ int dp_affine(const uint8_t* p, int pl, const uint8_t* t, int tl, int x, int o, 
     std::swap(Hp, Hc); std::swap(Ep, Ec); std::swap(Fp, Fc);
   }
   return best;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A second witness for the op-string rule (tests only): gap-affine alignment by the classic O(nm) three-matrix dynamic programme
+ * (Gotoh) with a backtrace that applies, cell by cell, the priorities the wavefront aligner's piggy-back provenance implies
+ *  — written from the alignment matrix, not from wavefronts:
+ *   in the match state at (v, h) with score s, walking backwards:  a mismatch column (bases differ, the diagonal predecessor holds
+ *   s - x) wins over closing a deletion (F(v, h) = s) wins over closing an insertion (E(v, h) = s) wins over continuing along equal
+ *   bases — the wavefront backtrace enters a diagonal at its FURTHEST entry point, which a backwards walk meets first;
+ *   in a gap state: extending (the same gap state one column back holds s - e) wins over opening.
+ * End-to-end, or ends-free with WFA2's end rule (lowest score, then the lowest diagonal) and explicit leading / trailing gap runs.
+ * tests/test_oracle_align.py asserts that it returns the very op strings of wfa_affine above on 10^4 tandem-repeat pairs.
+ * ------------------------------------------------------------------------------------------ */
+int gotoh_witness(const uint8_t* p, int pl, const uint8_t* t, int tl, int x, int o, int e, const Form& f, std::string* cigar)
+{
+  const int INF = 1 << 28;
+  const int pbf = f.endsfree ? std::min(f.pbf, pl) : 0, pef = f.endsfree ? f.pef : 0;
+  const int tbf = f.endsfree ? std::min(f.tbf, tl) : 0, tef = f.endsfree ? f.tef : 0;
+  const size_t W = (size_t)tl + 1;
+  std::vector<int> A((size_t)(pl + 1) * W, INF), E((size_t)(pl + 1) * W, INF), F((size_t)(pl + 1) * W, INF);   /* A = best of the three states */
+  auto at = [&](std::vector<int>& M, int v, int h) -> int& { return M[(size_t)v * W + h]; };
+  for (int v = 0; v <= pl; ++v) {
+    for (int h = 0; h <= tl; ++h) {
+      int best = INF;
+      if ((v == 0 && h <= tbf) || (h == 0 && v <= pbf)) best = 0;          /* a free start (the origin included) */
+      if (h > 0) { const int ee = std::min(at(E, v, h - 1) + e, at(A, v, h - 1) + o + e); at(E, v, h) = std::min(ee, INF); best = std::min(best, at(E, v, h)); }
+      if (v > 0) { const int ff = std::min(at(F, v - 1, h) + e, at(A, v - 1, h) + o + e); at(F, v, h) = std::min(ff, INF); best = std::min(best, at(F, v, h)); }
+      if (v > 0 && h > 0) best = std::min(best, at(A, v - 1, h - 1) + (p[v - 1] == t[h - 1] ? 0 : x));
+      at(A, v, h) = best;
+    }
+  }
+  /* the end cell */
+  int ve = pl, he = tl, score = at(A, pl, tl);
+  if (f.endsfree) {
+    score = INF; int kbest = 0;
+    auto cand = [&](int v, int h) { const int sc = at(A, v, h), k = h - v; if (sc < score || (sc == score && k < kbest)) { score = sc; kbest = k; ve = v; he = h; } };
+    for (int v = pl; v >= 0 && pl - v <= pef; --v) cand(v, tl);
+    for (int h = tl; h >= 0 && tl - h <= tef; --h) cand(pl, h);
+  }
+  if (!cigar) return score;
+  std::string rev;
+  const std::string trailing = std::string(tl - he, 'I') + std::string(pl - ve, 'D');      /* free trailing gaps: remaining text first, then remaining pattern */
+  int v = ve, h = he, s = score, state = 0;
+  while (true) {
+    if (state == 0) {
+      if (s == 0) {
+        /* score 0: only equal bases are left on this diagonal, back to a free start cell on an axis */
+        while (v > 0 && h > 0) { rev.push_back('M'); --v; --h; }
+        break;
+      }
+      const bool diag = v > 0 && h > 0;
+      const bool eq = diag && p[v - 1] == t[h - 1];
+      if (diag && !eq && at(A, v - 1, h - 1) == s - x) { rev.push_back('X'); --v; --h; s -= x; }
+      else if (v > 0 && at(F, v, h) == s) state = 2;
+      else if (h > 0 && at(E, v, h) == s) state = 1;
+      else if (eq && at(A, v - 1, h - 1) == s) { rev.push_back('M'); --v; --h; }
+      else return -3;      /* inconsistent matrix */
+    } else if (state == 1) {
+      rev.push_back('I');
+      if (at(E, v, h - 1) + e == s) { s -= e; } else { s -= o + e; state = 0; }
+      --h;
+    } else {
+      rev.push_back('D');
+      if (at(F, v - 1, h) + e == s) { s -= e; } else { s -= o + e; state = 0; }
+      --v;
+    }
+  }
+  cigar->clear();
+  cigar->append(h, 'I');
+  cigar->append(v, 'D');
+  cigar->append(rev.rbegin(), rev.rend());
+  cigar->append(trailing);
+  return score;
 }
 
 /* Re-score an op string (validity check): returns penalty, or -1 if it does not consume both
@@ -1264,6 +1404,16 @@ int oto_dp_edit(const uint8_t* p, int pl, const uint8_t* t, int tl, int endsfree
 int oto_dp_affine(const uint8_t* p, int pl, const uint8_t* t, int tl, int x, int o, int e, int endsfree, int pbf, int pef, int tbf, int tef)
 { return oto::dp_affine(p, pl, t, tl, x, o, e, oto::Form{endsfree, pbf, pef, tbf, tef}); }
 
+/* the Gotoh witness: score, op string into out (capacity cap; returns the length through *len) */
+int oto_gotoh_align(const uint8_t* p, int pl, const uint8_t* t, int tl, int x, int o, int e, int endsfree, int pbf, int pef, int tbf, int tef,
+                    char* out, int cap, int* len)
+{
+  std::string c;
+  const int sc = oto::gotoh_witness(p, pl, t, tl, x, o, e, oto::Form{endsfree, pbf, pef, tbf, tef}, &c);
+  if (len) *len = (int)c.size();
+  if (out && (int)c.size() <= cap) memcpy(out, c.data(), c.size());
+  return sc;
+}
 int oto_cigar_score(const uint8_t* p, int pl, const uint8_t* t, int tl, int x, int o, int e, int endsfree, int pbf, int pef, int tbf, int tef,
                     const char* cig, int n)
 { return oto::cigar_score(p, pl, t, tl, x, o, e, oto::Form{endsfree, pbf, pef, tbf, tef}, cig, n); }
@@ -1470,6 +1620,12 @@ void oto_realign_batch(const otg_params* P, const uint8_t* arena, uint64_t, cons
 }
 
 void oto_assemble_free(oto_result* R) { delete R; }
+/* heuristic mode of the oracle's aligners (0 = exact, the contract; 1 = wfadaptive(min_wf_len, max_dist, steps)): process-wide, for
+ * scripts/heuristic_risk.py only */
+void oto_set_heuristic(int on, int min_wf_len, int max_dist, int steps)
+{
+  oto::g_heur.on = on; oto::g_heur.min_wf_len = min_wf_len; oto::g_heur.max_dist = max_dist; oto::g_heur.steps = steps < 1 ? 1 : steps;
+}
 void oto_set_poa_hook(void* fn) { oto::g_poa_hook = (oto::oto_poa_hook_t)fn; }
 uint32_t oto_result_n_alleles(oto_result* R) { return R->alleles.size(); }
 uint64_t oto_result_seq_bytes(oto_result* R) { return R->seqs.size(); }
