@@ -114,6 +114,8 @@ void otg_destroy(otg_ctx* ctx)
   (void)hipStreamSynchronize(ctx->stream);
   otg_pipeline_free(ctx);
   for (auto& b : ctx->pool) if (b.p) (void)hipFree(b.p);
+  for (int i = 0; i < 5; ++i) { if (ctx->tier_stream[i]) (void)hipStreamDestroy(ctx->tier_stream[i]); if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]); }
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

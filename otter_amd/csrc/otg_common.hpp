@@ -29,6 +29,9 @@ struct otg_ctx {
   // resident batch of the L3 pipeline
   struct Pipeline* pipe = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // side streams of the gap-affine chain: on small batches the register tiers run next to each other (wfa_affine.hip); created on first use
+  hipStream_t tier_stream[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   double last_kernel_ms = 0.0;                    // HIP-event time of the kernels of the latest operator-level call that reports one (otg_last_kernel_ms)
   unsigned long long* affine_visited = nullptr;   // device counter: (score, diagonal) cells the exact gap-affine tiers visited (wfa_affine.hip)
 };
