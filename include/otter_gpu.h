@@ -405,6 +405,25 @@ int otg_assemble_result_sizes(otg_ctx* ctx, uint32_t* n_alleles, uint64_t* seq_b
  * otg_assemble_result_sizes.  The library's stream is synchronised before returning.             */
 int otg_assemble_device_results(otg_ctx* ctx, const otg_region_result** d_regions, const otg_allele** d_alleles,
                                 const uint8_t** d_seqs);
+/* ---------------------------------------------------------------------------------------------
+ * One process per GPU: the end-of-run gather of the allele records to rank 0 over RCCL (xGMI) — north_star's multi-GPU form; the
+ * single-process reference prints under a mutex instead (src/assemble.cpp:143-149).  Rank r owns the r-th contiguous BED shard
+ * (src/BS_thread_pool.hpp:183-198), so rank order is BED order.  librccl is loaded at run time by the first call.
+ *   otg_comm_unique_id   rank 0 makes the 128-byte id; the host hands it to the other ranks (file, socket, environment: its business);
+ *   otg_comm_create      every rank, with its device, its rank and the world size (collective: returns when all ranks have called it);
+ *   otg_gather_sizes     after otg_assemble_run: counts_out[3 * r + {0, 1, 2}] = regions, allele records, sequence bytes of rank r (every rank);
+ *   otg_gather_records   rank 0 passes buffers for the totals and receives regions / alleles / sequences of all ranks in rank order,
+ *                        region / allele / sequence indices rebased to job-wide ones; the other ranks pass NULL.  Records travel
+ *                        device -> device; the one device-to-host copy happens on rank 0.
+ * ------------------------------------------------------------------------------------------- */
+#define OTG_COMM_ID_BYTES 128
+typedef struct otg_comm otg_comm;
+int  otg_comm_unique_id(uint8_t* id_out);
+int  otg_comm_create(int device, int rank, int world, const uint8_t* id, otg_comm** out);
+void otg_comm_destroy(otg_comm* comm);
+int  otg_gather_sizes(otg_ctx* ctx, otg_comm* comm, uint64_t* counts_out);
+int  otg_gather_records(otg_ctx* ctx, otg_comm* comm, const uint64_t* counts, otg_region_result* regions_out, otg_allele* alleles_out, uint8_t* seqs_out);
+
 /* D2H of the results.  labels_out (nullable) gets the final per-read label (-1 unassigned).     */
 int otg_assemble_collect(otg_ctx* ctx,
                          otg_region_result* region_out,
@@ -443,6 +462,21 @@ typedef struct otg_job_stats {
 } otg_job_stats;
 /* (otg_write_fn is declared above, with otg_wgat) */
 int otg_assemble_files(const otg_assemble_job* job, otg_write_fn write, void* user, otg_job_stats* stats);
+/* `otter genotype` from files to text in one call — genotype() / genotype_process() (src/genotype.cpp:69-192): BED regions in bounded
+ * batches through allele ingest (otg_ingest_alleles on `threads` host threads), anallele_cluster on the device (otg_genotype_cluster_batch)
+ * and the VCF text (header first; otg_emit_vcf_lines), in BED order.  Without a reference FASTA the reference prints region, sample and the
+ * two allele lengths instead (src/genotype.cpp:112-121): otg_emit_genotype_lengths, no device work.  stats: n_reads counts allele records. */
+typedef struct otg_genotype_job {
+  const char* bam_path;          /* the allele BAM `otter assemble` wrote (its index is <BAM>.bai)  */
+  const char* bed_path;          /* -b                                                               */
+  const char* fasta_path;        /* -r (NULL or "": the length table instead of VCF)                 */
+  otg_params  params;            /* gt_max_error (-e), gt_max_cosdis (-c)                            */
+  int32_t     threads;           /* -t: host threads of the allele ingest                            */
+  int32_t     device;            /* HIP device ordinal                                               */
+  uint32_t    batch_regions;     /* regions per batch, 0 = 1024                                      */
+  uint32_t    reserved;
+} otg_genotype_job;
+int otg_genotype_files(const otg_genotype_job* job, otg_write_fn write, void* user, otg_job_stats* stats);
 /* The dispatcher keeps its per-device contexts (and their HBM workspaces) for the next job of the process; this frees them. */
 void otg_assemble_files_release(void);
 

@@ -18,7 +18,8 @@ EXPORTS = [
     "otg_bam_open", "otg_bam_close", "otg_bam_n_targets", "otg_bam_target", "otg_ingest_regions",
     "otg_ingest_regions_named", "otg_emit_reads", "otg_parse_bed_file", "otg_fasta_open", "otg_fasta_close", "otg_fasta_n_seqs",
     "otg_fasta_seq", "otg_fasta_fetch", "otg_fasta_region_flanks",
-    "otg_bam_sample_index", "otg_bam_sample", "otg_ingest_alleles", "otg_emit_vcf_header", "otg_emit_vcf_lines", "otg_emit_genotype_lengths", "otg_assemble_files", "otg_assemble_files_release", "otg_wgat",
+    "otg_bam_sample_index", "otg_bam_sample", "otg_ingest_alleles", "otg_emit_vcf_header", "otg_emit_vcf_lines", "otg_emit_genotype_lengths", "otg_assemble_files", "otg_assemble_files_release", "otg_genotype_files", "otg_wgat",
+    "otg_comm_unique_id", "otg_comm_create", "otg_comm_destroy", "otg_gather_sizes", "otg_gather_records",
 ]
 
 _lib = None
@@ -238,6 +239,51 @@ class Context:
         self.assemble_submit(params, batch, region_range)
         self.assemble_run()
         return self.assemble_collect()
+
+
+class Comm:
+    """An RCCL communicator of the library (otg_comm_create): one per process and GPU, for Context.gather_records_rccl."""
+
+    def __init__(self, device, rank, world, uid):
+        L = load()
+        h = C.c_void_p()
+        L.otg_comm_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]
+        rc = L.otg_comm_create(int(device), int(rank), int(world), uid, C.byref(h))
+        if rc != 0:
+            raise OtterGpuError("otg_comm_create failed (%d): %s" % (rc, (L.otg_last_error(None) or b"").decode()))
+        self._h, self._L, self.rank, self.world = h, L, int(rank), int(world)
+        L.otg_comm_destroy.argtypes = [C.c_void_p]
+
+    @staticmethod
+    def unique_id():
+        L = load()
+        buf = C.create_string_buffer(128)
+        rc = L.otg_comm_unique_id(buf)
+        if rc != 0:
+            raise OtterGpuError("otg_comm_unique_id failed (%d): %s" % (rc, (L.otg_last_error(None) or b"").decode()))
+        return buf.raw
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.otg_comm_destroy(self._h)
+            self._h = None
+
+    def gather_records(self, ctx):
+        """End-of-run gather of ctx's last results to rank 0 (otg_gather_sizes + otg_gather_records).  Rank 0 gets
+        {"regions", "alleles", "seqs", "counts"} of the whole job in rank order; the other ranks get {"counts"}."""
+        L = self._L
+        counts = np.zeros(3 * self.world, dtype=np.uint64)
+        L.otg_gather_sizes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.otg_gather_records.argtypes = [C.c_void_p] * 6
+        ctx._check(L.otg_gather_sizes(ctx._h, self._h, abi.ptr(counts)), "otg_gather_sizes")
+        if self.rank != 0:
+            ctx._check(L.otg_gather_records(ctx._h, self._h, abi.ptr(counts), None, None, None), "otg_gather_records")
+            return {"counts": counts.reshape(-1, 3)}
+        tot = counts.reshape(-1, 3).sum(axis=0)
+        res = {"regions": np.zeros(int(tot[0]), dtype=abi.region_result_dt), "alleles": np.zeros(int(tot[1]), dtype=abi.allele_dt),
+               "seqs": np.zeros(max(1, int(tot[2])), dtype=np.uint8), "counts": counts.reshape(-1, 3)}
+        ctx._check(L.otg_gather_records(ctx._h, self._h, abi.ptr(counts), abi.ptr(res["regions"]), abi.ptr(res["alleles"]), abi.ptr(res["seqs"])), "otg_gather_records")
+        return res
 
 
 def device_count():
@@ -558,6 +604,28 @@ def assemble_files(bam, bed, fasta=None, read_group="", is_fasta=False, reads_on
     rc = L.otg_assemble_files(C.byref(job), cb, None, C.byref(st))
     if rc != 0:
         raise OtterGpuError("otg_assemble_files failed (%d): %s" % (rc, (L.otg_last_error(None) or b"").decode()))
+    return b"".join(chunks), {k: getattr(st, k) for k, _ in abi.JobStats._fields_}
+
+
+def genotype_files(bam, bed, fasta=None, params=None, threads=1, device=0, batch_regions=0):
+    """otg_genotype_files: `otter genotype` from files to text (VCF with a reference FASTA, the two-length table without).
+    Returns (text bytes, stats dict)."""
+    L = load()
+    job = abi.GenotypeJob()
+    job.bam_path = bam.encode(); job.bed_path = bed.encode(); job.fasta_path = fasta.encode() if fasta else None
+    job.params = params if params is not None else abi.default_params()
+    job.threads = threads; job.device = device; job.batch_regions = batch_regions
+    chunks = []
+
+    def sink(_user, data, n):
+        chunks.append(C.string_at(data, n))
+        return 0
+    cb = abi.WRITE_FN(sink)
+    st = abi.JobStats()
+    L.otg_genotype_files.argtypes = [C.POINTER(abi.GenotypeJob), abi.WRITE_FN, C.c_void_p, C.POINTER(abi.JobStats)]
+    rc = L.otg_genotype_files(C.byref(job), cb, None, C.byref(st))
+    if rc != 0:
+        raise OtterGpuError("otg_genotype_files failed (%d): %s" % (rc, (L.otg_last_error(None) or b"").decode()))
     return b"".join(chunks), {k: getattr(st, k) for k, _ in abi.JobStats._fields_}
 
 

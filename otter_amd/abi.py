@@ -156,6 +156,12 @@ class AssembleJob(C.Structure):
                 ("batch_regions", C.c_uint32), ("n_devices", C.c_int32), ("devices", C.POINTER(C.c_int32))]
 
 
+class GenotypeJob(C.Structure):
+    """otg_genotype_job (include/otter_gpu.h)."""
+    _fields_ = [("bam_path", C.c_char_p), ("bed_path", C.c_char_p), ("fasta_path", C.c_char_p), ("params", otg_params),
+                ("threads", C.c_int32), ("device", C.c_int32), ("batch_regions", C.c_uint32), ("reserved", C.c_uint32)]
+
+
 class JobStats(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ("n_regions", "n_regions_ok", "n_regions_skipped", "n_reads", "n_alleles", "input_bytes", "output_bytes")] + \
                [("n_devices", C.c_uint32), ("reserved", C.c_uint32)] + [(k, C.c_double) for k in ("ms_total", "ms_ingest", "ms_hot_path", "ms_emit")]

@@ -397,6 +397,107 @@ int otg_assemble_files(const otg_assemble_job* job, otg_write_fn write, void* us
   return OTG_OK;
 }
 
+// ---- `otter genotype` from files to text in one call: genotype() / genotype_process() (src/genotype.cpp:69-192).  Regions in bounded
+// batches: allele ingest (host threads) -> anallele_cluster on the device -> VCF lines (or, without a reference, the two-length table),
+// text in BED order.  The reference's worker loop does the same region by region on a thread pool and prints under a mutex.
+int otg_genotype_files(const otg_genotype_job* job, otg_write_fn write, void* user, otg_job_stats* stats)
+{
+  if (!job || !write || !job->bam_path || !job->bed_path) return otg_fail(nullptr, OTG_ERR_ARG, "otg_genotype_files: NULL job, writer, BAM or BED path");
+  const auto t_all = Clock::now();
+  otg_job_stats st{};
+  std::vector<otg_bed> beds; std::vector<char> chr_arena;
+  {
+    uint32_t n = 0, skipped = 0; uint64_t cu = 0;
+    int rc = otg_parse_bed_file(job->bed_path, nullptr, 0, &n, nullptr, 0, &cu, &skipped);
+    if (rc != OTG_OK && rc != OTG_ERR_CAPACITY) return rc;
+    beds.resize((size_t)n + 1); chr_arena.resize((size_t)cu + 16);
+    rc = otg_parse_bed_file(job->bed_path, beds.data(), (uint32_t)beds.size(), &n, chr_arena.data(), chr_arena.size(), &cu, &skipped);
+    if (rc != OTG_OK) return rc;
+    beds.resize(n);
+    st.n_regions = n;
+  }
+  otg_bam* bam = nullptr; otg_fasta* fasta = nullptr; otg_ctx* ctx = nullptr;
+  int rc = otg_bam_open(job->bam_path, &bam);
+  if (rc != OTG_OK) return rc;
+  auto cleanup = [&] { if (ctx) pool_release(job->device, ctx); if (fasta) otg_fasta_close(fasta); otg_bam_close(bam); };
+  uint32_t n_samples = 0; int32_t ol = 0, orr = 0;
+  rc = otg_bam_sample_index(bam, &n_samples, &ol, &orr);                      // SampleIndex::init (src/anbamdb.cpp:42-63)
+  if (rc != OTG_OK) { cleanup(); return rc; }
+  const bool with_ref = job->fasta_path && job->fasta_path[0];
+  if (with_ref) {
+    rc = otg_fasta_open(job->fasta_path, &fasta);
+    if (rc != OTG_OK) { cleanup(); return rc; }
+    if (!(ctx = pool_acquire(job->device))) { cleanup(); return otg_fail(nullptr, OTG_ERR_NO_DEVICE, "otg_genotype_files: %s", last_err().c_str()); }
+    uint64_t need = 0;
+    rc = otg_emit_vcf_header(bam, nullptr, 0, &need);                        // output_vcf_header (src/genotype.cpp:16-40)
+    if (rc != OTG_OK && rc != OTG_ERR_CAPACITY) { cleanup(); return rc; }
+    std::string hdr(need, '\0');
+    rc = otg_emit_vcf_header(bam, need ? &hdr[0] : nullptr, need, &need);
+    if (rc != OTG_OK) { cleanup(); return rc; }
+    if (write(user, hdr.data(), hdr.size()) != 0) { cleanup(); return otg_fail(nullptr, OTG_ERR_ARG, "otg_genotype_files: the writer failed"); }
+    st.output_bytes += hdr.size();
+  }
+  const uint32_t per = job->batch_regions ? job->batch_regions : 1024u;
+  const int threads = job->threads > 0 ? job->threads : 1;
+  std::vector<uint8_t> arena; std::vector<otg_allele> alleles; std::vector<uint32_t> first;
+  std::vector<uint64_t> seq_off; std::vector<uint32_t> seq_len, n_al;
+  std::vector<int32_t> gt, gtl, gtk, ngt, reps; std::vector<double> hsd;
+  std::string text;
+  for (uint32_t f = 0; f < (uint32_t)beds.size(); f += per) {
+    const uint32_t n = std::min<uint32_t>(per, (uint32_t)beds.size() - f);
+    first.assign((size_t)n + 1, 0);
+    size_t cap_al = std::max<size_t>(alleles.size(), (size_t)n * 128 + 64), cap_ar = std::max<size_t>(arena.size(), (size_t)n * 128 * 4096 + 4096);
+    uint32_t na = 0; uint64_t used = 0;
+    auto t0 = Clock::now();
+    for (int attempt = 0; attempt < 4; ++attempt) {
+      alleles.resize(cap_al); arena.resize(cap_ar);
+      na = 0; used = 0;
+      rc = otg_ingest_alleles(bam, beds.data() + f, chr_arena.data(), n, threads, fasta, arena.data(), arena.size(), &used, alleles.data(), (uint32_t)alleles.size(), &na, first.data());
+      if (rc != OTG_ERR_CAPACITY) break;
+      cap_al = (size_t)na + 64; cap_ar = (size_t)used + 4096;
+    }
+    if (rc != OTG_OK) { cleanup(); return rc; }
+    st.ms_ingest += ms_since(t0); st.n_reads += na; st.input_bytes += used;
+    uint64_t need = 0;
+    if (with_ref) {
+      t0 = Clock::now();
+      seq_off.resize(na); seq_len.resize(na); n_al.resize(n);
+      for (uint32_t i = 0; i < na; ++i) { seq_off[i] = alleles[i].seq_off; seq_len[i] = alleles[i].seq_len; }
+      for (uint32_t r = 0; r < n; ++r) n_al[r] = first[r + 1] - first[r];
+      gt.resize((size_t)na + 1); gtl.resize((size_t)na + 1); gtk.resize((size_t)na + 1); reps.resize((size_t)na + 1); hsd.resize((size_t)na + 1); ngt.resize((size_t)n + 1);
+      if (arena.size() < used + 64) arena.resize(used + 64);
+      if (na) {
+        rc = otg_genotype_cluster_batch(ctx, &job->params, arena.data(), used + 64, seq_off.data(), seq_len.data(), first.data(), n_al.data(), n,
+                                        gt.data(), gtl.data(), gtk.data(), hsd.data(), ngt.data(), reps.data());      // anallele_cluster (src/genotype.cpp:138)
+        if (rc != OTG_OK) { const std::string e = otg_last_error(ctx) ? otg_last_error(ctx) : ""; cleanup(); return otg_fail(nullptr, rc, "otg_genotype_files: %s", e.c_str()); }
+      } else std::fill(ngt.begin(), ngt.end(), 0);
+      st.ms_hot_path += ms_since(t0);
+      t0 = Clock::now();
+      rc = otg_emit_vcf_lines(beds.data() + f, chr_arena.data(), n, first.data(), alleles.data(), arena.data(), n_samples, gt.data(), hsd.data(), ngt.data(), reps.data(), ol, orr, nullptr, 0, &need);
+      if (rc != OTG_OK && rc != OTG_ERR_CAPACITY) { cleanup(); return rc; }
+      text.resize(need);
+      rc = otg_emit_vcf_lines(beds.data() + f, chr_arena.data(), n, first.data(), alleles.data(), arena.data(), n_samples, gt.data(), hsd.data(), ngt.data(), reps.data(), ol, orr,
+                              need ? &text[0] : nullptr, need, &need);
+    } else {
+      t0 = Clock::now();
+      rc = otg_emit_genotype_lengths(bam, beds.data() + f, chr_arena.data(), n, first.data(), alleles.data(), n_samples, nullptr, 0, &need);   // src/genotype.cpp:112-121
+      if (rc != OTG_OK && rc != OTG_ERR_CAPACITY) { cleanup(); return rc; }
+      text.resize(need);
+      rc = otg_emit_genotype_lengths(bam, beds.data() + f, chr_arena.data(), n, first.data(), alleles.data(), n_samples, need ? &text[0] : nullptr, need, &need);
+    }
+    if (rc != OTG_OK) { cleanup(); return rc; }
+    st.ms_emit += ms_since(t0);
+    for (uint32_t r = 0; r < n; ++r) { if (first[r + 1] > first[r]) ++st.n_regions_ok; }
+    st.n_alleles += na;
+    if (!text.empty() && write(user, text.data(), text.size()) != 0) { cleanup(); return otg_fail(nullptr, OTG_ERR_ARG, "otg_genotype_files: the writer failed"); }
+    st.output_bytes += text.size();
+  }
+  cleanup();
+  st.ms_total = ms_since(t_all); st.n_devices = 1;
+  if (stats) *stats = st;
+  return OTG_OK;
+}
+
 void otg_assemble_files_release(void)
 {
   std::lock_guard<std::mutex> lk(g_pool_m);

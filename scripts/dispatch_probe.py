@@ -16,8 +16,8 @@ tmp = tempfile.mkdtemp(prefix="otg_dp_")
 t0 = time.perf_counter()
 fx = bamwrite.make_tr_fixture(tmp, R, depth=30, len_range=(1000, 5000), seed=7)
 print("fixture: %d loci in %.0f s" % (R, time.perf_counter() - t0), flush=True)
-for batch in (250, 500, 1000):
-    for nctx in (1, 2, 3, 4):
+for batch in (int(b) for b in os.environ.get("OTG_PROBE_BATCHES", "250,500,1000").split(",")):
+    for nctx in (int(c) for c in os.environ.get("OTG_PROBE_CONTEXTS", "1,2,3,4").split(",")):
         os.environ["OTG_DISPATCH_CONTEXTS"] = str(nctx)
         best = None
         for rep in range(3):

@@ -264,3 +264,16 @@ def test_genotype_chain_bam_to_vcf_gpu_vs_oracle(gpu, oracle, tmp_path):
     exp = oracle.emit_vcf_header(bam.targets(), samples) + oracle.emit_vcf_lines(beds, carena, ref_blk, len(samples), ogt, ohsd, ongt, oreps, ol, orr)
     assert got == exp
     assert got.count(b"\n") == 13 + int((np.diff(blk["first_allele"].astype(np.int64)) > 0).sum())
+    # the one-call dispatcher (genotype() / genotype_process(), src/genotype.cpp:69-192): same text whatever the batch size; and the
+    # two-length table the reference prints without -r (src/genotype.cpp:112-121)
+    bed_path = str(tmp_path / "r.bed")
+    with open(bed_path, "w") as f:
+        for c, s_, e_ in regions:
+            f.write("%s\t%d\t%d\n" % (c, s_, e_))
+    for batch in (0, 7):
+        text, st = otter_amd.genotype_files(bam_path, bed_path, fasta=fa_path, threads=3, batch_regions=batch)
+        assert text == got, batch
+        assert st["n_regions"] == len(regions) and st["n_alleles"] == len(blk["alleles"])
+    blk0 = bam.ingest_alleles((beds, carena), reference=None, threads=2)
+    table, _ = otter_amd.genotype_files(bam_path, bed_path, fasta=None, threads=2, batch_regions=9)
+    assert table == otter_amd.emit_genotype_lengths(bam, beds, carena, blk0, len(samples)) and table.count(b"\n") > 10
