@@ -8,7 +8,7 @@ REG=${2:-}
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_bench_c$CFG
 rm -rf $OUT; mkdir -p $OUT
-ARGS="--config $CFG --steps 1 --warmup 0 --no-cpu-baseline --e2e-regions 0"
+ARGS="--config $CFG --steps 1 --warmup 0 --no-cpu-baseline --e2e-regions 0 --no-legs"
 if [ -n "$REG" ]; then ARGS="$ARGS --regions $REG"; fi
 i=0
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS" \

@@ -22,7 +22,7 @@ from otter_amd import synth  # noqa: E402
 
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 regions = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2] else (synth.CONFIGS[cfg]["n_regions"] // 8 if cfg == 4 else synth.CONFIGS[cfg]["n_regions"])
-tag = sys.argv[3] if len(sys.argv) > 3 else "r02"
+tag = sys.argv[3] if len(sys.argv) > 3 else "r03"
 src = os.path.join(ROOT, "gpurun_out", "pmc_bench_c%d" % cfg)
 
 
@@ -42,7 +42,7 @@ for f in glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive
 
 
 def group_of(k):
-    if "affine" in k or k.startswith("K_asort") or k.startswith("K_apart"):
+    if "affine" in k or k.startswith("K_tsort") or k.startswith("K_seg_copy"):
         return "wfa_affine_kernel"
     if "edit" in k or k.startswith("K_sort"):
         return "wfa_edit_kernel"
@@ -95,9 +95,20 @@ def n_of(name, default):
     return default
 chain_launches = {"wfa_edit_kernel": n_of("edit_route_kernel", 2), "wfa_affine_kernel": n_of("wfa_affine_bound1_kernel", 1), "poa": n_of("poa_count_kernel", 1),
                   "cluster": n_of("cluster_kernel", 1)}
+# cells the exact gap-affine tiers visited per chain launch: the device counter in the bench line of the profiled process (pass 1)
+visited = None
+try:
+    for ln in open(os.path.join(src, "p1.log")):
+        if ln.startswith("{") and '"roofline"' in ln:
+            visited = json.loads(ln)["roofline"].get("affine_visited_cells")
+except Exception:
+    pass
 physical, traffic = {}, {}
 for g, c in groups.items():
     d = derive(c, chain_launches[g])
+    if g == "wfa_affine_kernel" and visited and d.get("valu_insts"):
+        d["visited_cells_per_launch"] = visited
+        d["valu_insts_per_visited_cell"] = round(d["valu_insts"] / (float(visited) * chain_launches[g]), 4)
     d["bound"] = "valu"
     d["frac"] = d.get("valu_busy")
     d["what"] = "share of the chip's VALU issue slots (1024 SIMDs x kernel cycles) the chain's kernels used, summed over its kernels"
@@ -108,7 +119,7 @@ path = os.path.join(ROOT, "profiles", "pmc_summary.json")
 allc = json.load(open(path)) if os.path.exists(path) else {}
 allc["config%d" % cfg] = {
     "regions": regions, "workload": synth.config_workload(cfg, regions),
-    "source": "profiles/%s_pmc_c%d/ (rocprofv3 --kernel-trace --pmc <set> -- python3 bench.py --config %d --steps 1 --warmup 0 --no-cpu-baseline; scripts/pmc_bench.sh, scripts/pmc_summarize.py)" % (tag, cfg, cfg),
+    "source": "profiles/%s_pmc_c%d/ (scripts/pmc_bench.sh: rocprofv3 --kernel-trace --pmc <set> over bench.py --config %d --steps 1 --warmup 0)" % (tag, cfg, cfg),
     "traffic_bytes_per_launch": traffic, "physical": physical, "kernels": kernels}
 json.dump(allc, open(path, "w"), indent=1, sort_keys=True)
 dst = os.path.join(ROOT, "profiles", "%s_pmc_c%d" % (tag, cfg))
