@@ -34,7 +34,13 @@ def short(n):
 
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 launches = collections.defaultdict(lambda: collections.defaultdict(int))
+# gpurun merges a call's files into gpurun_out/ without removing those of earlier calls: one file per pass, the newest
+newest = {}
 for f in glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True):
+    p = os.path.relpath(f, src).split(os.sep)[0]
+    if p not in newest or os.path.getmtime(f) > os.path.getmtime(newest[p]):
+        newest[p] = f
+for f in newest.values():
     for r in csv.DictReader(open(f)):
         k = short(r["Kernel_Name"])
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
