@@ -43,7 +43,7 @@ def build(force=False, verbose=False, jobs=4):
         headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc"))] + [os.path.join(HERE, "..", "include", "otter_gpu.h")]
         if (not force) and os.path.exists(obj) and os.path.getmtime(obj) > max([os.path.getmtime(path)] + [os.path.getmtime(h) for h in headers]):
             continue
-        cmd = [cc] + FLAGS + ["-c", path, "-o", obj]
+        cmd = [cc] + FLAGS + os.environ.get("OTG_EXTRA_HIPCC_FLAGS", "").split() + ["-c", path, "-o", obj]      # (measurement builds: -DOTG_REG_TIMING, ...)
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -1048,6 +1048,13 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
     HIP_TRY(ctx, hipMemcpy(h5, cnt + 64, sizeof(h5), hipMemcpyDeviceToHost));
     fprintf(stderr, "[otg] affine: register tiers take %u / %u / %u / %u / %u alignments, %u go to the HBM-row tiers (of which given up by a register tier: %u); tier A gives up %u, tier B %u\n",
             h5[1] - h5[0], h5[2] - h5[1], h5[3] - h5[2], h5[4] - h5[3], h5[5] - h5[4], h5[7], h5[7] - (h5[6] - h5[5]), h[9], h[11]);
+#ifdef OTG_REG_TIMING
+    unsigned long long tm[7];
+    HIP_TRY(ctx, hipMemcpy(tm, cnt + 100, sizeof(tm), hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemsetAsync(cnt + 100, 0, sizeof(tm), ctx->stream));
+    if (tm[5]) fprintf(stderr, "[otg] register tiers, clock ticks per wave and score: preamble %.0f sweep %.0f (%.2f slot visits) drain+fold %.0f exports %.0f barrier %.0f; %llu wave-scores\n",
+                       (double)tm[0] / tm[5], (double)tm[1] / tm[5], (double)tm[6] / tm[5], (double)tm[2] / tm[5], (double)tm[3] / tm[5], (double)tm[4] / tm[5], tm[5]);
+#endif
   }
   if (kernel_ms) {
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));

@@ -64,6 +64,7 @@ __device__ __forceinline__ uint32_t pk_ne01_u16(uint32_t a, uint32_t b)
   return r;
 }
 __device__ __forceinline__ void opaque_v(int& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void opaque_v(uint32_t& x) { asm volatile("" : "+v"(x)); }
 // In-place update of a loop-carried wavefront word.  Written as a plain assignment, the conditional slot visit leaves a phi per word at its join,
 // and the allocator resolves part of them with copies at the loop header (dozens of v_mov per score) and spills; tied to its register, a word
 // never moves.
@@ -82,7 +83,7 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t x)
 #define OTG_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
 
-template <int NW, int S2, int SEQB, int WPEU, int QCAP = 512>
+template <int NW, int S2, int SEQB, int WPEU, int QCAP = 512, int LB = 2>
 __global__ __launch_bounds__(NW == 1 ? 256 : NW * 64, WPEU) void wfa_affine_reg_kernel(
     const uint8_t* __restrict__ arena, const otg_align_task* __restrict__ tasks,
     const uint32_t* __restrict__ todo, const uint32_t* __restrict__ seg, int g,
@@ -104,8 +105,10 @@ __global__ __launch_bounds__(NW == 1 ? 256 : NW * 64, WPEU) void wfa_affine_reg_
   __shared__ uint32_t s_seq[ALN][SEQB / 4];
   __shared__ uint32_t s_patch[ALN][CAP / 2];
   __shared__ uint32_t s_queue[WAVES][QCAP];
-  __shared__ uint32_t s_xl[2][GS + 2], s_xr[2][GS + 2];     // [score parity][slot + 1]: X_I of a slot's lane 63 / X_D of its lane 0, for the next score
-  __shared__ int s_cand[2][WAVES];
+  // (NW > 1) what the waves hand each other at the end of a score, double-buffered by score parity: [0, GS + 2) entry g + 1 = X_I of slot g's lane 63,
+  // [GS + 2, 2 GS + 4) entry g + 1 = X_D of slot g's lane 0, then one termination candidate per wave
+  constexpr int XROW = 2 * (GS + 2) + WAVES;
+  __shared__ uint32_t s_x[2 * XROW + 64];       // (+ 64: a row is read back by all 64 lanes)
   __shared__ int s_misc[4];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -115,9 +118,7 @@ __global__ __launch_bounds__(NW == 1 ? 256 : NW * 64, WPEU) void wfa_affine_reg_
   volatile lds_u32* PT = (volatile lds_u32*)&s_patch[al][0];
   volatile lds_u32* QU = (volatile lds_u32*)&s_queue[wv][0];
   volatile lds_u16* PT16 = (volatile lds_u16*)&s_patch[al][0];
-  volatile lds_u32* XL = (volatile lds_u32*)&s_xl[0][0];
-  volatile lds_u32* XR = (volatile lds_u32*)&s_xr[0][0];
-  volatile __attribute__((address_space(3))) int* CA = (volatile __attribute__((address_space(3))) int*)&s_cand[0][0];
+  volatile lds_u32* XT = (volatile lds_u32*)&s_x[0];
   volatile __attribute__((address_space(3))) int* MISC = (volatile __attribute__((address_space(3))) int*)&s_misc[0];
   uint8_t* my = ws.base + (size_t)(blockIdx.x * ALN + al) * ws.stride;
   int64_t* rowtab = (int64_t*)(my + ws.off_rowtab);
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(NW == 1 ? 256 : NW * 64, WPEU) void wfa_affine_reg_
     }
     if (!fail) {
       for (int q = (NW == 1 ? lane : (int)threadIdx.x); q < CAP / 2; q += (NW == 1 ? 64 : NW * 64)) PT[q] = NN;
-      if (NW > 1) for (int q = (int)threadIdx.x; q < 2 * (GS + 2); q += NW * 64) { XL[q] = NN; XR[q] = NN; }
+      if (NW > 1) for (int q = (int)threadIdx.x; q < 2 * XROW; q += NW * 64) XT[q] = NN;
       bool bad = false;
       auto pack = [&](const uint8_t* S, int len, int woff) {
         for (int q = (NW == 1 ? lane : (int)threadIdx.x); q < (len + 15) / 16; q += (NW == 1 ? 64 : NW * 64)) {
@@ -195,6 +196,21 @@ __global__ __launch_bounds__(NW == 1 ? 256 : NW * 64, WPEU) void wfa_affine_reg_
       const uint32_t sh = (uint32_t)(pos & 15) * 2u;
       const uint32_t d0 = SQ[w], d1 = SQ[w + 1], d2 = SQ[w + 2];
       return (uint64_t)__builtin_amdgcn_alignbit(d1, d0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32);
+    };
+    // A probe in two halves: the three words of each sequence around a position are requested first — for BOTH cells of a lane before anything is
+    // combined, so a slot visit waits for LDS once, not four times in a row — and shifted into place after a scheduling fence.
+    struct Ld3 { uint32_t d0, d1, d2; };
+    auto ld3 = [&](int woff, int pos) -> Ld3 { const int w = woff + (pos >> 4); return Ld3{SQ[w], SQ[w + 1], SQ[w + 2]}; };
+    auto cat32 = [&](const Ld3& a, int pos) -> uint64_t {
+      const uint32_t sh = (uint32_t)(pos & 15) * 2u;
+      return (uint64_t)__builtin_amdgcn_alignbit(a.d1, a.d0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(a.d2, a.d1, sh) << 32);
+    };
+    auto probe_of = [&](const Ld3& p, int v, const Ld3& t, int h) -> int {
+      const uint64_t x = cat32(p, v) ^ cat32(t, h);
+      uint32_t flo, fhi;      // v_ffbl_b32: index of the lowest set bit, 0xffffffff for zero — which is what the min below wants
+      asm("v_ffbl_b32 %0, %1" : "=v"(flo) : "v"((uint32_t)x));
+      asm("v_ffbl_b32 %0, %1" : "=v"(fhi) : "v"((uint32_t)(x >> 32)));
+      return (int)(umin3(flo, fhi | 32u, 64u) >> 1);
     };
     // equal leading bases of pattern[v ..] and text[h ..], looking 32 bases ahead (32 = all equal); not limited by the sequence ends
     auto probe32 = [&](int v, int h) -> int {
@@ -235,14 +251,21 @@ __global__ __launch_bounds__(NW == 1 ? 256 : NW * 64, WPEU) void wfa_affine_reg_
     uint32_t M4[2][S2], M2[2][S2];     // [parity set][pair-slot] = {lo16: even diagonal, hi16: odd diagonal}; set 0 = the parity of the current score: M[s-4], M[s-2]
     uint32_t WI[S2], WD[S2];           // I[s-1], D[s-1]
     static_for<0, S2>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value;
-      M4[0][i] = NN; M2[0][i] = NN; M4[1][i] = NN; M2[1][i] = NN; WI[i] = NN; WD[i] = NN; });
+      M4[0][i] = NN; M2[0][i] = NN; M4[1][i] = NN; M2[1][i] = NN; WI[i] = NN; WD[i] = NN;
+      opaque_v(M4[0][i]); opaque_v(M2[0][i]); opaque_v(M4[1][i]); opaque_v(M2[1][i]); });     // vector registers from the start (the swaps at the loop top are tied to them)
     size_t slab_top = 0;
     int s_end = -1, k_end = 0;
     int r1lo = 1, r1hi = 0, r2lo = 1, r2hi = 0, r3lo = 1, r3hi = 0, r4lo = 1, r4hi = 0, idlo = 1, idhi = 0;
-    int ej0 = 1, ej1 = 0;                        // touched slots of the latest reachable score (the export tables follow them through unreachable scores)
+    uint32_t xlv = NN, xrv = NN;                 // (NW > 1) lane g: X_I of slot g - 1 / X_D of slot g + 1 as exported at the end of the previous score
     const int xe = kend - kbase;                 // window index of the end diagonal (end-to-end termination)
 
     int lane2 = 2 * lane, kb = __builtin_amdgcn_readfirstlane(kbase);
+#ifdef OTG_REG_TIMING   // where a wave's cycles go, per section of a score (s_memtime; sums over all waves land behind the visited-cell counter)
+    unsigned long long tm_pre = 0, tm_sweep = 0, tm_drain = 0, tm_exp = 0, tm_bar = 0, tm_n = 0, tm_vis = 0, tm_last = __builtin_amdgcn_s_memtime();
+#define OTG_TM(acc) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - tm_last; tm_last = now_; }
+#else
+#define OTG_TM(acc)
+#endif
     for (int s = 0; !fail; ++s) {
       if (s >= ws.nrows) { fail = true; break; }
       // opaque to the optimiser: per-slot expressions built on these are recomputed where they are used instead of being hoisted out of
@@ -277,7 +300,6 @@ __global__ __launch_bounds__(NW == 1 ? 256 : NW * 64, WPEU) void wfa_affine_reg_
       const int xlo = lo - kbase, xhi = hi - kbase;
       if (xlo < 2 || xhi + 3 >= CAP) { fail = true; break; }
       j0 = (xlo - 1) >> 7; j1 = (xhi + 1) >> 7;  // one diagonal of margin on both sides: a cell's provenance byte carries its neighbours' gap choices
-      ej0 = j0; ej1 = j1;
       const int width = (j1 - j0 + 1) * 128;
       if (slab_top + (size_t)width > ws.slab_bytes) { fail = true; break; }
       uint8_t* brow = slab + slab_top - 128 * j0;                  // provenance byte of window index x: brow[x]
@@ -356,6 +378,7 @@ __global__ __launch_bounds__(NW == 1 ? 256 : NW * 64, WPEU) void wfa_affine_reg_
       // end condition of a fully extended cell (ends-free form; the end-to-end form is checked on the one end diagonal)
       auto fin_ef = [&](int h, int v) -> bool { return h >= 0 && ((h >= tl && pl - v <= pef) || (v >= pl && tl - h <= tef)); };
 
+      OTG_TM(tm_pre);
       if (s == 0) {
         // score 0: offset max(k, 0) on every start diagonal, no I / D wavefronts; everything is extended through the queue
         static_for<0, S2>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value;
@@ -380,7 +403,6 @@ __global__ __launch_bounds__(NW == 1 ? 256 : NW * 64, WPEU) void wfa_affine_reg_
         // ---- the sweep over the touched pair-slots, ascending
         uint32_t carryI = NN;                     // X_I of lane 63 of the slot left of the current one, from before that slot's update (NW == 1)
         uint32_t XDc = NN;                        // X_D of the next slot, computed one visit ahead (NW == 1)
-        const int xp = (s & 1) * (GS + 2);        // this score's half of the export tables
         static_for<0, S2>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value;
           const int gi = NW == 1 ? i : i * NW + ww;
           if (NW == 1 && gi + 1 == j0)             // the slot left of the first touched one: its lane 63 is the left neighbour of the sweep
@@ -398,8 +420,8 @@ __global__ __launch_bounds__(NW == 1 ? 256 : NW * 64, WPEU) void wfa_affine_reg_
             if constexpr (i + 1 < S2) { XDc = pk_max_i16(M4[0][i + 1], WD[i + 1]); rcar = (uint32_t)__builtin_amdgcn_readlane((int)XDc, 0); }   // the next slot's lane 0, still old
           } else {
             XD = pk_max_i16(m4, wd);
-            lcar = (uint32_t)__builtin_amdgcn_readfirstlane((int)XL[xp + gi]);             // slot gi - 1 (entry g + 1 holds slot g)
-            rcar = (uint32_t)__builtin_amdgcn_readfirstlane((int)XR[xp + gi + 2]);         // slot gi + 1
+            lcar = (uint32_t)__builtin_amdgcn_readlane((int)xlv, gi);                       // slot gi - 1
+            rcar = (uint32_t)__builtin_amdgcn_readlane((int)xrv, gi);                       // slot gi + 1
           }
           const uint32_t XIl = (uint32_t)__builtin_amdgcn_update_dpp((int)lcar, (int)XI, 0x138, 0xf, 0xf, false);   // lane l <- lane l-1, lane 0 <- the left slot
           const uint32_t XDr = (uint32_t)__builtin_amdgcn_update_dpp((int)rcar, (int)XD, 0x130, 0xf, 0xf, false);   // lane l <- lane l+1, lane 63 <- the right slot
@@ -427,11 +449,28 @@ __global__ __launch_bounds__(NW == 1 ? 256 : NW * 64, WPEU) void wfa_affine_reg_
           // the block's allocation, where reads return zero — and its result is dropped by the `valid` selects below; a valid cell at an end of
           // a sequence gets m = 0 from the remaining lengths.  No clamps, no gating of the probe itself.
           const int rvE = pl - vE, rhE = tl - hE, rvO = pl - vO, rhO = tl - hO;
-          OTG_SCHED_FENCE();
-          const int mE = imin(probe32(vE, hE), imin(rvE, rhE));
-          OTG_SCHED_FENCE();
-          const int mO = imin(probe32(vO, hO), imin(rvO, rhO));
-          OTG_SCHED_FENCE();
+          // LB = how many of the lane's two probes have their LDS requests in flight together: 2 = both (one wait per slot visit; twelve more live
+          // registers), 1 = one probe at a time (two waits), 0 = pattern and text one after the other (four)
+          int mE, mO;
+          if constexpr (LB == 2) {
+            const Ld3 pE = ld3(0, vE), tE = ld3(offT, hE), pO = ld3(0, vO), tO = ld3(offT, hO);
+            OTG_SCHED_FENCE();
+            mE = imin(probe_of(pE, vE, tE, hE), imin(rvE, rhE));
+            mO = imin(probe_of(pO, vO, tO, hO), imin(rvO, rhO));
+            OTG_SCHED_FENCE();
+          } else if constexpr (LB == 1) {
+            OTG_SCHED_FENCE();
+            { const Ld3 pE = ld3(0, vE), tE = ld3(offT, hE); OTG_SCHED_FENCE(); mE = imin(probe_of(pE, vE, tE, hE), imin(rvE, rhE)); }
+            OTG_SCHED_FENCE();
+            { const Ld3 pO = ld3(0, vO), tO = ld3(offT, hO); OTG_SCHED_FENCE(); mO = imin(probe_of(pO, vO, tO, hO), imin(rvO, rhO)); }
+            OTG_SCHED_FENCE();
+          } else {
+            OTG_SCHED_FENCE();
+            mE = imin(probe32(vE, hE), imin(rvE, rhE));
+            OTG_SCHED_FENCE();
+            mO = imin(probe32(vO, hO), imin(rvO, rhO));
+            OTG_SCHED_FENCE();
+          }
           hE += mE; hO += mO;
           bool moreE = validE && mE == 32 && rvE > 32 && rhE > 32, moreO = validO && mO == 32 && rvO > 32 && rhO > 32;
           // a second probe where a run outlives the first (one in 120 cells at ONT divergence, i.e. most slot visits have one): the queue, its
@@ -443,7 +482,9 @@ __global__ __launch_bounds__(NW == 1 ? 256 : NW * 64, WPEU) void wfa_affine_reg_
             const int h2 = selO ? hO : hE;
             const int v2 = h2 - (selO ? kE + 1 : kE);
             const int rv2 = pl - v2, rh2 = tl - h2;
-            const int m2nd = imin(probe32(v2, h2), imin(rv2, rh2));
+            int m2nd;
+            if constexpr (LB > 0) { const Ld3 p2 = ld3(0, v2), t2 = ld3(offT, h2); OTG_SCHED_FENCE(); m2nd = imin(probe_of(p2, v2, t2, h2), imin(rv2, rh2)); }
+            else m2nd = imin(probe32(v2, h2), imin(rv2, rh2));
             const bool more2 = m2nd == 32 && rv2 > 32 && rh2 > 32;
             if (selO) { hO += m2nd; moreO = more2; }
             else if (moreE) { hE += m2nd; moreE = more2; }
@@ -461,6 +502,10 @@ __global__ __launch_bounds__(NW == 1 ? 256 : NW * 64, WPEU) void wfa_affine_reg_
           if (__ballot(moreE || moreO)) push2(moreE, moreO, xE, hE, hO);
         });
       }
+      OTG_TM(tm_sweep);
+#ifdef OTG_REG_TIMING
+      tm_n += 1; tm_vis += (unsigned long long)(NW == 1 ? (j1 - j0 + 1) : ((j1 - ww + NW) / NW - (j0 - ww + NW - 1) / NW));
+#endif
       if (qfull) cand = FAILV;
       else if (pushed) {
         drain();
@@ -477,35 +522,50 @@ __global__ __launch_bounds__(NW == 1 ? 256 : NW * 64, WPEU) void wfa_affine_reg_
         });
       }
       idlo = s == 0 ? 1 : lo; idhi = s == 0 ? 0 : hi;
+      OTG_TM(tm_drain);
       }
       // ---- close the score: (NW > 1) publish what the neighbouring slots need for score s + 1 — X_I / X_D from the M[s-3] of the OTHER parity
       // set, which is the current one of the next score, and the I / D words just written — and this wave's candidate; one barrier; then every
       // wave sees every candidate
       cand = __builtin_amdgcn_readfirstlane(cand);
       if (NW > 1) {
-        const int np = ((s + 1) & 1) * (GS + 2);
-        static_for<0, S2>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value;
-          const int gi = i * NW + ww;
-          if (gi + 3 < ej0 || gi > ej1 + 3) return;          // the range moves by at most one diagonal per score (ej: also through unreachable scores)
-          const uint32_t xi = pk_max_i16(M4[1][i], WI[i]), xd = pk_max_i16(M4[1][i], WD[i]);
-          if (lane == 63) XL[np + gi + 1] = xi;
-          if (lane == 0) XR[np + gi + 1] = xd;
-        });
-        if (lane == 0) CA[(s & 1) * WAVES + ww] = cand;
+        // Every slot is exported, touched or not (a slot's X words change with the score parity even while it rests), by its two edge lanes under ONE
+        // execution mask; after the barrier one row read per table serves all slot visits of the next score and one more the candidates.  (Written slot
+        // by slot with a lane test and a range test each, and read back one word per slot visit, this section took a fifth of the four-wave tier's time.)
+        const int np = ((s + 1) & 1) * XROW;
+        if (lane == 0 || lane == 63) {
+          volatile lds_u32* dst = XT + np + (lane == 63 ? 0 : GS + 2) + ww + 1;
+          static_for<0, S2>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value;
+            dst[i * NW] = pk_max_i16(M4[1][i], lane == 63 ? WI[i] : WD[i]); });
+          if (lane == 0) XT[np + 2 * (GS + 2) + ww] = (uint32_t)cand;
+        }
+        OTG_TM(tm_exp);
         __syncthreads();
+        xlv = XT[np + lane];                      // entry g = slot g - 1
+        xrv = XT[np + GS + 4 + lane];             // entry GS + 2 + g + 2 = slot g + 1
+        const int cv = (int)XT[np + 2 * (GS + 2) + (lane & (WAVES - 1))];
         int gc = NOCAND;
 #pragma unroll
-        for (int w2 = 0; w2 < NW; ++w2) { const int c2 = CA[(s & 1) * WAVES + w2]; gc = c2 < gc ? c2 : gc; }
+        for (int w2 = 0; w2 < NW; ++w2) { const int c2 = __builtin_amdgcn_readlane(cv, w2); gc = c2 < gc ? c2 : gc; }
         cand = __builtin_amdgcn_readfirstlane(gc);
+        OTG_TM(tm_bar);
       }
-      if (cand == FAILV) { fail = true; break; }
-      if (cand != NOCAND) { s_end = s; k_end = cand; break; }
-      // the other parity is next
+      if (cand == FAILV) fail = true;
+      else if (cand != NOCAND) { s_end = s; k_end = cand; }
+      // the other parity is next.  Unconditional, also in the last pass: with the two exits above in front of them the same sixteen swaps came
+      // wrapped in a copy of the whole state out of its registers and back (80 instructions per score)
       static_for<0, S2>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value;
         vswap(M4[0][i], M4[1][i]);
         vswap(M2[0][i], M2[1][i]); });
+      if (s_end >= 0) break;
     }
 
+#ifdef OTG_REG_TIMING
+    if (visited && lane == 0) {
+      atomicAdd(visited + 2, tm_pre); atomicAdd(visited + 3, tm_sweep); atomicAdd(visited + 4, tm_drain); atomicAdd(visited + 5, tm_exp);
+      atomicAdd(visited + 6, tm_bar); atomicAdd(visited + 7, tm_n); atomicAdd(visited + 8, tm_vis);
+    }
+#endif
     if (NW > 1 && wv != 0) continue;           // wave 0 reports / unpacks; the others wait at the next ticket barrier
     if (fail || s_end < 0) {
       const uint32_t q = otg_wave_atomic_add(n_overflow, 1u);
@@ -527,15 +587,15 @@ void otg_affine_reg_geometry(int tier, int shape, int* aln_per_block, int* block
   int a = 4, b = 4;
   switch (tier * 10 + shape) {
     case 0: a = 4; b = 4; break;        // <1,8>   16 waves per CU
-    case 1: a = 4; b = 5; break;        // <1,8>   20 (spills, half the match-run queue)
-    case 10: a = 4; b = 4; break;       // <1,12>  16
-    case 11: a = 4; b = 3; break;       // <1,12>  12 (no spills)
+    case 1: a = 1; b = 10; break;       // <2,4>   20
+    case 10: a = 4; b = 3; break;       // <1,12>  12 (no spills)
+    case 11: a = 4; b = 4; break;       // <1,12>  16 (32 spilled registers)
     case 12: a = 1; b = 8; break;       // <2,6>   16
-    case 20: a = 4; b = 3; break;       // <1,16>  12
-    case 21: a = 4; b = 2; break;       // <1,16>  8 (no spills)
-    case 22: a = 1; b = 8; break;       // <2,8>   16
-    case 23: a = 1; b = 4; break;       // <4,4>   16
+    case 20: a = 1; b = 8; break;       // <2,8>   16
+    case 21: a = 4; b = 3; break;       // <1,16>  12 (32 spilled registers)
+    case 22: a = 4; b = 2; break;       // <1,16>  8 (no spills)
     case 30: a = 1; b = 4; break;       // <4,8>   16
+    case 31: a = 1; b = 3; break;       // <8,4>   24
     case 40: a = 1; b = 2; break;       // <8,8>   16
     default: break;
   }
@@ -548,22 +608,23 @@ int otg_launch_affine_reg_tier(otg_ctx* ctx, int tier, int shape, uint32_t block
                                uint32_t* d_cig_len, uint8_t* d_cig_arena, uint64_t* d_cells, uint32_t* ticket, uint32_t* n_overflow,
                                uint32_t* overflow_list, const AffWs& ws, const int32_t* d_bound, unsigned long long* visited)
 {
-#define OTG_REG_LAUNCH(NWV, S2V, SEQV, WPEUV)                                                                                                   \
-  hipLaunchKernelGGL((wfa_affine_reg_kernel<NWV, S2V, SEQV, WPEUV>), dim3(blocks), dim3(NWV == 1 ? 256 : NWV * 64), 0, ctx->stream, d_arena, d_tasks, \
-                     d_sorted, d_seg, g, d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, ticket, n_overflow, overflow_list, ws, d_bound, visited)
+#define OTG_REG_LAUNCH(NWV, S2V, SEQV, WPEUV, ...)                                                                                              \
+  hipLaunchKernelGGL((wfa_affine_reg_kernel<NWV, S2V, SEQV, WPEUV, ##__VA_ARGS__>), dim3(blocks), dim3(NWV == 1 ? 256 : NWV * 64), 0, ctx->stream, d_arena, \
+                     d_tasks, d_sorted, d_seg, g, d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, ticket, n_overflow, overflow_list, ws, d_bound, visited)
   switch (tier * 10 + shape) {
     case 0: OTG_REG_LAUNCH(1, 8, 4096, 4); break;
-    case 1: hipLaunchKernelGGL((wfa_affine_reg_kernel<1, 8, 4096, 5, 256>), dim3(blocks), dim3(256), 0, ctx->stream, d_arena, d_tasks, d_sorted, d_seg, g, d_scores, d_cig_off,
-                               d_cig_len, d_cig_arena, d_cells, ticket, n_overflow, overflow_list, ws, d_bound, visited); break;
-    case 10: OTG_REG_LAUNCH(1, 12, 4608, 4); break;
-    case 11: OTG_REG_LAUNCH(1, 12, 4608, 3); break;
-    case 12: OTG_REG_LAUNCH(2, 6, 4608, 4); break;
-    case 20: OTG_REG_LAUNCH(1, 16, 6144, 3); break;
-    case 21: OTG_REG_LAUNCH(1, 16, 6144, 2); break;
-    case 22: OTG_REG_LAUNCH(2, 8, 6144, 4); break;
-    case 23: OTG_REG_LAUNCH(4, 4, 6144, 4); break;
     case 30: OTG_REG_LAUNCH(4, 8, 8192, 4); break;
+#ifndef OTG_REG_PROBE       // (a compile-time probe of the two main bodies: -DOTG_REG_PROBE)
+    case 1: OTG_REG_LAUNCH(2, 4, 4096, 5, 256); break;
+    case 10: OTG_REG_LAUNCH(1, 12, 4608, 3); break;
+    case 11: OTG_REG_LAUNCH(1, 12, 4608, 4, 512, 0); break;
+    case 12: OTG_REG_LAUNCH(2, 6, 4608, 4); break;
+    case 20: OTG_REG_LAUNCH(2, 8, 6144, 4); break;
+    case 21: OTG_REG_LAUNCH(1, 16, 6144, 3, 512, 1); break;
+    case 22: OTG_REG_LAUNCH(1, 16, 6144, 2); break;
+    case 31: OTG_REG_LAUNCH(8, 4, 8192, 6, 256); break;
     case 40: OTG_REG_LAUNCH(8, 8, 12288, 4); break;
+#endif
     default: return otg_fail(ctx, OTG_ERR_ARG, "no register tier %d shape %d", tier, shape);
   }
 #undef OTG_REG_LAUNCH
