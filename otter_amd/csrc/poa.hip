@@ -155,8 +155,9 @@ template <bool LDS> __device__ __forceinline__ void poa_phase_fence()
 using lds_u32 = __attribute__((address_space(3))) uint32_t;
 using lds_i32 = __attribute__((address_space(3))) int32_t;
 using lds_f32 = __attribute__((address_space(3))) float;
-struct PoaScratch {          // per-wave LDS of the second-generation path (2.3 KB)
-  volatile lds_u32* ops;     // [256] the chunk's ops: op | target base << 8
+constexpr int POA_WK = 8;     // ops per lane in a wide chunk of the threading (64 * POA_WK ops, at most 64 runs)
+struct PoaScratch {          // per-wave LDS of the second-generation path (3.3 KB)
+  volatile lds_u32* ops;     // [64 * POA_WK] the chunk's ops: op | target base << 8
   volatile lds_u32* stage;   // [64]  edge ids of the block being swept
   volatile lds_f32* hw;      // [128] window of backbone weights ...
   volatile lds_i32* pred;    // [128] ... and their sources (circular: node v at v & 127)
@@ -209,6 +210,7 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
   auto nbase = S.nbase; auto isend = S.isend; auto bbc = S.bbc; auto queue = S.queue; auto starts = S.starts;
   const int B = (int)G.backbone_len;
   const bool V2 = !LDS && v2_in && B >= 2;
+  constexpr int WK = POA_WK;
   // V2: a stretch of plain 'M' ops raises the counts of a RANGE of backbone edges by one; the lane-parallel threading only marks the two
   // ends of each stretch (+1 / -1, atomics without a return value) and one prefix sum after the last member turns the marks into counts
   int* bdiff = (int*)(void*)&queue[0];
@@ -410,31 +412,33 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
         }
         cn_id = 0xffffffffu;
     };
-    int pre_ci = -1; int pre_cc[4] = {0, 0, 0, 0};      // V2: ops read ahead for the chunk that starts at pre_ci
+    int pre_ci = -1; int pre_cc[WK];
+#pragma unroll
+    for (int k = 0; k < WK; ++k) pre_cc[k] = 0;      // V2: ops read ahead for the chunk that starts at pre_ci
     int lastop = 0;                    // op just before position ci in the main phase (0 = none)
     while (ci < clen && !status) {
       const int i = ci + lane;
       const int rem = clen - ci;
       if (V2 && lastop == 'M' && !first && rem > 64) {
-        // ---- wide chunk: four ops per lane (up to 256 ops; cut after the last 'M' like the narrow chunk below).  The round trips of a chunk
+        // ---- wide chunk: WK ops per lane (up to 64 * WK ops; cut after the last 'M' like the narrow chunk below).  The round trips of a chunk
         // (ops, target bases, backbone counts, the runs' subtrees) are what the threading waits for, so fewer, fuller chunks; more than 64
-        // runs in 256 ops (a member that disagrees with the backbone everywhere) or anything irregular leaves the chunk to the narrow code
-        const int rem4 = rem < 256 ? rem : 256;
-        const int o0 = 4 * lane;
-        int cc[4];
+        // runs in the chunk (a member that disagrees with the backbone everywhere) or anything irregular leaves the chunk to the narrow code
+        const int rem4 = rem < 64 * WK ? rem : 64 * WK;
+        const int o0 = WK * lane;
+        int cc[WK];
         if (pre_ci == ci) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) cc[k] = o0 + k < rem4 ? pre_cc[k] : 0;
+          for (int k = 0; k < WK; ++k) cc[k] = o0 + k < rem4 ? pre_cc[k] : 0;
         } else {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) cc[k] = o0 + k < rem4 ? (int)cig[ci + o0 + k] : 0;
+          for (int k = 0; k < WK; ++k) cc[k] = o0 + k < rem4 ? (int)cig[ci + o0 + k] : 0;
         }
         bool wide_ok = true;
         int nv = rem4;
-        if (rem > 256) {
+        if (rem > 64 * WK) {
           int lm = -1;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) if (cc[k] == 'M') lm = o0 + k;
+          for (int k = 0; k < WK; ++k) if (cc[k] == 'M') lm = o0 + k;
           lm = otg_wave_max_i32(lm);
           if (lm < 0) wide_ok = false; else nv = lm + 1;
         }
@@ -443,10 +447,10 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
           // this one then overlaps with the rest of this chunk
           pre_ci = ci + nv;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) pre_cc[k] = pre_ci + o0 + k < clen ? (int)cig[pre_ci + o0 + k] : 0;
+          for (int k = 0; k < WK; ++k) pre_cc[k] = pre_ci + o0 + k < clen ? (int)cig[pre_ci + o0 + k] : 0;
           uint32_t nref = 0, ntgt = 0;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
+          for (int k = 0; k < WK; ++k) {
             const bool v = o0 + k < nv;
             const int c4 = cc[k];
             nref += (v && (c4 == 'M' || c4 == 'X' || c4 == 'D')) ? 1u : 0u;
@@ -454,13 +458,13 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
           }
           uint32_t totr = 0, tott = 0, totl = 0;
           int ra = ref_i + (int)poa_wave_excl_sum(nref, lane, &totr), ta = tgt + (int)poa_wave_excl_sum(ntgt, lane, &tott);
-          int pcur = __shfl_up(cc[3], 1);
+          int pcur = __shfl_up(cc[WK - 1], 1);
           if (lane == 0) pcur = 'M';
-          int refk[4], tgtk[4]; bool simk[4], leadk[4];
+          int refk[WK], tgtk[WK]; bool simk[WK], leadk[WK];
           bool irregular = false;
           uint32_t nl = 0;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
+          for (int k = 0; k < WK; ++k) {
             const bool v = o0 + k < nv;
             const int c4 = cc[k];
             const bool m = c4 == 'M', x = c4 == 'X', d = c4 == 'D', in = c4 == 'I';
@@ -475,16 +479,16 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
           if (__ballot(irregular) || totl > 64u) wide_ok = false;
           if (wide_ok) {
             // every load of the chunk head first (backbone counts of the plain 'M' ops, target bases), then the stores: one round trip
-            int tbv[4];
+            int tbv[WK];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) tbv[k] = (o0 + k < nv && (cc[k] == 'X' || cc[k] == 'I')) ? (int)seq[tgtk[k]] : 0;
+            for (int k = 0; k < WK; ++k) tbv[k] = (o0 + k < nv && (cc[k] == 'X' || cc[k] == 'I')) ? (int)seq[tgtk[k]] : 0;
             {
-              const unsigned long long s3 = __ballot(simk[3]), s0 = __ballot(simk[0]);
+              const unsigned long long s3 = __ballot(simk[WK - 1]), s0 = __ballot(simk[0]);
               const bool prev_s = lane > 0 && ((s3 >> (lane - 1)) & 1ull), next_s = lane < 63 && ((s0 >> (lane + 1)) & 1ull);
 #pragma unroll
-              for (int k = 0; k < 4; ++k) {
+              for (int k = 0; k < WK; ++k) {
                 if (simk[k]) {
-                  const bool ps = k > 0 ? simk[k > 0 ? k - 1 : 0] : prev_s, ns = k < 3 ? simk[k < 3 ? k + 1 : 3] : next_s;
+                  const bool ps = k > 0 ? simk[k > 0 ? k - 1 : 0] : prev_s, ns = k < WK - 1 ? simk[k < WK - 1 ? k + 1 : WK - 1] : next_s;
                   if (!ps) atomicAdd(&bdiff[refk[k] - 1], 1);
                   if (!ns) atomicAdd(&bdiff[refk[k]], -1);
                   if (B - (refk[k] + 1) <= 10 && spr && (uint32_t)refk[k] < node_cap) isend[refk[k]] = 1;
@@ -492,14 +496,14 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
               }
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < WK; ++k) {
               if (o0 + k < nv) L.ops[o0 + k] = (uint32_t)cc[k] | ((uint32_t)tbv[k] << 8);
-              if (leadk[k]) { L.stage[li] = (uint32_t)(o0 + k) | ((uint32_t)refk[k] << 8); ++li; }
+              if (leadk[k]) { L.stage[li] = (uint32_t)(o0 + k) | ((uint32_t)refk[k] << 10); ++li; }
             }
             poa_lds_order();
             const bool lead = lane < (int)totl;
             const uint32_t ld = lead ? L.stage[lane] : 0u;
-            par_runs(lead, (int)(ld & 0xffu), (int)(ld >> 8), nv);
+            par_runs(lead, (int)(ld & 0x3ffu), (int)(ld >> 10), nv);
             lastop = (int)(L.ops[nv - 1] & 0xffu);
             ref_i += (int)totr; tgt += (int)tott;
             if (lastop == 'M') { prev = ref_i - 1; first = false; cur_anc = prev; }
@@ -884,10 +888,10 @@ __global__ __launch_bounds__(64) void poa_graph_lds_kernel(PoaDev P, const uint3
 }
 
 // global-memory instantiation over a list of graphs: those too large for the LDS kernel, then what the LDS kernel left behind
-__global__ __launch_bounds__(64, 6) void poa_graph_wave_kernel(PoaDev P, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count_ptr,
+__global__ __launch_bounds__(64, 4) void poa_graph_wave_kernel(PoaDev P, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count_ptr,
                                                                uint32_t count_imm)
 {
-  __shared__ uint32_t s_ops[256], s_stage[64];
+  __shared__ uint32_t s_ops[64 * POA_WK], s_stage[64];
   __shared__ float s_hw[128];
   __shared__ int32_t s_pred[128];
   const uint32_t n = count_ptr ? *count_ptr : count_imm;

@@ -64,6 +64,13 @@ __device__ __forceinline__ uint32_t pk_ne01_u16(uint32_t a, uint32_t b)
   return r;
 }
 __device__ __forceinline__ void opaque_v(int& x) { asm volatile("" : "+v"(x)); }
+// lane masks of comparisons (v_cmp into an SGPR pair) and selects on a lane mask — see the slot visit
+__device__ __forceinline__ unsigned long long mk_eq(int a, int b) { return __builtin_amdgcn_sicmp(a, b, 32); }
+__device__ __forceinline__ unsigned long long mk_gt(int a, int b) { return __builtin_amdgcn_sicmp(a, b, 38); }
+__device__ __forceinline__ unsigned long long mk_ule(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 37); }
+__device__ __forceinline__ int sel(unsigned long long m, int a, int b) { int r; asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m)); return r; }     // lane in m ? a : b
+__device__ __forceinline__ int sel0(unsigned long long m, int a) { int r; asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(a), "s"(m)); return r; }                   // lane in m ? a : 0
+__device__ __forceinline__ bool lane_in(unsigned long long m, int lane) { return ((m >> lane) & 1ull) != 0ull; }
 __device__ __forceinline__ void opaque_v(uint32_t& x) { asm volatile("" : "+v"(x)); }
 // In-place update of a loop-carried wavefront word.  Written as a plain assignment, the conditional slot visit leaves a phi per word at its join,
 // and the allocator resolves part of them with copies at the loop header (dozens of v_mov per score) and spills; tied to its register, a word
@@ -260,6 +267,7 @@ __global__ __launch_bounds__(NW == 1 ? 256 : NW * 64, WPEU) void wfa_affine_reg_
     const int xe = kend - kbase;                 // window index of the end diagonal (end-to-end termination)
 
     int lane2 = 2 * lane, kb = __builtin_amdgcn_readfirstlane(kbase);
+    const int nul16v = NUL16;
 #ifdef OTG_REG_TIMING   // where a wave's cycles go, per section of a score (s_memtime; sums over all waves land behind the visited-cell counter)
     unsigned long long tm_pre = 0, tm_sweep = 0, tm_drain = 0, tm_exp = 0, tm_bar = 0, tm_n = 0, tm_vis = 0, tm_last = __builtin_amdgcn_s_memtime();
 #define OTG_TM(acc) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - tm_last; tm_last = now_; }
@@ -358,8 +366,7 @@ __global__ __launch_bounds__(NW == 1 ? 256 : NW * 64, WPEU) void wfa_affine_reg_
         }
       };
       int pushed = 0, qfull = 0;
-      auto push2 = [&](bool moreE, bool moreO, int xE, int hE, int hO) {
-        const unsigned long long mE = __ballot(moreE), mO = __ballot(moreO);
+      auto push2 = [&](bool moreE, bool moreO, unsigned long long mE, unsigned long long mO, int xE, int hE, int hO) {     // mE / mO = the lane masks of moreE / moreO
         if (mE | mO) {
           if (qn + 128 > QCAP) { qfull = 1; return; }          // more unfinished match runs in one score than the queue holds: the next tier takes the alignment
           const int nE = __builtin_popcountll(mE);
@@ -397,7 +404,7 @@ __global__ __launch_bounds__(NW == 1 ? 256 : NW * 64, WPEU) void wfa_affine_reg_
             const int hx = __builtin_amdgcn_readlane((xe & 1) ? (validO && !moreO ? hO : -1) : (validE && !moreE ? hE : -1), (xe & 127) >> 1);
             if (hx >= tl) cand = kend;
           }
-          push2(moreE, moreO, xE, hE, hO);
+          push2(moreE, moreO, __ballot(moreE), __ballot(moreO), xE, hE, hO);
         });
       } else {
         // ---- the sweep over the touched pair-slots, ascending
@@ -443,8 +450,11 @@ __global__ __launch_bounds__(NW == 1 ? 256 : NW * 64, WPEU) void wfa_affine_reg_
           WI[i] = Inew; WD[i] = Dnew;
           int hE = (int)(int16_t)(Mx & 0xffffu), hO = (int)Mx >> 16;
           const int vE = hE - kE, vO = hO - kE - 1;
-          const bool validE = (uint32_t)hE <= (uint32_t)tl && (uint32_t)vE <= (uint32_t)pl;
-          const bool validO = (uint32_t)hO <= (uint32_t)tl && (uint32_t)vO <= (uint32_t)pl;
+          // From here on every per-lane condition is a 64-bit LANE MASK in scalar registers: comparisons deliver one (v_cmp into an SGPR pair,
+          // mk_*), the logic runs on the scalar unit, "does any lane ..." is a scalar test, and selects take the mask as their condition
+          // (v_cndmask, sel).  Written with bools, every wave-level test came out as a select and a compare on the vector unit in front of its branch.
+          const unsigned long long vmE = mk_ule((uint32_t)hE, (uint32_t)tl) & mk_ule((uint32_t)vE, (uint32_t)pl);
+          const unsigned long long vmO = mk_ule((uint32_t)hO, (uint32_t)tl) & mk_ule((uint32_t)vO, (uint32_t)pl);
           // Probes read wherever the offsets point: an invalid cell (null or past an end) yields an LDS address outside the pair — possibly outside
           // the block's allocation, where reads return zero — and its result is dropped by the `valid` selects below; a valid cell at an end of
           // a sequence gets m = 0 from the remaining lengths.  No clamps, no gating of the probe itself.
@@ -472,34 +482,40 @@ __global__ __launch_bounds__(NW == 1 ? 256 : NW * 64, WPEU) void wfa_affine_reg_
             OTG_SCHED_FENCE();
           }
           hE += mE; hO += mO;
-          bool moreE = validE && mE == 32 && rvE > 32 && rhE > 32, moreO = validO && mO == 32 && rvO > 32 && rhO > 32;
+          // more = the run is still going after 32 bases (valid cell, full probe, more than 32 bases left of both sequences)
+          unsigned long long mmE = vmE & mk_eq(mE, 32) & mk_gt(rvE, 32) & mk_gt(rhE, 32), mmO = vmO & mk_eq(mO, 32) & mk_gt(rvO, 32) & mk_gt(rhO, 32);
           // a second probe where a run outlives the first (one in 120 cells at ONT divergence, i.e. most slot visits have one): the queue, its
           // drain and the fold-back of the patch table — a fixed cost per score — are then left to runs beyond 64 bases (one slot visit in 100)
-          if (__ballot(moreE || moreO)) {
+          if ((mmE | mmO) != 0ull) {
             // one probe sequence for both cells of the lane: it extends the even cell if that one needs it, else the odd one (a lane where both do —
             // one in 15 000 — leaves the odd cell to the queue)
-            const bool selO = !moreE && moreO;
-            const int h2 = selO ? hO : hE;
-            const int v2 = h2 - (selO ? kE + 1 : kE);
+            const unsigned long long selO = mmO & ~mmE;
+            const int h2 = sel(selO, hO, hE);
+            const int v2 = h2 - sel(selO, kE + 1, kE);
             const int rv2 = pl - v2, rh2 = tl - h2;
             int m2nd;
             if constexpr (LB > 0) { const Ld3 p2 = ld3(0, v2), t2 = ld3(offT, h2); OTG_SCHED_FENCE(); m2nd = imin(probe_of(p2, v2, t2, h2), imin(rv2, rh2)); }
             else m2nd = imin(probe32(v2, h2), imin(rv2, rh2));
-            const bool more2 = m2nd == 32 && rv2 > 32 && rh2 > 32;
-            if (selO) { hO += m2nd; moreO = more2; }
-            else if (moreE) { hE += m2nd; moreE = more2; }
+            const unsigned long long m2m = mk_eq(m2nd, 32) & mk_gt(rv2, 32) & mk_gt(rh2, 32);
+            hO += sel0(selO, m2nd); hE += sel0(mmE, m2nd);
+            mmO &= mmE | m2m; mmE &= m2m;             // (the odd cell of a lane whose even cell took the probe stays as it was)
           }
           M4[0][i] = m2;
-          M2[0][i] = pack16(validE ? hE : NUL16, validO ? hO : NUL16);
+          M2[0][i] = pack16(sel(vmE, hE, nul16v), sel(vmO, hO, nul16v));
           if (ef) {
-            const bool fE = validE && !moreE && fin_ef(hE, hE - kE), fO = validO && !moreO && fin_ef(hO, hO - kE - 1);
-            const unsigned long long fm = __ballot(fE || fO);
-            if (fm) { int kc = fE ? kE : (fO ? kE + 1 : NOCAND); kc = -otg_wave_max_i32(-kc); cand = imin(cand, kc); }
+            // a (valid) cell can end the alignment only where it has reached the end of a sequence: h == tl, or v == pl i.e. h == pl + k
+            const int hp = pl + kE;
+            if ((mk_eq(hE, tl) | mk_eq(hE, hp) | mk_eq(hO, tl) | mk_eq(hO, hp + 1)) != 0ull) {
+              const bool fE = lane_in(vmE & ~mmE, lane) && fin_ef(hE, hE - kE), fO = lane_in(vmO & ~mmO, lane) && fin_ef(hO, hO - kE - 1);
+              const unsigned long long fm = __ballot(fE || fO);
+              if (fm) { int kc = fE ? kE : (fO ? kE + 1 : NOCAND); kc = -otg_wave_max_i32(-kc); cand = imin(cand, kc); }
+            }
           } else if (xe >= 128 * gi && xe < 128 * gi + 128) {
-            const int hx = __builtin_amdgcn_readlane((xe & 1) ? (validO && !moreO ? hO : -1) : (validE && !moreE ? hE : -1), (xe & 127) >> 1);
+            const bool odd = (xe & 1) != 0;
+            const int hx = __builtin_amdgcn_readlane(sel(odd ? (vmO & ~mmO) : (vmE & ~mmE), odd ? hO : hE, -1), (xe & 127) >> 1);
             if (hx >= tl) cand = kend;
           }
-          if (__ballot(moreE || moreO)) push2(moreE, moreO, xE, hE, hO);
+          if ((mmE | mmO) != 0ull) push2(lane_in(mmE, lane), lane_in(mmO, lane), mmE, mmO, xE, hE, hO);
         });
       }
       OTG_TM(tm_sweep);
