@@ -260,7 +260,8 @@ __global__ __launch_bounds__(NW == 1 ? 256 : NW * 64, WPEU) void wfa_affine_reg_
     static_for<0, S2>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value;
       M4[0][i] = NN; M2[0][i] = NN; M4[1][i] = NN; M2[1][i] = NN; WI[i] = NN; WD[i] = NN;
       opaque_v(M4[0][i]); opaque_v(M2[0][i]); opaque_v(M4[1][i]); opaque_v(M2[1][i]); });     // vector registers from the start (the swaps at the loop top are tied to them)
-    size_t slab_top = 0;
+    uint32_t slab_top = 0;                       // (a slab is a few hundred megabytes at most: 32-bit bookkeeping on the scalar unit)
+    const uint32_t slab_cap = ws.slab_bytes > 0xfff00000ull ? 0xfff00000u : (uint32_t)ws.slab_bytes;
     int s_end = -1, k_end = 0;
     int r1lo = 1, r1hi = 0, r2lo = 1, r2hi = 0, r3lo = 1, r3hi = 0, r4lo = 1, r4hi = 0, idlo = 1, idhi = 0;
     uint32_t xlv = NN, xrv = NN;                 // (NW > 1) lane g: X_I of slot g - 1 / X_D of slot g + 1 as exported at the end of the previous score
@@ -309,10 +310,10 @@ __global__ __launch_bounds__(NW == 1 ? 256 : NW * 64, WPEU) void wfa_affine_reg_
       if (xlo < 2 || xhi + 3 >= CAP) { fail = true; break; }
       j0 = (xlo - 1) >> 7; j1 = (xhi + 1) >> 7;  // one diagonal of margin on both sides: a cell's provenance byte carries its neighbours' gap choices
       const int width = (j1 - j0 + 1) * 128;
-      if (slab_top + (size_t)width > ws.slab_bytes) { fail = true; break; }
+      if (slab_top + (uint32_t)width > slab_cap) { fail = true; break; }
       uint8_t* brow = slab + slab_top - 128 * j0;                  // provenance byte of window index x: brow[x]
       rowtab[s] = (int64_t)slab_top - (int64_t)(kbase + 128 * j0);  // wave-uniform store (same value from every lane and every wave)
-      slab_top += (size_t)width;
+      slab_top += (uint32_t)width;
       int qn = 0;
       // ---- drain: queued cells {x | h << 16} are extended to the end of their match run in 64-lane batches; final offsets go to the patch table
       auto drain = [&]() {
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(NW == 1 ? 256 : NW * 64, WPEU) void wfa_affine_reg_
           bw ^= 0x000C000Cu;
           const uint16_t b2 = (uint16_t)__builtin_amdgcn_perm(bw, bw, 0x0c0c0200u);
           const int xE = 128 * gi + lane2, kE = kb + xE;
-          __builtin_memcpy(brow + xE, &b2, 2);
+          __builtin_memcpy(brow + 128 * gi + (uint32_t)lane2, &b2, 2);     // uniform base + unsigned lane offset: no 64-bit address arithmetic per lane
           WI[i] = Inew; WD[i] = Dnew;
           int hE = (int)(int16_t)(Mx & 0xffffu), hO = (int)Mx >> 16;
           const int vE = hE - kE, vO = hO - kE - 1;
