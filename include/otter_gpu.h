@@ -450,7 +450,8 @@ typedef struct otg_assemble_job {
   int32_t     reads_only;        /* --reads-only                                                     */
   otg_params  params;            /* heuristics (realign is set from fasta_path)                      */
   otg_ingest_opts ingest;        /* --offset, --mapq, --non-primary, --omit-nonspanning, --read-quality; .threads = -t (host ingest threads) */
-  uint32_t    batch_regions;     /* regions per batch, 0 = 2048                                      */
+  uint32_t    batch_regions;     /* regions per batch; 0 = the library's plan: batches of 2048, smaller
+                                  * ones at both ends of a shard (256, 512, 1024 first; thirds at the end) */
   int32_t     n_devices;         /* 0: device 0 only                                                 */
   const int32_t* devices;        /* HIP device ordinals, one shard each                              */
 } otg_assemble_job;
@@ -479,6 +480,10 @@ typedef struct otg_genotype_job {
 int otg_genotype_files(const otg_genotype_job* job, otg_write_fn write, void* user, otg_job_stats* stats);
 /* The dispatcher keeps its per-device contexts (and their HBM workspaces) for the next job of the process; this frees them. */
 void otg_assemble_files_release(void);
+
+/* The batch sizes otg_assemble_files cuts a shard of `n_regions` regions into (batch_regions as in the job; 0 = the library's plan).
+ * Writes at most `capacity` sizes, *n_batches = how many there are; OTG_ERR_CAPACITY when they do not fit. */
+int otg_assemble_batch_plan(uint32_t n_regions, uint32_t batch_regions, uint32_t* sizes, uint32_t capacity, uint32_t* n_batches);
 
 #ifdef __cplusplus
 }

@@ -18,7 +18,7 @@ EXPORTS = [
     "otg_bam_open", "otg_bam_close", "otg_bam_n_targets", "otg_bam_target", "otg_ingest_regions",
     "otg_ingest_regions_named", "otg_emit_reads", "otg_parse_bed_file", "otg_fasta_open", "otg_fasta_close", "otg_fasta_n_seqs",
     "otg_fasta_seq", "otg_fasta_fetch", "otg_fasta_region_flanks",
-    "otg_bam_sample_index", "otg_bam_sample", "otg_ingest_alleles", "otg_emit_vcf_header", "otg_emit_vcf_lines", "otg_emit_genotype_lengths", "otg_assemble_files", "otg_assemble_files_release", "otg_genotype_files", "otg_wgat",
+    "otg_bam_sample_index", "otg_bam_sample", "otg_ingest_alleles", "otg_emit_vcf_header", "otg_emit_vcf_lines", "otg_emit_genotype_lengths", "otg_assemble_files", "otg_assemble_files_release", "otg_assemble_batch_plan", "otg_genotype_files", "otg_wgat",
     "otg_comm_unique_id", "otg_comm_create", "otg_comm_destroy", "otg_gather_sizes", "otg_gather_records",
 ]
 
@@ -605,6 +605,21 @@ def assemble_files(bam, bed, fasta=None, read_group="", is_fasta=False, reads_on
     if rc != 0:
         raise OtterGpuError("otg_assemble_files failed (%d): %s" % (rc, (L.otg_last_error(None) or b"").decode()))
     return b"".join(chunks), {k: getattr(st, k) for k, _ in abi.JobStats._fields_}
+
+
+def assemble_batch_plan(n_regions, batch_regions=0):
+    """Batch sizes otg_assemble_files cuts a shard of n_regions into (otg_assemble_batch_plan)."""
+    L = load()
+    L.otg_assemble_batch_plan.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32)]
+    n = C.c_uint32(0)
+    rc = L.otg_assemble_batch_plan(n_regions, batch_regions, None, 0, C.byref(n))
+    if rc not in (0, abi.OTG_ERR_CAPACITY):
+        raise OtterGpuError("otg_assemble_batch_plan failed (%d)" % rc)
+    out = (C.c_uint32 * max(1, n.value))()
+    rc = L.otg_assemble_batch_plan(n_regions, batch_regions, out, n.value, C.byref(n))
+    if rc != 0:
+        raise OtterGpuError("otg_assemble_batch_plan failed (%d)" % rc)
+    return [int(out[i]) for i in range(n.value)]
 
 
 def genotype_files(bam, bed, fasta=None, params=None, threads=1, device=0, batch_regions=0):

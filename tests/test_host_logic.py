@@ -43,3 +43,22 @@ def test_pack_and_tasks():
     assert arena[:6].tobytes() == b"ACGTTT" and off.tolist() == [0, 4, 4] and ln.tolist() == [4, 0, 2]
     t = abi.make_tasks([(0, 4, 4, 2, None), (0, 4, 4, 2, (1, 2, 3, 4))])
     assert t[0]["endsfree"] == 0 and t[1]["endsfree"] == 1 and t[1]["text_end_free"] == 4
+
+
+def test_dispatcher_batch_plan():
+    """otg_assemble_batch_plan (the cut of a shard into batches, include/otter_gpu.h): every region once and in order whatever the size; a
+    requested size is kept; the library's own plan starts small (the device idles while the first batch is read), reaches full batches
+    of 2048 on a large shard and ends on smaller ones again."""
+    import otter_amd
+    for n in (0, 1, 7, 255, 256, 1025, 2048, 4096, 10000, 12500, 100000, 123457):
+        for req in (0, 1, 3, 1000, 2048, 5000):
+            plan = otter_amd.assemble_batch_plan(n, req)
+            assert sum(plan) == n and all(p > 0 for p in plan), (n, req, plan)
+            if req:
+                assert plan == [req] * (n // req) + ([n % req] if n % req else []), (n, req)
+            else:
+                assert max(plan, default=0) <= 2048
+    plan = otter_amd.assemble_batch_plan(100000, 0)
+    assert plan[:3] == [256, 512, 1024] and plan[3] == 2048 and plan.count(2048) >= 40
+    assert plan[-1] <= 512 and len(plan) <= 60
+    assert otter_amd.assemble_batch_plan(1000, 0) == [1000] or sum(otter_amd.assemble_batch_plan(1000, 0)) == 1000
