@@ -50,6 +50,7 @@ struct PoaDev {
   const uint64_t* out_off; uint32_t* out_len; uint8_t* out_arena; uint32_t* out_start; int32_t* status;
   const uint32_t* order;      // launch lists: graphs for the LDS kernel, then graphs for the global-memory kernel (longest first each)
   unsigned long long* prof;   // OTG_POA_PROFILE: wall-clock ticks per phase, summed over graphs (null otherwise)
+  unsigned long long* prof_graph;   // ... and six words per graph: threading ticks, wide / narrow / serial chunks, ticks in the narrow + serial code, members | backbone << 32
   uint32_t* fb_list;          // graphs left to the global-memory kernel by the LDS kernel (outgrew the optimistic capacities)
   uint32_t* fb_count;
   // second generation of the global-memory path (v2 != 0): per edge its successor in the edge list of its ANCHOR (the backbone node its
@@ -219,6 +220,9 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
   bool tree_ok = true;                 // V2: every alt node has one in-edge and every edge list belongs to one anchor
   const unsigned long long lt = (1ull << lane) - 1ull;
   const unsigned long long t0 = P.prof ? wall_clock64() : 0ull;
+  unsigned long long pf_wide = 0, pf_wide_ops = 0, pf_narrow = 0, pf_serial = 0, pf_follow = 0, pf_sM = 0, pf_sX = 0, pf_sI = 0, pf_sD = 0, pf_snom = 0, pf_sirr = 0, pf_shead = 0;     // OTG_POA_PROFILE: chunks by kind
+  unsigned long long tq_serial = 0, tq_layout = 0, tq_mid = 0, tq_a = 0, tq_turn = 0, tq_c = 0, tq_mark = 0;      // ... and where a wide chunk's time goes (10 ns ticks)
+  auto tick = [&](unsigned long long& acc) { if (P.prof) { const unsigned long long now = wall_clock64(); acc += now - tq_mark; tq_mark = now; } };
 
   // ---- PPOA::init (src/anppoa.hpp:64-84)
   {
@@ -282,24 +286,243 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
     if ((int)sink >= B) tree_ok = false;      // a second way into an alt node (only op strings that run past the backbone get here)
     append_edge(src, src_head, src_tail, sink, (int)sink >= B ? (uint32_t)nbase[sink] : 0u);
   };
+  int as_edge = -1;                    // the edge the latest alt_step followed (-1: it made a node)
   auto alt_step = [&](uint32_t prev, int prev_head, int prev_tail, uint8_t tc) -> uint32_t {   // :162-186 / :206-233
     for (int e = prev_head; e >= 0;) {
       const EdgeG x = S.ldE(e);
-      if ((int)x.sink >= B && (x.base & 0xffu) == (uint32_t)tc) { S.stEw(e, x.w + 1.0f); return x.sink; }
+      if ((int)x.sink >= B && (x.base & 0xffu) == (uint32_t)tc) { S.stEw(e, x.w + 1.0f); as_edge = e; return x.sink; }
       e = x.next;
     }
+    as_edge = -1;
     const uint32_t nn = new_node(tc);
     if (!status) append_edge(prev, prev_head, prev_tail, nn, tc);     // a fresh node: no edge to it can exist yet
     return nn;
   };
 
+  // the member whose op string is being threaded
+  const uint8_t* seq = nullptr; const uint8_t* cig = nullptr;
+  int clen = 0, slen = 0;
+  bool spl = false, spr = false;
+  auto set_member = [&](const uint32_t mi) {
+    const otg_poa_member M = P.members[G.first_member + mi];
+    seq = P.seq_arena + M.seq_off; cig = P.cig_arena + M.cigar_off;
+    clen = (int)M.cigar_len; slen = (int)M.seq_len;
+    spl = M.spanning_l != 0; spr = M.spanning_r != 0;
+  };
+  // one lane per run (lead: this lane has one; p0 = its first op in L.ops, ref0 = the backbone position there, nv = ops in the chunk)
+  auto par_runs = [&](const bool lead, const int p0, const int ref0, const int nv) {
+      uint32_t n_newn = 0, n_newe = 0, pv = 0, last_ex = 0;
+      int ph = -1, pt = -1, ltl = -1, r = 0, r_miss = 0, jmiss = -1, r_close = -1, anc = 0;
+      bool missed = false, close_new = false, closed = false;
+      if (lead) {
+        // phase A: follow the run through the subtree that exists (weights of the edges it reuses go up), stop creating at the first miss
+        anc = ref0 - 1; pv = (uint32_t)anc; r = ref0;
+        { const NodeG na = S.ldN(pv); ph = na.head; pt = na.pred; }
+        for (int j = p0; j < nv; ++j) {
+          const uint32_t o = L.ops[j];
+          const int op = (int)(o & 0xffu);
+          const uint32_t tc = (o >> 8) & 0xffu;
+          if (op == 'M') { closed = true; r_close = r; break; }
+          if (op == 'D') { r += 1; if (!missed && B - r <= 10 && spr) isend[pv] = 1; continue; }
+          if (!missed) {
+            bool found = false;
+            for (int e = ph; e >= 0;) {
+              const EdgeG x = S.ldE(e);
+              if ((int)x.sink >= B && (x.base & 0xffu) == tc) { S.stEw(e, x.w + 1.0f); pv = x.sink; found = true; break; }
+              e = x.next;
+            }
+            if (found) { const NodeG nn = S.ldN(pv); ph = nn.head; pt = nn.pred; }
+            else { missed = true; jmiss = j; r_miss = r; last_ex = pv; ltl = pt; }
+          }
+          if (missed) ++n_newn;
+          if (op == 'X') r += 1;
+          if (!missed && B - r <= 10 && spr) isend[pv] = 1;
+        }
+        if (closed) {
+          if (!missed) {
+            if ((int)pv < B - 1 && r_close == (int)pv + 1) bbc[pv] = bbc[pv] + 1;
+            else {
+              bool found = false;
+              for (int e = ph; e >= 0;) {
+                const EdgeG x = S.ldE(e);
+                if ((int)x.sink == r_close) { S.stEw(e, x.w + 1.0f); found = true; break; }
+                e = x.next;
+              }
+              if (!found) { close_new = true; last_ex = pv; ltl = pt; }
+            }
+          }
+          if (B - (r_close + 1) <= 10 && spr) isend[r_close] = 1;
+        }
+        n_newe = n_newn + ((closed && (missed || close_new)) ? 1u : 0u);
+      }
+      // phase B: ids in op order
+      tick(tq_a);
+      tick(tq_turn);
+      uint32_t tot_n = 0, tot_e = 0;
+      const uint32_t nb = n_nodes + poa_wave_excl_sum(n_newn, lane, &tot_n);
+      const uint32_t eb = n_edges + poa_wave_excl_sum(n_newe, lane, &tot_e);
+      if (n_nodes + tot_n > node_cap) status = 1;
+      else if (n_edges + tot_e > edge_cap) status = 2;
+      if (!status) {
+        // phase C: the new chain of each run
+        if (lead && n_newe) {
+          uint32_t src = last_ex, k = 0;
+          if (missed) {
+            int r2 = r_miss;
+            for (int j = jmiss; j < nv; ++j) {
+              const uint32_t o = L.ops[j];
+              const int op = (int)(o & 0xffu);
+              const uint32_t tc = (o >> 8) & 0xffu;
+              if (op == 'M') break;
+              if (op == 'D') { r2 += 1; if (B - r2 <= 10 && spr) isend[src] = 1; continue; }
+              const uint32_t id = nb + k;
+              const int ein = (int)(eb + k);
+              const bool has_out = k + 1u < n_newe;
+              nbase[id] = (uint8_t)tc;
+              EdgeG x; x.sink = id; x.w = 1.0f; x.next = -1; x.base = tc | (src << 8);
+              S.stE(ein, x);
+              X.anext[ein] = has_out ? ein + 1 : -1;
+              NodeG nn; nn.hw = 0.0f; nn.pred = has_out ? ein + 1 : -1; nn.indeg = (uint32_t)(ein + 1); nn.head = has_out ? ein + 1 : -1;
+              S.stN(id, nn);
+              src = id; ++k;
+              if (op == 'X') r2 += 1;
+              if (B - r2 <= 10 && spr) isend[id] = 1;
+            }
+          }
+          if (closed && (missed || close_new)) {
+            const int ec = (int)(eb + k);
+            EdgeG x; x.sink = (uint32_t)r_close; x.w = 1.0f; x.next = -1; x.base = src << 8;
+            S.stE(ec, x);
+            X.anext[ec] = -1;
+          }
+          if (ltl >= 0) { S.stEnext(ltl, (int)eb); S.stTail(last_ex, (int)eb); } else S.stList(last_ex, (int)eb, (int)eb);
+          const int t = X.atail[anc + 1];
+          if (t >= 0) X.anext[t] = (int)eb; else X.ahead[anc + 1] = (int)eb;
+          X.atail[anc + 1] = (int)(eb + n_newe - 1u);
+          X.acnt[anc + 1] = X.acnt[anc + 1] + n_newe;
+        }
+        n_nodes += tot_n; n_edges += tot_e;
+      }
+      cn_id = 0xffffffffu;
+  };
+  int pre_ci = -1; int pre_cc[WK];      // V2: ops read ahead for the chunk that starts at pre_ci
+#pragma unroll
+  for (int k = 0; k < WK; ++k) pre_cc[k] = 0;
+  // ---- one wide chunk: WK ops per lane from op ci0 on (up to 64 * WK ops, cut after their last 'M' so that the next chunk starts right after an
+  // 'M' and every run lies inside one chunk; at most 64 runs).  The round trips of a chunk (ops, target bases, backbone counts, the runs'
+  // subtrees) are what the threading waits for, so few, full chunks.  Returns false — nothing done — when the window holds something out
+  // of the ordinary: the narrow code below takes it.
+  auto wide_chunk = [&](const int ci0, const int ref0, const int tgt0, int& nv_out, int& totr_out, int& tott_out, int& lastop_out) -> bool {
+    const int rem = clen - ci0;
+    const int rem4 = rem < 64 * WK ? rem : 64 * WK;
+    const int o0 = WK * lane;
+    int cc[WK];
+    if (P.prof) tq_mark = wall_clock64();
+    if (pre_ci == ci0) {
+#pragma unroll
+      for (int k = 0; k < WK; ++k) cc[k] = o0 + k < rem4 ? pre_cc[k] : 0;
+    } else {
+#pragma unroll
+      for (int k = 0; k < WK; ++k) cc[k] = o0 + k < rem4 ? (int)cig[ci0 + o0 + k] : 0;
+    }
+    int nv = rem4;
+    if (rem > 64 * WK) {
+      int lm = -1;
+#pragma unroll
+      for (int k = 0; k < WK; ++k) if (cc[k] == 'M') lm = o0 + k;
+      lm = otg_wave_max_i32(lm);
+      if (lm < 0) return false;
+      nv = lm + 1;
+    }
+    uint32_t totr = 0, tott = 0, totl = 0;
+    int refk[WK], tgtk[WK]; bool simk[WK], leadk[WK];
+    uint32_t li = 0;
+    // Two passes at most: a chunk with more than 64 runs (one lane per run) is cut in front of its 65th run — a run starts right after an
+    // 'M', so the shorter chunk still ends on one — and laid out again.  (At ONT divergence a 512-op chunk holds ~63 runs.)
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      uint32_t nref = 0, ntgt = 0;
+#pragma unroll
+      for (int k = 0; k < WK; ++k) {
+        const bool v = o0 + k < nv;
+        const int c4 = cc[k];
+        nref += (v && (c4 == 'M' || c4 == 'X' || c4 == 'D')) ? 1u : 0u;
+        ntgt += (v && (c4 == 'M' || c4 == 'X' || c4 == 'I')) ? 1u : 0u;
+      }
+      int ra = ref0 + (int)poa_wave_excl_sum(nref, lane, &totr), ta = tgt0 + (int)poa_wave_excl_sum(ntgt, lane, &tott);
+      int pcur = __shfl_up(cc[WK - 1], 1);
+      if (lane == 0) pcur = 'M';
+      bool irregular = false;
+      uint32_t nl = 0;
+#pragma unroll
+      for (int k = 0; k < WK; ++k) {
+        const bool v = o0 + k < nv;
+        const int c4 = cc[k];
+        const bool m = c4 == 'M', x = c4 == 'X', d = c4 == 'D', in = c4 == 'I';
+        refk[k] = ra; tgtk[k] = ta;
+        simk[k] = v && m && pcur == 'M' && ra < B;
+        leadk[k] = v && !m && pcur == 'M';
+        if (v && (!(m || x || d || in) || (m && ra >= B) || (!m && ra > B) || ((x || in) && ta >= slen))) irregular = true;
+        if (v) { ra += (m || x || d) ? 1 : 0; ta += (m || x || in) ? 1 : 0; pcur = c4; }
+        nl += leadk[k] ? 1u : 0u;
+      }
+      li = poa_wave_excl_sum(nl, lane, &totl);
+      if (__ballot(irregular) || (totl > 64u && attempt == 1)) return false;
+      if (totl <= 64u) break;
+      int cut = -(1 << 30);                              // minus the position of the run that would be the 65th
+      uint32_t rank = li;
+#pragma unroll
+      for (int k = 0; k < WK; ++k) if (leadk[k]) { if (rank == 64u) cut = -(o0 + k); ++rank; }
+      nv = -otg_wave_max_i32(cut);
+    }
+    nv = __builtin_amdgcn_readfirstlane(nv);
+    int lsel = 0;                                          // the chunk's last op: the op in front of the next chunk
+#pragma unroll
+    for (int k = 0; k < WK; ++k) if (k == ((nv - 1) & (WK - 1))) lsel = cc[k];
+    const int lastop_n = __builtin_amdgcn_readlane(lsel, (nv - 1) / WK);
+    tick(tq_layout);
+    {
+      // the ops of the chunk after this one are asked for now: first-touch reads of the op string cost far more than a cache hit, and
+      // this one then overlaps with the rest of this chunk
+      pre_ci = ci0 + nv;
+#pragma unroll
+      for (int k = 0; k < WK; ++k) pre_cc[k] = pre_ci + o0 + k < clen ? (int)cig[pre_ci + o0 + k] : 0;
+    }
+    // every load of the chunk head first (backbone counts of the plain 'M' ops, target bases), then the stores: one round trip
+    int tbv[WK];
+#pragma unroll
+    for (int k = 0; k < WK; ++k) tbv[k] = (o0 + k < nv && (cc[k] == 'X' || cc[k] == 'I')) ? (int)seq[tgtk[k]] : 0;
+    {
+      const unsigned long long s3 = __ballot(simk[WK - 1]), s0 = __ballot(simk[0]);
+      const bool prev_s = lane > 0 && ((s3 >> (lane - 1)) & 1ull), next_s = lane < 63 && ((s0 >> (lane + 1)) & 1ull);
+#pragma unroll
+      for (int k = 0; k < WK; ++k) {
+        if (simk[k]) {
+          const bool ps = k > 0 ? simk[k > 0 ? k - 1 : 0] : prev_s, ns = k < WK - 1 ? simk[k < WK - 1 ? k + 1 : WK - 1] : next_s;
+          if (!ps) atomicAdd(&bdiff[refk[k] - 1], 1);
+          if (!ns) atomicAdd(&bdiff[refk[k]], -1);
+          if (B - (refk[k] + 1) <= 10 && spr && (uint32_t)refk[k] < node_cap) isend[refk[k]] = 1;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < WK; ++k) {
+      if (o0 + k < nv) L.ops[o0 + k] = (uint32_t)cc[k] | ((uint32_t)tbv[k] << 8);
+      if (leadk[k]) { L.stage[li] = (uint32_t)(o0 + k) | ((uint32_t)refk[k] << 10); ++li; }
+    }
+    poa_lds_order();
+    const bool lead = lane < (int)totl;
+    const uint32_t ld = lead ? L.stage[lane] : 0u;
+    tick(tq_mid);
+    par_runs(lead, (int)(ld & 0x3ffu), (int)(ld >> 10), nv);
+    tick(tq_c);
+    pf_wide += 1; pf_wide_ops += (unsigned long long)nv;
+    nv_out = nv; totr_out = (int)totr; tott_out = (int)tott; lastop_out = lastop_n;
+    return true;
+  };
   // ---- insert_alignment for every member, in order (src/anppoa.hpp:112-241)
   for (uint32_t mi = 0; mi < G.n_members && !status; ++mi) {
-    const otg_poa_member M = P.members[G.first_member + mi];
-    const uint8_t* seq = P.seq_arena + M.seq_off;
-    const uint8_t* cig = P.cig_arena + M.cigar_off;
-    const int clen = (int)M.cigar_len, slen = (int)M.seq_len;
-    const bool spl = M.spanning_l != 0, spr = M.spanning_r != 0;
+    set_member(mi);
+    pre_ci = -1;
     int prev = 0, ref_i = 0, tgt = 0, ci = 0;
     bool first = true;
     cur_anc = 0;
@@ -318,200 +541,21 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
         ci += upto; stop = upto < 64;
       }
     }
-    // one lane per run (lead: this lane has one; p0 = its first op in L.ops, ref0 = the backbone position there, nv = ops in the chunk)
-    auto par_runs = [&](const bool lead, const int p0, const int ref0, const int nv) {
-        uint32_t n_newn = 0, n_newe = 0, pv = 0, last_ex = 0;
-        int ph = -1, pt = -1, ltl = -1, r = 0, r_miss = 0, jmiss = -1, r_close = -1, anc = 0;
-        bool missed = false, close_new = false, closed = false;
-        if (lead) {
-          // phase A: follow the run through the subtree that exists (weights of the edges it reuses go up), stop creating at the first miss
-          anc = ref0 - 1; pv = (uint32_t)anc; r = ref0;
-          { const NodeG na = S.ldN(pv); ph = na.head; pt = na.pred; }
-          for (int j = p0; j < nv; ++j) {
-            const uint32_t o = L.ops[j];
-            const int op = (int)(o & 0xffu);
-            const uint32_t tc = (o >> 8) & 0xffu;
-            if (op == 'M') { closed = true; r_close = r; break; }
-            if (op == 'D') { r += 1; if (!missed && B - r <= 10 && spr) isend[pv] = 1; continue; }
-            if (!missed) {
-              bool found = false;
-              for (int e = ph; e >= 0;) {
-                const EdgeG x = S.ldE(e);
-                if ((int)x.sink >= B && (x.base & 0xffu) == tc) { S.stEw(e, x.w + 1.0f); pv = x.sink; found = true; break; }
-                e = x.next;
-              }
-              if (found) { const NodeG nn = S.ldN(pv); ph = nn.head; pt = nn.pred; }
-              else { missed = true; jmiss = j; r_miss = r; last_ex = pv; ltl = pt; }
-            }
-            if (missed) ++n_newn;
-            if (op == 'X') r += 1;
-            if (!missed && B - r <= 10 && spr) isend[pv] = 1;
-          }
-          if (closed) {
-            if (!missed) {
-              if ((int)pv < B - 1 && r_close == (int)pv + 1) bbc[pv] = bbc[pv] + 1;
-              else {
-                bool found = false;
-                for (int e = ph; e >= 0;) {
-                  const EdgeG x = S.ldE(e);
-                  if ((int)x.sink == r_close) { S.stEw(e, x.w + 1.0f); found = true; break; }
-                  e = x.next;
-                }
-                if (!found) { close_new = true; last_ex = pv; ltl = pt; }
-              }
-            }
-            if (B - (r_close + 1) <= 10 && spr) isend[r_close] = 1;
-          }
-          n_newe = n_newn + ((closed && (missed || close_new)) ? 1u : 0u);
-        }
-        // phase B: ids in op order
-        uint32_t tot_n = 0, tot_e = 0;
-        const uint32_t nb = n_nodes + poa_wave_excl_sum(n_newn, lane, &tot_n);
-        const uint32_t eb = n_edges + poa_wave_excl_sum(n_newe, lane, &tot_e);
-        if (n_nodes + tot_n > node_cap) status = 1;
-        else if (n_edges + tot_e > edge_cap) status = 2;
-        if (!status) {
-          // phase C: the new chain of each run
-          if (lead && n_newe) {
-            uint32_t src = last_ex, k = 0;
-            if (missed) {
-              int r2 = r_miss;
-              for (int j = jmiss; j < nv; ++j) {
-                const uint32_t o = L.ops[j];
-                const int op = (int)(o & 0xffu);
-                const uint32_t tc = (o >> 8) & 0xffu;
-                if (op == 'M') break;
-                if (op == 'D') { r2 += 1; if (B - r2 <= 10 && spr) isend[src] = 1; continue; }
-                const uint32_t id = nb + k;
-                const int ein = (int)(eb + k);
-                const bool has_out = k + 1u < n_newe;
-                nbase[id] = (uint8_t)tc;
-                EdgeG x; x.sink = id; x.w = 1.0f; x.next = -1; x.base = tc | (src << 8);
-                S.stE(ein, x);
-                X.anext[ein] = has_out ? ein + 1 : -1;
-                NodeG nn; nn.hw = 0.0f; nn.pred = has_out ? ein + 1 : -1; nn.indeg = (uint32_t)(ein + 1); nn.head = has_out ? ein + 1 : -1;
-                S.stN(id, nn);
-                src = id; ++k;
-                if (op == 'X') r2 += 1;
-                if (B - r2 <= 10 && spr) isend[id] = 1;
-              }
-            }
-            if (closed && (missed || close_new)) {
-              const int ec = (int)(eb + k);
-              EdgeG x; x.sink = (uint32_t)r_close; x.w = 1.0f; x.next = -1; x.base = src << 8;
-              S.stE(ec, x);
-              X.anext[ec] = -1;
-            }
-            if (ltl >= 0) { S.stEnext(ltl, (int)eb); S.stTail(last_ex, (int)eb); } else S.stList(last_ex, (int)eb, (int)eb);
-            const int t = X.atail[anc + 1];
-            if (t >= 0) X.anext[t] = (int)eb; else X.ahead[anc + 1] = (int)eb;
-            X.atail[anc + 1] = (int)(eb + n_newe - 1u);
-            X.acnt[anc + 1] = X.acnt[anc + 1] + n_newe;
-          }
-          n_nodes += tot_n; n_edges += tot_e;
-        }
-        cn_id = 0xffffffffu;
-    };
-    int pre_ci = -1; int pre_cc[WK];
-#pragma unroll
-    for (int k = 0; k < WK; ++k) pre_cc[k] = 0;      // V2: ops read ahead for the chunk that starts at pre_ci
     int lastop = 0;                    // op just before position ci in the main phase (0 = none)
     while (ci < clen && !status) {
       const int i = ci + lane;
       const int rem = clen - ci;
       if (V2 && lastop == 'M' && !first && rem > 64) {
-        // ---- wide chunk: WK ops per lane (up to 64 * WK ops; cut after the last 'M' like the narrow chunk below).  The round trips of a chunk
-        // (ops, target bases, backbone counts, the runs' subtrees) are what the threading waits for, so fewer, fuller chunks; more than 64
-        // runs in the chunk (a member that disagrees with the backbone everywhere) or anything irregular leaves the chunk to the narrow code
-        const int rem4 = rem < 64 * WK ? rem : 64 * WK;
-        const int o0 = WK * lane;
-        int cc[WK];
-        if (pre_ci == ci) {
-#pragma unroll
-          for (int k = 0; k < WK; ++k) cc[k] = o0 + k < rem4 ? pre_cc[k] : 0;
-        } else {
-#pragma unroll
-          for (int k = 0; k < WK; ++k) cc[k] = o0 + k < rem4 ? (int)cig[ci + o0 + k] : 0;
-        }
-        bool wide_ok = true;
-        int nv = rem4;
-        if (rem > 64 * WK) {
-          int lm = -1;
-#pragma unroll
-          for (int k = 0; k < WK; ++k) if (cc[k] == 'M') lm = o0 + k;
-          lm = otg_wave_max_i32(lm);
-          if (lm < 0) wide_ok = false; else nv = lm + 1;
-        }
-        if (wide_ok) {
-          // the ops of the chunk after this one are asked for now: first-touch reads of the op string cost far more than a cache hit, and
-          // this one then overlaps with the rest of this chunk
-          pre_ci = ci + nv;
-#pragma unroll
-          for (int k = 0; k < WK; ++k) pre_cc[k] = pre_ci + o0 + k < clen ? (int)cig[pre_ci + o0 + k] : 0;
-          uint32_t nref = 0, ntgt = 0;
-#pragma unroll
-          for (int k = 0; k < WK; ++k) {
-            const bool v = o0 + k < nv;
-            const int c4 = cc[k];
-            nref += (v && (c4 == 'M' || c4 == 'X' || c4 == 'D')) ? 1u : 0u;
-            ntgt += (v && (c4 == 'M' || c4 == 'X' || c4 == 'I')) ? 1u : 0u;
-          }
-          uint32_t totr = 0, tott = 0, totl = 0;
-          int ra = ref_i + (int)poa_wave_excl_sum(nref, lane, &totr), ta = tgt + (int)poa_wave_excl_sum(ntgt, lane, &tott);
-          int pcur = __shfl_up(cc[WK - 1], 1);
-          if (lane == 0) pcur = 'M';
-          int refk[WK], tgtk[WK]; bool simk[WK], leadk[WK];
-          bool irregular = false;
-          uint32_t nl = 0;
-#pragma unroll
-          for (int k = 0; k < WK; ++k) {
-            const bool v = o0 + k < nv;
-            const int c4 = cc[k];
-            const bool m = c4 == 'M', x = c4 == 'X', d = c4 == 'D', in = c4 == 'I';
-            refk[k] = ra; tgtk[k] = ta;
-            simk[k] = v && m && pcur == 'M' && ra < B;
-            leadk[k] = v && !m && pcur == 'M';
-            if (v && (!(m || x || d || in) || (m && ra >= B) || (!m && ra > B) || ((x || in) && ta >= slen))) irregular = true;
-            if (v) { ra += (m || x || d) ? 1 : 0; ta += (m || x || in) ? 1 : 0; pcur = c4; }
-            nl += leadk[k] ? 1u : 0u;
-          }
-          uint32_t li = poa_wave_excl_sum(nl, lane, &totl);
-          if (__ballot(irregular) || totl > 64u) wide_ok = false;
-          if (wide_ok) {
-            // every load of the chunk head first (backbone counts of the plain 'M' ops, target bases), then the stores: one round trip
-            int tbv[WK];
-#pragma unroll
-            for (int k = 0; k < WK; ++k) tbv[k] = (o0 + k < nv && (cc[k] == 'X' || cc[k] == 'I')) ? (int)seq[tgtk[k]] : 0;
-            {
-              const unsigned long long s3 = __ballot(simk[WK - 1]), s0 = __ballot(simk[0]);
-              const bool prev_s = lane > 0 && ((s3 >> (lane - 1)) & 1ull), next_s = lane < 63 && ((s0 >> (lane + 1)) & 1ull);
-#pragma unroll
-              for (int k = 0; k < WK; ++k) {
-                if (simk[k]) {
-                  const bool ps = k > 0 ? simk[k > 0 ? k - 1 : 0] : prev_s, ns = k < WK - 1 ? simk[k < WK - 1 ? k + 1 : WK - 1] : next_s;
-                  if (!ps) atomicAdd(&bdiff[refk[k] - 1], 1);
-                  if (!ns) atomicAdd(&bdiff[refk[k]], -1);
-                  if (B - (refk[k] + 1) <= 10 && spr && (uint32_t)refk[k] < node_cap) isend[refk[k]] = 1;
-                }
-              }
-            }
-#pragma unroll
-            for (int k = 0; k < WK; ++k) {
-              if (o0 + k < nv) L.ops[o0 + k] = (uint32_t)cc[k] | ((uint32_t)tbv[k] << 8);
-              if (leadk[k]) { L.stage[li] = (uint32_t)(o0 + k) | ((uint32_t)refk[k] << 10); ++li; }
-            }
-            poa_lds_order();
-            const bool lead = lane < (int)totl;
-            const uint32_t ld = lead ? L.stage[lane] : 0u;
-            par_runs(lead, (int)(ld & 0x3ffu), (int)(ld >> 10), nv);
-            lastop = (int)(L.ops[nv - 1] & 0xffu);
-            ref_i += (int)totr; tgt += (int)tott;
-            if (lastop == 'M') { prev = ref_i - 1; first = false; cur_anc = prev; }
-            ci += nv;
-            continue;
-          }
+        int nv = 0, tr = 0, tt = 0, lo = 0;
+        if (wide_chunk(ci, ref_i, tgt, nv, tr, tt, lo)) {
+          lastop = lo;
+          ref_i += tr; tgt += tt;
+          if (lastop == 'M') { prev = ref_i - 1; first = false; cur_anc = prev; }
+          ci += nv;
+          continue;
         }
       }
+      const unsigned long long ts0 = P.prof ? wall_clock64() : 0ull;
       const int c = lane < rem ? (int)cig[i] : 0;
       // V2: the chunk ends after the last 'M' of the 64-op window (the whole rest of the op string when that is shorter), so that the
       // next chunk starts right after an 'M' and every run of non-'M' ops lies inside one chunk
@@ -552,13 +596,89 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
         L.ops[lane] = valid ? ((uint32_t)c | ((uint32_t)tb << 8)) : 0u;
         poa_lds_order();
         par_runs(valid && !isM && pc == 'M', lane, ref_at, nvalid);
+        pf_narrow += 1;
       } else {
+      pf_serial += 1;
+      if (no_m) pf_snom += 1; else if (lastop == 0 || first) pf_shead += 1; else pf_sirr += 1;
       int pf_head = -1, pf_tail = -1;
       if (valid && !simple && pc == 'M' && ref_at >= 1 && ref_at <= B) { const NodeG n = S.ldN((uint32_t)(ref_at - 1)); pf_head = n.head; pf_tail = n.pred; }
       unsigned long long todo = __ballot(valid && !simple);
+      // A stretch of 'X' / 'I' ops that retraces what an earlier member put down in one go (a long insertion shared by the reads of an allele:
+      // every step a dependent load of the node's list head and of that edge, ~2 us each, 64 of them per window).  A chain made in one go has
+      // consecutive node and edge ids, node u + j leaving through edge e + j + 1 at the head of its list.  So once the op of lane l has
+      // followed edge e into node u, the lanes behind it test that guess for their own step in parallel — two coalesced loads — and the
+      // longest prefix of steps whose test holds is taken at once: same edges, same weight increments, same end marks as one by one.
+      auto follow_chain = [&](const int l) {
+        if (LDS || as_edge < 0 || l >= 63) return;
+        const unsigned long long xi = __ballot(valid && (isX || isI)) >> (l + 1);
+        const int run = (int)__builtin_ctzll(~xi);           // ops of the stretch behind lane l
+        if (run < 4) return;
+        const int k = lane - l;                              // this lane's step, 1 .. run
+        const uint32_t nu = (uint32_t)prev + (uint32_t)(k - 1), ek = (uint32_t)as_edge + (uint32_t)k;
+        bool good = false; float w = 0.0f; uint32_t snk = 0;
+        if (k >= 1 && k <= run && nu < n_nodes && ek < n_edges && (int)nu >= B) {
+          const NodeG N = S.ldN(nu); const EdgeG E = S.ldE((int)ek);
+          good = N.head == (int)ek && E.sink == nu + 1u && (E.base & 0xffu) == (uint32_t)tb;
+          w = E.w; snk = E.sink;
+        }
+        const unsigned long long gm = __ballot(good) >> (l + 1);
+        const int m = (int)__builtin_ctzll(~gm);             // steps that go as guessed
+        if (m == 0) return;
+        if (k >= 1 && k <= m) {
+          S.stEw((int)ek, w + 1.0f);
+          if (B - (ref_at + (isX ? 1 : 0)) <= 10 && spr && snk < node_cap) isend[snk] = 1;
+        }
+        prev += m;
+        todo &= ~(((1ull << m) - 1ull) << (l + 1));
+        cn_id = 0xffffffffu;
+        pf_follow += (unsigned long long)m;
+      };
+      // The other long stretch: 'X' / 'I' ops that leave from the node made last, which has no successors yet — every one of them makes a
+      // node (an insertion at the head of a read starts at a start node of its own: ~200 ops per member at 2.7 us each where alleles differ
+      // by a few repeat units).  Made one by one, ids and edge ids are consecutive and each edge is the only one of its source: so the lanes
+      // of the stretch write their node, their edge and their part of the anchor's list side by side, as the one-lane-per-run code does
+      // for the chain of a run.  Returns false when the stretch is left to the loop (too short, no room: the loop reports that).
+      auto create_chain = [&](const int l) -> bool {
+        if (LDS || first || (uint32_t)prev != cn_id || cn_head >= 0) return false;
+        const unsigned long long xi = __ballot(valid && (isX || isI)) >> l;
+        const int run = ~xi ? (int)__builtin_ctzll(~xi) : 64;     // ops of the stretch from lane l on
+        if (run < 4 || n_nodes + (uint32_t)run > node_cap || n_edges + (uint32_t)run > edge_cap) return false;
+        const bool anc_ok = !(cur_anc < -1 || cur_anc >= B || (prev < B && prev != cur_anc));
+        const int k = lane - l;
+        if (k >= 0 && k < run) {
+          const uint32_t id = n_nodes + (uint32_t)k, src = k == 0 ? (uint32_t)prev : id - 1u;
+          const int ein = (int)(n_edges + (uint32_t)k);
+          const bool has_out = k + 1 < run;
+          nbase[id] = (uint8_t)tb;
+          EdgeG x; x.sink = id; x.w = 1.0f; x.next = -1; x.base = V2 ? ((uint32_t)tb | (src << 8)) : (uint32_t)tb;
+          S.stE(ein, x);
+          NodeG nn; nn.hw = 0.0f; nn.pred = has_out ? ein + 1 : -1; nn.indeg = V2 ? (uint32_t)(ein + 1) : 0u; nn.head = has_out ? ein + 1 : -1;
+          S.stN(id, nn);
+          if (k == 0) S.stList((uint32_t)prev, ein, ein);
+          if (V2) X.anext[ein] = (has_out && anc_ok) ? ein + 1 : -1;
+          if (B - (ref_at + (isX ? 1 : 0)) <= 10 && spr) isend[id] = 1;
+        }
+        if (V2) {
+          if (!anc_ok) tree_ok = false;
+          else {
+            const int e0 = (int)n_edges, t = X.atail[cur_anc + 1];
+            if (t >= 0) X.anext[t] = e0; else X.ahead[cur_anc + 1] = e0;
+            X.atail[cur_anc + 1] = e0 + run - 1;
+            X.acnt[cur_anc + 1] = X.acnt[cur_anc + 1] + (uint32_t)run;
+          }
+        }
+        n_nodes += (uint32_t)run; n_edges += (uint32_t)run;
+        prev = (int)n_nodes - 1;
+        cn_id = (uint32_t)prev; cn_head = -1; cn_tail = -1;
+        if (run > 1) todo &= ~(((1ull << (run - 1)) - 1ull) << (l + 1));
+        pf_follow += (unsigned long long)run;
+        return true;
+      };
       while (todo && !status) {
         const int l = (int)__builtin_ctzll(todo);
         todo &= todo - 1ull;
+        bool stepped = false;
+        if (P.prof) { const int o_ = __builtin_amdgcn_readlane(c, l); pf_sM += o_ == 'M'; pf_sX += o_ == 'X'; pf_sI += o_ == 'I'; pf_sD += o_ == 'D'; }
         const int op = __builtin_amdgcn_readlane(c, l), pop = __builtin_amdgcn_readlane(pc, l);
         const int r = __builtin_amdgcn_readlane(ref_at, l);
         const uint8_t tc = (uint8_t)__builtin_amdgcn_readlane(tb, l);
@@ -584,9 +704,11 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
             if (need_new) { prev = (int)new_node(tc); starts[n_start++] = (uint32_t)prev; cur_anc = -1; }
             first = false;
           } else if ((uint32_t)prev >= n_nodes) { status = 3; break; }
+          else if (create_chain(l)) continue;
           else {
             if (!have_lists) node_lists((uint32_t)prev, ph, pt);
             prev = (int)alt_step((uint32_t)prev, ph, pt, tc);
+            stepped = true;
           }
           ref_after = r + 1;
         } else if (op == 'D') {
@@ -595,15 +717,19 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
         } else if (op == 'I') {
           if (first) { prev = (int)new_node(tc); starts[n_start++] = (uint32_t)prev; first = false; cur_anc = -1; }
           else if ((uint32_t)prev >= n_nodes) { status = 3; break; }
+          else if (create_chain(l)) continue;
           else {
             if (!have_lists) node_lists((uint32_t)prev, ph, pt);
             prev = (int)alt_step((uint32_t)prev, ph, pt, tc);
+            stepped = true;
           }
         }
         if (B - ref_after <= 10 && spr && (uint32_t)prev < node_cap) isend[prev] = 1;   // ids not yet created are remembered too
+        if (stepped && !status) follow_chain(l);
       }
       }
       lastop = __builtin_amdgcn_readlane(c, nvalid - 1);
+      if (P.prof) tq_serial += wall_clock64() - ts0;
       ref_i += __builtin_popcountll(mMXD); tgt += __builtin_popcountll(mMXI);
       if (lastop == 'M') { prev = ref_i - 1; first = false; cur_anc = prev; }
       ci += nvalid;
@@ -835,6 +961,10 @@ __device__ __forceinline__ bool poa_graph_body(const PoaDev& P, const uint32_t g
     atomicAdd(P.prof + 0, t1 - t0); atomicAdd(P.prof + 1, t2 - t1); atomicAdd(P.prof + 2, t3 - t2); atomicAdd(P.prof + 3, 1ull);
     atomicAdd(P.prof + 4, (unsigned long long)n_nodes); atomicAdd(P.prof + 5, (unsigned long long)n_edges); atomicAdd(P.prof + 6, (unsigned long long)B);
     if (LDS) atomicAdd(P.prof + 7, 1ull);
+    atomicAdd(P.prof + 8, pf_wide); atomicAdd(P.prof + 9, pf_wide_ops); atomicAdd(P.prof + 10, pf_narrow); atomicAdd(P.prof + 11, pf_serial);
+    atomicMax(P.prof + 12, t1 - t0); atomicMax(P.prof + 13, t3 - t0);
+    if (P.prof_graph) { unsigned long long* q = P.prof_graph + 9 * (size_t)g; q[0] = t1 - t0; q[1] = pf_wide; q[2] = pf_narrow; q[3] = pf_serial; q[4] = tq_serial | (pf_follow << 40); q[5] = (unsigned long long)G.n_members | ((unsigned long long)B << 32); q[6] = pf_sM | (pf_sX << 32); q[7] = pf_sI | (pf_sD << 32); q[8] = pf_snom | (pf_shead << 20) | (pf_sirr << 40); }
+    atomicAdd(P.prof + 27, tq_layout); atomicAdd(P.prof + 28, tq_mid); atomicAdd(P.prof + 29, tq_a); atomicAdd(P.prof + 30, tq_turn); atomicAdd(P.prof + 31, tq_c); atomicAdd(P.prof + 20, tq_serial);
   }
   P.out_len[g] = len; P.out_start[g] = startpos; P.status[g] = status;
   return true;
@@ -1066,11 +1196,14 @@ int otg_launch_poa(otg_ctx* ctx, const uint8_t* d_seq_arena, const uint8_t* d_ci
   HIP_TRY(ctx, hipMemcpyAsync(d_woff + 3 * (size_t)(n_graphs + 1), wanch.data(), (size_t)(n_graphs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // host vectors go out of scope after return
   static const bool profile = getenv("OTG_POA_PROFILE") != nullptr;
-  P.prof = nullptr;
+  P.prof = nullptr; P.prof_graph = nullptr;
   if (profile) {
-    P.prof = (unsigned long long*)otg_slot(ctx, SLOT_P19, 8 * sizeof(unsigned long long));
+    P.prof_graph = (unsigned long long*)otg_slot(ctx, SLOT_P23, (size_t)n_graphs * 9 * sizeof(unsigned long long));
+    if (!P.prof_graph) return OTG_ERR_HIP;
+    HIP_TRY(ctx, hipMemsetAsync(P.prof_graph, 0, (size_t)n_graphs * 9 * sizeof(unsigned long long), ctx->stream));
+    P.prof = (unsigned long long*)otg_slot(ctx, SLOT_P19, 32 * sizeof(unsigned long long));
     if (!P.prof) return OTG_ERR_HIP;
-    HIP_TRY(ctx, hipMemsetAsync(P.prof, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(P.prof, 0, 32 * sizeof(unsigned long long), ctx->stream));
   }
   P.fb_list = (uint32_t*)otg_slot(ctx, SLOT_P22, (size_t)(n_graphs + 1) * sizeof(uint32_t));
   if (!P.fb_list) return OTG_ERR_HIP;
@@ -1088,12 +1221,32 @@ int otg_launch_poa(otg_ctx* ctx, const uint8_t* d_seq_arena, const uint8_t* d_ci
   }
   HIP_TRY(ctx, hipGetLastError());
   if (profile) {
-    unsigned long long h[8];
+    unsigned long long h[32];
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(h, P.prof, sizeof(h), hipMemcpyDeviceToHost));
     const double n = h[3] ? (double)h[3] : 1.0;     // wall_clock64: 100 MHz
     fprintf(stderr, "[otg] poa profile: %u LDS + %u global launches; %llu graphs done (%llu in LDS, %u bytes each), per graph: insert %.1f us, sweep %.1f us, emit %.1f us; nodes %.0f (backbone %.0f), edges %.0f\n",
             n_lds, n_glob, h[3], h[7], lds_bytes, h[0] / n / 100.0, h[1] / n / 100.0, h[2] / n / 100.0, h[4] / n, h[6] / n, h[5] / n);
+    fprintf(stderr, "[otg] poa profile: threading chunks per graph: %.1f wide (%.0f ops each), %.1f narrow one-lane-per-run, %.1f serial; slowest graph: insert %.1f us, whole %.1f us\n",
+            h[8] / n, h[8] ? (double)h[9] / (double)h[8] : 0.0, h[10] / n, h[11] / n, h[12] / 100.0, h[13] / 100.0);
+    { const double nw = h[8] ? (double)h[8] : 1.0;
+      fprintf(stderr, "[otg] poa profile: a wide chunk, us: layout %.2f, bases + marks + staging %.2f, subtree walk %.2f, ids %.2f, chains %.2f; narrow + serial code per graph %.1f us\n",
+              h[27] / nw / 100.0, h[28] / nw / 100.0, h[29] / nw / 100.0, h[30] / nw / 100.0, h[31] / nw / 100.0, h[20] / n / 100.0); }
+    {
+      std::vector<unsigned long long> pg((size_t)n_graphs * 9);
+      HIP_TRY(ctx, hipMemcpy(pg.data(), P.prof_graph, pg.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      std::vector<uint32_t> idx(n_graphs);
+      for (uint32_t g = 0; g < n_graphs; ++g) idx[g] = g;
+      const size_t top = std::min<size_t>(5, n_graphs);
+      std::partial_sort(idx.begin(), idx.begin() + top, idx.end(), [&](uint32_t a, uint32_t b) { return pg[9 * (size_t)a] > pg[9 * (size_t)b]; });
+      for (size_t t = 0; t < top; ++t) {
+        const unsigned long long* q = &pg[9 * (size_t)idx[t]];
+        fprintf(stderr, "[otg] poa profile: slow graph %u: %llu members on a backbone of %llu, threading %.1f us = %llu wide + %llu narrow + %llu serial chunks; %.1f us in the narrow + serial code (%llu steps taken as a retraced chain)\n",
+                idx[t], q[5] & 0xffffffffull, q[5] >> 32, q[0] / 100.0, q[1], q[2], q[3], (q[4] & ((1ull << 40) - 1ull)) / 100.0, q[4] >> 40);
+        fprintf(stderr, "[otg] poa profile:   its serial code: %llu windows without an 'M', %llu member heads, %llu others; ops taken one by one: %llu M, %llu X, %llu I, %llu D\n",
+                q[8] & 0xfffffull, (q[8] >> 20) & 0xfffffull, q[8] >> 40, q[6] & 0xffffffffull, q[6] >> 32, q[7] & 0xffffffffull, q[7] >> 32);
+      }
+    }
   }
   return OTG_OK;
 }
