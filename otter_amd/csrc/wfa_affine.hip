@@ -1048,6 +1048,20 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
     HIP_TRY(ctx, hipMemcpy(h5, cnt + 64, sizeof(h5), hipMemcpyDeviceToHost));
     fprintf(stderr, "[otg] affine: register tiers take %u / %u / %u / %u / %u alignments, %u go to the HBM-row tiers (of which given up by a register tier: %u); tier A gives up %u, tier B %u\n",
             h5[1] - h5[0], h5[2] - h5[1], h5[3] - h5[2], h5[4] - h5[3], h5[5] - h5[4], h5[7], h5[7] - (h5[6] - h5[5]), h[9], h[11]);
+    const int32_t* dbg_bound = (const int32_t*)ctx->pool[SLOT_BT_POOL].p;
+    if (h5[7] && dbg_bound && bounded && reg_mask) {        // who left a register tier (the first few): lengths, free ends, bound
+      const uint32_t nshow = std::min<uint32_t>(h5[7], 24u);
+      std::vector<uint32_t> ids(nshow);
+      HIP_TRY(ctx, hipMemcpy(ids.data(), todo + 3 * (size_t)n_tasks, nshow * sizeof(uint32_t), hipMemcpyDeviceToHost));
+      for (uint32_t i = 0; i < nshow; ++i) {
+        otg_align_task t; int32_t U = 0, sc = 0;
+        HIP_TRY(ctx, hipMemcpy(&t, d_tasks + ids[i], sizeof(t), hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(&U, dbg_bound + ids[i], sizeof(U), hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(&sc, d_scores + ids[i], sizeof(sc), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[otg] affine:   left its register tier: task %u, pattern %u, text %u, ends-free %d (pattern begin / end %d / %d, text begin / end %d / %d), bound %d, score %d\n",
+                ids[i], t.pattern_len, t.text_len, t.endsfree, t.pattern_begin_free, t.pattern_end_free, t.text_begin_free, t.text_end_free, U, sc);
+      }
+    }
 #ifdef OTG_REG_TIMING
     unsigned long long tm[7];
     HIP_TRY(ctx, hipMemcpy(tm, cnt + 100, sizeof(tm), hipMemcpyDeviceToHost));

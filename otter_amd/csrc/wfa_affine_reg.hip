@@ -388,26 +388,20 @@ __global__ __launch_bounds__(NW == 1 ? 256 : NW * 64, WPEU) void wfa_affine_reg_
 
       OTG_TM(tm_pre);
       if (s == 0) {
-        // score 0: offset max(k, 0) on every start diagonal, no I / D wavefronts; everything is extended through the queue
+        // score 0: offset max(k, 0) on every start diagonal of the range, nothing elsewhere, no I / D wavefronts.  Written as "M[-2]" = that offset
+        // minus one, so that the sweep below makes M[0] out of it like any other score (mismatch term M[s-2] + 1, then the probes): an ends-free
+        // alignment can have thousands of start diagonals, and pushed through the queue one by one — as this branch once did — more than 384 of
+        // them sent the alignment to the HBM-row tier behind the register tiers (0.1 % of the alignments, 5 % of the time of a small batch).
         static_for<0, S2>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value;
           const int gi = NW == 1 ? i : i * NW + ww;
           if (gi < j0 || gi > j1) return;
           const int xE = 128 * gi + lane2, kE = kb + xE, kO = kE + 1;
           const int hE = kE > 0 ? kE : 0, vE = hE - kE, hO = kO > 0 ? kO : 0, vO = hO - kO;
           const bool validE = kE >= lo && kE <= hi && hE <= tl && vE <= pl, validO = kO >= lo && kO <= hi && hO <= tl && vO <= pl;
-          M2[0][i] = pack16(validE ? hE : NUL16, validO ? hO : NUL16);
-          const bool moreE = validE && vE < pl && hE < tl, moreO = validO && vO < pl && hO < tl;
-          if (ef) {
-            const bool fE = validE && !moreE && fin_ef(hE, vE), fO = validO && !moreO && fin_ef(hO, vO);
-            const unsigned long long fm = __ballot(fE || fO);
-            if (fm) { int kc = fE ? kE : (fO ? kO : NOCAND); kc = -otg_wave_max_i32(-kc); cand = imin(cand, kc); }
-          } else if (xe >= 128 * gi && xe < 128 * gi + 128) {
-            const int hx = __builtin_amdgcn_readlane((xe & 1) ? (validO && !moreO ? hO : -1) : (validE && !moreE ? hE : -1), (xe & 127) >> 1);
-            if (hx >= tl) cand = kend;
-          }
-          push2(moreE, moreO, __ballot(moreE), __ballot(moreO), xE, hE, hO);
+          M2[0][i] = pack16(validE ? hE - 1 : NUL16, validO ? hO - 1 : NUL16);
         });
-      } else {
+      }
+      {
         // ---- the sweep over the touched pair-slots, ascending
         uint32_t carryI = NN;                     // X_I of lane 63 of the slot left of the current one, from before that slot's update (NW == 1)
         uint32_t XDc = NN;                        // X_D of the next slot, computed one visit ahead (NW == 1)
@@ -519,6 +513,7 @@ __global__ __launch_bounds__(NW == 1 ? 256 : NW * 64, WPEU) void wfa_affine_reg_
           if ((mmE | mmO) != 0ull) push2(lane_in(mmE, lane), lane_in(mmO, lane), mmE, mmO, xE, hE, hO);
         });
       }
+      if (s == 0) static_for<0, S2>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; M4[0][i] = NN; opaque_v(M4[0][i]); });     // (what stood in for M[-2])
       OTG_TM(tm_sweep);
 #ifdef OTG_REG_TIMING
       tm_n += 1; tm_vis += (unsigned long long)(NW == 1 ? (j1 - j0 + 1) : ((j1 - ww + NW) / NW - (j0 - ww + NW - 1) / NW));
