@@ -23,6 +23,7 @@ CASES = [
     ("OTG_NO_EDIT_ROUTE OTG_NO_EDIT_SORT", ["tests/test_gpu_edit.py"]),
     ("OTG_NO_EDIT_SAMPLE", ["tests/test_gpu_edit.py"]),
     ("OTG_POA_V1 OTG_POA_NO_LDS", ["tests/test_gpu_poa.py", "tests/test_gpu_pipeline.py::test_ont_kb"]),   # first-generation POA (serial threading, Kahn sweep), global memory only
+    ("OTG_POA_NO_LDS", ["tests/test_gpu_poa.py"]),                                       # second-generation POA on every graph (the op-string fuzz and the insertion stretches in global memory)
     ("OTG_POA_PIECE_MB=1", ["tests/test_gpu_poa.py", "tests/test_gpu_pipeline.py::test_ont_kb"]),         # graph images in many small pieces that reuse the work arrays
     ("OTG_NO_REASSIGN_REV", ["tests/test_gpu_pipeline.py::test_haps_mode", "tests/test_gpu_pipeline.py::test_ont_kb"]),
 ]

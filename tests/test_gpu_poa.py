@@ -168,3 +168,79 @@ def test_poa_crowded_anchors_and_long_jumps(gpu, oracle):
         c = np.float32(n * 0.4) if n >= 4 else np.float32(1.0)
         specs.append((bb, mem, c, np.float32(0.3)))
     _check(gpu, oracle, specs)
+
+
+def test_poa_shared_and_private_insertions(gpu, oracle):
+    """Long stretches of X / I ops on graphs in global memory — the lane-parallel paths of the wave-uniform code (csrc/poa.hip: a stretch that
+    makes a fresh chain, a stretch that retraces a chain an earlier member made): members of one allele share insertions at the head of the read,
+    inside it and next to the end of the backbone (where nodes become ending nodes), some copy them exactly (a retraced chain), some diverge in the
+    middle of one (retrace, then a fresh chain), some carry substitutions inside the stretch, lengths straddle the 64-op windows; spanning and
+    non-spanning members.  Reference: PPOA::insert_alignment (src/anppoa.hpp:112-241)."""
+    from helpers import rand_seq
+    rng = np.random.default_rng(46)
+    other = {65: b"CGT", 67: b"AGT", 71: b"ACT", 84: b"ACG"}
+    specs = []
+    for g in range(36):
+        B = int(rng.integers(700, 1900))
+        bb = rand_seq(rng, B)
+        templates = []
+        for _ in range(int(rng.integers(1, 4))):
+            ev = {}
+            if rng.random() < 0.8:
+                ev[0] = ("I", rand_seq(rng, int(rng.choice([3, 4, 5, 63, 64, 65, 130, 300]))))
+            for _ in range(int(rng.integers(2, 9))):
+                pos = int(rng.integers(1, B - 1))
+                kind = rng.choice(["I", "X", "D", "IX"])
+                if kind == "I":
+                    ev[pos] = ("I", rand_seq(rng, int(rng.choice([4, 40, 70, 129, 200]))))
+                elif kind == "X":
+                    n = int(min(rng.choice([1, 5, 70]), B - pos))
+                    ev[pos] = ("X", bytes(other[bb[pos + j]][int(rng.integers(0, 3))] for j in range(n)))
+                elif kind == "D":
+                    ev[pos] = ("D", int(min(rng.choice([1, 6, 80]), B - pos)))
+                else:   # an insertion with substitutions on both sides of it
+                    ev[pos] = ("IX", rand_seq(rng, int(rng.choice([8, 66, 140]))))
+            if rng.random() < 0.6:
+                ev[B - int(rng.integers(0, 12))] = ("I", rand_seq(rng, int(rng.choice([2, 9, 70]))))     # at / next to the end of the backbone
+            templates.append(ev)
+        mem = []
+        for _ in range(int(rng.integers(4, 14))):
+            ev = dict(templates[int(rng.integers(0, len(templates)))])
+            for pos in list(ev):
+                kind, val = ev[pos]
+                if kind in ("I", "IX") and rng.random() < 0.35:
+                    val = bytearray(val)
+                    cut = int(rng.integers(0, len(val)))
+                    if rng.random() < 0.5:
+                        val = val[:max(cut, 1)]                                  # a shorter copy: retraces a prefix of the chain
+                    else:
+                        val[cut] = other[val[cut]][0]                             # diverges in the middle: retrace, then a fresh chain
+                    ev[pos] = (kind, bytes(val))
+            ops, seq, ref = [], bytearray(), 0
+            while ref <= B:
+                e = ev.get(ref)
+                if e and e[0] in ("I", "IX"):
+                    if e[0] == "IX" and ref < B:
+                        ops.append("X"); seq.append(other[bb[ref]][0]); ref += 1
+                        if ref > B:
+                            break
+                    ops.append("I" * len(e[1])); seq += e[1]
+                    if e[0] == "IX" and ref < B:
+                        ops.append("X"); seq.append(other[bb[ref]][1]); ref += 1
+                        continue
+                if ref >= B:
+                    break
+                if e and e[0] == "X":
+                    n = min(len(e[1]), B - ref)
+                    ops.append("X" * n); seq += e[1][:n]; ref += n
+                elif e and e[0] == "D":
+                    n = min(e[1], B - ref)
+                    ops.append("D" * n); ref += n
+                else:
+                    ops.append("M"); seq.append(bb[ref]); ref += 1
+            cig = "".join(ops).encode()
+            assert cig.count(b"M") + cig.count(b"X") + cig.count(b"D") == B and cig.count(b"M") + cig.count(b"X") + cig.count(b"I") == len(seq)
+            mem.append((bytes(seq), cig, bool(rng.random() < 0.85), bool(rng.random() < 0.85)))
+        n = len(mem)
+        specs.append((bb, mem, np.float32(n * 0.4) if n >= 4 else np.float32(1.0), np.float32(0.3)))
+    _check(gpu, oracle, specs)
