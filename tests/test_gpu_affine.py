@@ -217,3 +217,30 @@ def test_affine_probe_boundaries(gpu, oracle):
     assert np.array_equal(gs, es), [(i, int(gs[i]), int(es[i])) for i in np.flatnonzero(gs != es)[:8]]
     bad = [(i, len(pairs[i][0]), len(pairs[i][1])) for i in range(len(pairs)) if gc[i] != ec[i]]
     assert not bad, bad[:8]
+
+
+def test_affine_wide_free_begin(gpu, oracle):
+    """Right-spanning partial reads against their allele's representative (rapid_consensus, src/analignments.cpp:261-292): the read is a suffix of
+    the pattern and the pattern's begin is free over hundreds to thousands of bases, so score 0 has that many start diagonals.  (The register tiers
+    used to push every one of them through a 512-entry queue and hand the alignment to the HBM-row tier when they did not fit.)  Both orientations,
+    free ends on the text side too, and the two-sided form."""
+    rng = np.random.default_rng(29)
+    pairs, forms = [], []
+    for i in range(40):
+        L = int(rng.integers(1800, 4700))
+        a = mutate(rng, tr_seq(rng, L), 0.07)
+        cut = int(rng.integers(400, L - 700))
+        b = mutate(rng, a[cut:], 0.07)
+        k = i % 5
+        if k == 0: pairs.append((a, b)); forms.append((cut, 0, 0, 0))                       # pattern begin free = exactly the missing prefix
+        elif k == 1: pairs.append((a, b)); forms.append((cut + 150, 0, 0, 0))               # ... with slack
+        elif k == 2: pairs.append((b, a)); forms.append((0, 0, cut + 40, 0))                # the same on the text side
+        elif k == 3: pairs.append((a, mutate(rng, a[:L - cut], 0.07))); forms.append((0, cut + 25, 0, 0))     # a prefix: pattern end free
+        else: pairs.append((a, b)); forms.append((cut + 60, 0, 30, 0))                      # both begins free
+    arena, tasks = pair_tasks(pairs, forms)
+    gs, gc, gcells = gpu.affine_align_batch(arena, tasks, want_cells=True)
+    es, ec, ecells = oracle.affine_align_batch(arena, tasks, want_cells=True)
+    assert np.array_equal(gs, es), [(i, int(gs[i]), int(es[i])) for i in np.flatnonzero(gs != es)[:8]]
+    bad = [i for i in range(len(pairs)) if gc[i] != ec[i]]
+    assert not bad, bad[:10]
+    assert np.array_equal(gcells, ecells)
