@@ -175,6 +175,7 @@ __global__ __launch_bounds__(WPB * 64) void myers_edit_kernel(
 
     // ---- skewed sweep
     int B = gl;                         // current superblock of this lane
+    if (!unsupported) while (B < nsb && SB * B + SB - 1 + KL < 0) B += GL;      // (KL < 0: the band starts below diagonal 0, the superblocks above it never enter it)
     bool inited = false;
     u64 Pv[BPL], Mv[BPL];
 #pragma unroll

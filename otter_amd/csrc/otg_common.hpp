@@ -105,15 +105,19 @@ __device__ __forceinline__ int otg_wave_max_i32(int v)
 // Band of the bit-parallel edit tiers (myers_edit.hip) for a cost threshold K.  Rows i (pattern), columns j (text),
 // d = m - n >= 0; the alignment starts on a diagonal e0 in [0, pbf] and ends on e1 in [d - pef, d].  A path of cost
 // <= K that visits diagonal e pays at least |e - e0| + |e - e1| indels and needs |e0 - e1| <= K, hence
-//   e <= KU = min((K + d + pbf) / 2, K + pbf)      and      e >= -KL, KL = max(0, min((K - d + pef) / 2, K)).
+//   e <= KU = min((K + d + pbf) / 2, K + pbf)      and      e >= -KL,
+//   KL = min((K - d + pef) / 2, K) while the alignment may start on diagonal 0 (K >= d - pef), and beyond that — a start on diagonal 0 would
+//   cost more than K, so e0 >= d - pef - K and the lowest diagonal any path can visit is that one — KL = K - (d - pef) < 0: the band's
+//   lower edge lies ABOVE diagonal 0.  (A read that covers only the end of its pattern, d = pbf = 1500, K = 300: 450 diagonals instead of
+//   1650 — the reassignment pass of a batch with clipped reads ran on tiers four times as wide as its alignments needed.)
 __device__ __forceinline__ void otg_myers_band(int K, int d, int pbf, int pef, int* KL, int* KU)
 {
   const int u1 = (K + d + pbf + 1) / 2, u2 = K + pbf;
   *KU = u1 < u2 ? u1 : u2;
   int l = (K - d + pef + 1) / 2;
   if (l > K) l = K;
-  if (K - d + pef < 0) l = 0;
-  *KL = l < 0 ? 0 : l;
+  if (K - d + pef < 0) l = K - d + pef;
+  *KL = l;
 }
 // Largest threshold K whose band fits R rows of lane schedule (KL + KU <= R, monotone in K).
 // W_p of SURVEY.md §8d in closed form: wavefront cells an edit-distance WFA evaluates up to score s when the wavefront of score t spans
