@@ -201,7 +201,7 @@ void reg2bins(int64_t beg, int64_t end, std::vector<uint32_t>& out)
 struct Rec {
   int32_t tid, pos, l_seq;
   uint32_t mapq, flag, n_cigar;
-  const uint32_t* cigar;       // may be unaligned: read with rd32
+  const uint8_t* cigar;        // n_cigar 32-bit words at any alignment: only ever read through rd32 (cig_op / cig_len)
   const uint8_t* seq;
   const uint8_t* aux;
   const uint8_t* aux_end;
@@ -234,17 +234,18 @@ int read_record(otg_bam* b, Rec* r)
   const uint8_t* q = p + 32 + l_name;
   r->name = (const char*)p + 32;
   r->l_name = l_name ? (uint32_t)strnlen((const char*)p + 32, l_name) : 0;
-  r->cigar = (const uint32_t*)q;
+  r->cigar = q;
   r->seq = q + 4 * (size_t)r->n_cigar;
   r->aux = r->seq + ((size_t)r->l_seq + 1) / 2 + (size_t)r->l_seq;
   r->aux_end = p + block_len;
   // Alignments with more than 65535 CIGAR operations (ultra-long reads) carry a placeholder `<l_seq>S<rlen>N` and the real CIGAR in the
   // tag CG:B,I; the reference's bam_read1 moves it into place (bam_tag2cigar, src/sam.c:243-285).  Same test, the ops are read in place.
-  if (r->n_cigar != 0 && r->tid >= 0 && r->pos >= 0 && cig_op((const uint8_t*)r->cigar, 0) == 4 && cig_len((const uint8_t*)r->cigar, 0) == r->l_seq) {
+  if (r->n_cigar != 0 && r->tid >= 0 && r->pos >= 0 && cig_op(r->cigar, 0) == 4 && cig_len(r->cigar, 0) == r->l_seq) {
     const uint8_t* cg = aux_get(*r, 'C', 'G');
     if (cg && cg[0] == 'B' && cg[1] == 'I') {
       const uint32_t n = rd32(cg + 2);
-      if (n != 0) { r->cigar = (const uint32_t*)(cg + 6); r->n_cigar = n; }      // bounds were checked by aux_get
+      // bam_tag2cigar's own condition: a CG array shorter than the placeholder, or absurdly long, leaves the placeholder in place
+      if (n >= r->n_cigar && n < (1u << 29)) { r->cigar = cg + 6; r->n_cigar = n; }      // (bounds were checked by aux_get)
     }
   }
   return 1;
@@ -254,7 +255,7 @@ int read_record(otg_bam* b, Rec* r)
 int cigar_rlen(const Rec& r)
 {
   int l = 0;
-  const uint8_t* c = (const uint8_t*)r.cigar;
+  const uint8_t* c = r.cigar;
   for (uint32_t k = 0; k < r.n_cigar; ++k) { const int op = cig_op(c, k); if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) l += cig_len(c, k); }
   return l;
 }
@@ -321,7 +322,7 @@ void get_breakpoints(int start, int end, const Rec& r, ParseMsg& msg, bool& have
   int leftmost_q = -1, rightmost_q = -1, leftmost_r = -1, rightmost_r = -1;
   int qstart_q = -1, qend_q = -1;
   uint32_t qstart_cigar_i = 0, qend_cigar_i = 0;
-  const uint8_t* cg = (const uint8_t*)r.cigar;
+  const uint8_t* cg = r.cigar;
   int rpos = r.pos, qpos = 0;
   for (uint32_t i = 0; i < r.n_cigar; ++i) {
     const int op = cig_op(cg, i), ol = cig_len(cg, i);
@@ -880,7 +881,7 @@ extern "C" int otg_wgat(otg_bam* b, const otg_bed* beds, const char* chr_arena, 
     // bam_itr_querys("chr:1-len"): every alignment that overlaps [0, len)
     const int rc = scan_region(b, local, (int)tid, 0, (long long)b->lengths[tid], bins, chunks, err, [&](const Rec& r) {
       if (r.l_seq <= 0) return;
-      const uint8_t* cg = (const uint8_t*)r.cigar;
+      const uint8_t* cg = r.cigar;
       const int ref_end = r.pos + cigar_rlen(r);
       hits.clear();
       bed_tree.overlapping(r.pos, ref_end, hits);

@@ -239,3 +239,36 @@ def test_python_bam_writer_is_read_alike_by_both_readers(tmp_path):
         _same(bamh.ingest(regions, **kw), ref)
         _same(bamh.ingest(regions, threads=4, **kw), ref)
     bamh.close()
+
+
+def test_ingest_short_cg_tag_leaves_the_placeholder(tmp_path):
+    """bam_tag2cigar (src/sam.c:243-285) only moves a CG:B,I array into place when it is at least as long as the placeholder CIGAR and shorter than
+    2^29 entries; a record whose CG tag is shorter than its two-operation placeholder keeps `<l_seq>S<rlen>N` — no aligned base, nothing to take
+    from it.  (The reference's own region walk reads out of range on such a record — it segfaults in the reference build here — so the pin is the
+    rule itself: a record with a one-operation CG, and one without the tag, must change nothing; a reader that took any non-empty CG array would
+    use the first as `300M`.)"""
+    import struct
+    from otter_amd import bamwrite
+    rng = np.random.default_rng(9)
+    def seq(n):
+        return bytes(b"ACGT"[int(x)] for x in rng.integers(0, 4, n))
+    def cg(ops):
+        return b"CGBI" + struct.pack("<I", len(ops)) + b"".join(struct.pack("<I", (l << 4) | o) for l, o in ops)
+    plain = (0, 1005, "plain", 0, 60, "280M", seq(280), b"")
+    real = (0, 1000, "real", 0, 60, "300S260N", seq(300), cg([(20, 4), (260, 0), (20, 4)]))
+    short_cg = (0, 1000, "short_cg", 0, 60, "300S260N", seq(300), cg([(300, 0)]))
+    no_cg = (0, 1000, "no_cg", 0, 60, "300S260N", seq(300), b"")
+    regions = [("chr1", 1050, 1150), ("chr1", 990, 1010), ("chr1", 1200, 1262)]
+    def run(name, recs):
+        bam = str(tmp_path / (name + ".bam"))
+        assert bamwrite.write_bam(bam, [("chr1", 100000)], recs) == len(recs)
+        bamh = otter_amd.Bam(bam)
+        out = bamh.ingest(regions), bamh.ingest(regions, offset_l=1, offset_r=1, threads=2)
+        bamh.close()
+        return out
+    base = run("base", [real, plain])
+    assert base[0]["regions"]["n_reads"].tolist() == [2, 2, 2]            # the real CIGAR of the tag is used
+    assert run("plain", [plain])[0]["regions"]["n_reads"].tolist() == [1, 1, 1]
+    with_junk = run("junk", [real, short_cg, no_cg, plain])
+    for a, b in zip(base, with_junk):
+        _same(a, b)
