@@ -247,6 +247,8 @@ def roofline(kstats, cfg, n_regions):
                           "source": pm.get("source")}
         if out.get("impl_min_bytes") and out["traffic"]:
             out["traffic_over_impl_min"] = round(float(out["traffic"]) / out["impl_min_bytes"], 2)
+        if out["traffic"] and kms > 0:       # the physical HBM fraction: bytes the counters saw / chain time / peak
+            out["traffic_frac_of_hbm_peak"] = round(float(out["traffic"]) / (kms / kl * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     return out
 
 
