@@ -343,9 +343,10 @@ int launch_one(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_task* d_tas
 
 // One tier of the bit-parallel engine: tasks from (d_todo, d_n_todo) (or all n_tasks when d_todo is null);
 // tasks it cannot finish exactly are appended to overflow_list / n_overflow.
-// tier: 0 = 8-lane groups x 1 block per lane (8 pairs / wave); 1..4 = 8 / 16 / 32 / 64-lane groups x 2 blocks per lane
-//       (two blocks share the per-column overhead of a lane: ~19 % fewer instructions per row than one block per lane);
-//       5 = whole wave x 4 blocks per lane.
+// tier (OTG_MYERS_TIERS of them): 0 = 8-lane groups x 1 block per lane (8 pairs / wave); then 8 / 16 / 32 / 64-lane groups x 2 blocks per lane
+//       (two blocks share the per-column overhead of a lane: ~19 % fewer instructions per row than one block per lane), with a three-block step
+//       between the 8- and 16-lane and between the 16- and 32-lane ones (<3,8> = 1352 rows at 0.7 x the cost of <2,16>, <3,16> = 2896 rows at
+//       0.7 x the cost of <2,32>: a pair pays for the band of its tier, not for its own); last = whole wave x 4 blocks per lane.
 int otg_launch_myers(otg_ctx* ctx, int tier, const uint8_t* d_arena, const otg_align_task* d_tasks, const uint32_t* d_todo,
                      const uint32_t* d_n_todo, uint32_t n_tasks, int32_t* d_scores, uint64_t* d_cells,
                      uint32_t* ticket, uint32_t* n_overflow, uint32_t* overflow_list)
@@ -354,9 +355,11 @@ int otg_launch_myers(otg_ctx* ctx, int tier, const uint8_t* d_arena, const otg_a
   switch (tier) {
     case 0: rc = launch_one<1, 8>(ctx, d_arena, d_tasks, d_todo, d_n_todo, n_tasks, d_scores, d_cells, ticket, n_overflow, overflow_list); break;
     case 1: rc = launch_one<2, 8>(ctx, d_arena, d_tasks, d_todo, d_n_todo, n_tasks, d_scores, d_cells, ticket, n_overflow, overflow_list); break;
-    case 2: rc = launch_one<2, 16>(ctx, d_arena, d_tasks, d_todo, d_n_todo, n_tasks, d_scores, d_cells, ticket, n_overflow, overflow_list); break;
-    case 3: rc = launch_one<2, 32>(ctx, d_arena, d_tasks, d_todo, d_n_todo, n_tasks, d_scores, d_cells, ticket, n_overflow, overflow_list); break;
-    case 4: rc = launch_one<2, 64>(ctx, d_arena, d_tasks, d_todo, d_n_todo, n_tasks, d_scores, d_cells, ticket, n_overflow, overflow_list); break;
+    case 2: rc = launch_one<3, 8>(ctx, d_arena, d_tasks, d_todo, d_n_todo, n_tasks, d_scores, d_cells, ticket, n_overflow, overflow_list); break;
+    case 3: rc = launch_one<2, 16>(ctx, d_arena, d_tasks, d_todo, d_n_todo, n_tasks, d_scores, d_cells, ticket, n_overflow, overflow_list); break;
+    case 4: rc = launch_one<3, 16>(ctx, d_arena, d_tasks, d_todo, d_n_todo, n_tasks, d_scores, d_cells, ticket, n_overflow, overflow_list); break;
+    case 5: rc = launch_one<2, 32>(ctx, d_arena, d_tasks, d_todo, d_n_todo, n_tasks, d_scores, d_cells, ticket, n_overflow, overflow_list); break;
+    case 6: rc = launch_one<2, 64>(ctx, d_arena, d_tasks, d_todo, d_n_todo, n_tasks, d_scores, d_cells, ticket, n_overflow, overflow_list); break;
     default: rc = launch_one<4, 64>(ctx, d_arena, d_tasks, d_todo, d_n_todo, n_tasks, d_scores, d_cells, ticket, n_overflow, overflow_list); break;
   }
   if (rc) return rc;

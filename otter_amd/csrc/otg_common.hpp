@@ -32,6 +32,7 @@ struct otg_ctx {
   // side streams of the gap-affine chain: on small batches the register tiers run next to each other (wfa_affine.hip); created on first use
   hipStream_t tier_stream[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  int edit_sparse_pass = 0;                       // set around an edit-distance pass whose todo list is a small share of its task slots (the reassignment pass)
   double last_kernel_ms = 0.0;                    // HIP-event time of the kernels of the latest operator-level call that reports one (otg_last_kernel_ms)
   unsigned long long* affine_visited = nullptr;   // device counter: (score, diagonal) cells the exact gap-affine tiers visited (wfa_affine.hip)
 };
@@ -190,6 +191,8 @@ __device__ __forceinline__ int otg_wave_match(const uint8_t* P, const uint8_t* T
 int otg_launch_edit(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_task* d_tasks, uint32_t n_tasks,
                     int32_t* d_scores, uint64_t* d_cells, float* kernel_ms, uint64_t* launches);
 
+// bit-parallel edit tiers (myers_edit.hip), narrowest first: <blocks per lane, lanes per pair> = <1,8> <2,8> <3,8> <2,16> <3,16> <2,32> <2,64> <4,64>
+constexpr int OTG_MYERS_TIERS = 8;
 int otg_launch_myers(otg_ctx* ctx, int tier, const uint8_t* d_arena, const otg_align_task* d_tasks, const uint32_t* d_todo,
                      const uint32_t* d_n_todo, uint32_t n_tasks, int32_t* d_scores, uint64_t* d_cells,
                      uint32_t* ticket, uint32_t* n_overflow, uint32_t* overflow_list);

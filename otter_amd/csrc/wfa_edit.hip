@@ -161,18 +161,18 @@ __device__ __forceinline__ u128 load16(const uint8_t* p)
 }
 
 // bit-parallel tier whose band holds an estimated distance `need` (same threshold function the tier itself applies)
-__device__ __forceinline__ int otg_route_tier(const otg_align_task& t, int need)
+__device__ __forceinline__ int otg_route_tier(const otg_align_task& t, int need, uint32_t tier_mask)
 {
   const int pl = (int)t.pattern_len, tl = (int)t.text_len;
   const bool ef = t.endsfree != 0;
-  int tier = 6;
+  int tier = OTG_MYERS_TIERS;           // (none fits: the wide wavefront tier)
   const bool swap = !ef && pl < tl;                       // the bit-parallel kernel puts the longer sequence in the rows
   const int dd = swap ? tl - pl : pl - tl;
   const int fb = ef ? (int)t.pattern_begin_free : 0, fe2 = ef ? (int)t.pattern_end_free : 0;
   if (dd >= 0) {
-    const int rows[6] = {456, 904, 1936, 4000, 8128, 16192};    // (GL-1)*64*BPL + GL of the six tiers (myers_edit.hip)
+    const int rows[OTG_MYERS_TIERS] = {456, 904, 1352, 1936, 2896, 4000, 8128, 16192};    // (GL-1)*64*BPL + GL of the tiers (myers_edit.hip)
 #pragma unroll
-    for (int q = 5; q >= 0; --q) if (need <= otg_myers_threshold(rows[q], dd, fb < dd ? fb : dd, fe2 < dd ? fe2 : dd)) tier = q;
+    for (int q = OTG_MYERS_TIERS - 1; q >= 0; --q) if (((tier_mask >> q) & 1u) && need <= otg_myers_threshold(rows[q], dd, fb < dd ? fb : dd, fe2 < dd ? fe2 : dd)) tier = q;
   }
   return tier;
 }
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_kernel_v2(
     const uint32_t* __restrict__ todo, const uint32_t* __restrict__ n_todo_ptr, uint32_t n_todo_imm,
     int32_t* __restrict__ scores, uint64_t* __restrict__ cells,
     uint32_t* __restrict__ ticket, uint32_t* __restrict__ n_overflow, uint32_t* __restrict__ overflow_list,
-    float cap_coeff, uint32_t* __restrict__ route_cnt, uint32_t* __restrict__ route_lists, uint32_t route_stride, float route_margin)
+    float cap_coeff, uint32_t* __restrict__ route_cnt, uint32_t* __restrict__ route_lists, uint32_t route_stride, float route_margin, uint32_t tier_mask)
 {
   extern __shared__ __attribute__((aligned(16))) int32_t smem[];
   const int lane = threadIdx.x & 63;
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_kernel_v2(
       // estimate is the cheapest choice (OTG_EDIT_ROUTE_MARGIN overrides, in percent)
       const int need = (int)(route_margin * (est + (ef ? 0.0f : (float)dlen)));
       // threshold of tier t for this pair's length difference and free ends (same function the tier itself uses)
-      const int tier = otg_route_tier(t, need);
+      const int tier = otg_route_tier(t, need, tier_mask);
       const uint32_t q = otg_wave_atomic_add(route_cnt + tier, 1u);
       route_lists[(size_t)tier * route_stride + q] = ti;
     } else if (overflow && overflow_list) {
@@ -438,11 +438,11 @@ __device__ __forceinline__ void otg_sample64(const uint8_t* P, int pl, const uin
   *dmin = best; *jmin = bj;
 }
 
-// route_cnt[0..6] / route_lists as in wfa_edit_kernel_v2; list 7 (count wf_cnt) = input of the wavefront pass
+// route_cnt[0..OTG_MYERS_TIERS] / route_lists as in wfa_edit_kernel_v2; one more list (count wf_cnt) = input of the wavefront pass
 __global__ __launch_bounds__(256) void edit_route_kernel(
     const uint8_t* __restrict__ arena, const otg_align_task* __restrict__ tasks, const uint32_t* __restrict__ todo,
     const uint32_t* __restrict__ n_todo_ptr, uint32_t n_todo_imm, float cap_coeff, uint32_t* __restrict__ route_cnt,
-    uint32_t* __restrict__ route_lists, uint32_t route_stride, float route_margin, uint32_t* __restrict__ wf_cnt, uint32_t* __restrict__ wf_list)
+    uint32_t* __restrict__ route_lists, uint32_t route_stride, float route_margin, uint32_t* __restrict__ wf_cnt, uint32_t* __restrict__ wf_list, uint32_t tier_mask)
 {
   const uint32_t n_todo = n_todo_ptr ? *n_todo_ptr : n_todo_imm;
   const int lane = threadIdx.x & 63;
@@ -451,12 +451,12 @@ __global__ __launch_bounds__(256) void edit_route_kernel(
     const uint32_t tk = base + threadIdx.x;
     const bool act = tk < n_todo;
     uint32_t ti = 0;
-    int tier = -1;                      // -1: not active; 0..6: list of that tier; 7: wavefront pass
+    int tier = -1;                      // -1: not active; 0..OTG_MYERS_TIERS: list of that tier; OTG_MYERS_TIERS + 1: wavefront pass
     if (act) {
       ti = todo ? todo[tk] : tk;
       const otg_align_task t = tasks[ti];
       const int pl = (int)t.pattern_len, tl = (int)t.text_len;
-      tier = 7;
+      tier = OTG_MYERS_TIERS + 1;
       // an end that is free on either sequence cannot anchor a sample: use the other end alone, or leave the pair to the wavefront pass
       const bool ef = t.endsfree != 0;
       const bool fwd_ok = !ef || (t.pattern_begin_free == 0 && t.text_begin_free == 0);
@@ -482,19 +482,19 @@ __global__ __launch_bounds__(256) void edit_route_kernel(
         if (cap < 48) cap = 48;
         const int need = (int)(route_margin * (est + (float)dlen));
         // near-identical pairs (projected distance within the wavefront pass's score cap) are finished there
-        if ((int)est + dlen > cap) tier = otg_route_tier(t, need);
+        if ((int)est + dlen > cap) tier = otg_route_tier(t, need, tier_mask);
       }
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < OTG_MYERS_TIERS + 2; ++q) {
       const unsigned long long m = __ballot(tier == q);
       if (m) {
-        uint32_t* c = q == 7 ? wf_cnt : route_cnt + q;
+        uint32_t* c = q == OTG_MYERS_TIERS + 1 ? wf_cnt : route_cnt + q;
         uint32_t b0 = 0;
         if (lane == (int)__builtin_ctzll(m)) b0 = atomicAdd(c, (uint32_t)__builtin_popcountll(m));
         b0 = (uint32_t)__builtin_amdgcn_readlane((int)b0, (int)__builtin_ctzll(m));
         if (tier == q) {
-          uint32_t* l = q == 7 ? wf_list : route_lists + (size_t)q * route_stride;
+          uint32_t* l = q == OTG_MYERS_TIERS + 1 ? wf_list : route_lists + (size_t)q * route_stride;
           l[b0 + (uint32_t)__builtin_popcountll(m & lt)] = ti;
         }
       }
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(256) void K_sort_scatter(const uint32_t* __restrict
 } // namespace
 
 // Enqueue the tier chain: wavefront tier 1 (LDS, score-capped) -> bit-parallel tiers 0..4 -> wavefront tier 2 -> global.  Requires: d_arena padded with >= 8 readable bytes after the last
-// sequence byte.  Uses SLOT_COUNTERS (16 u32), SLOT_TODO (8*n_tasks u32), SLOT_WF_WS (tier 3 only).
+// sequence byte.  Uses SLOT_COUNTERS (64 u32), SLOT_TODO ((OTG_MYERS_TIERS + 4) * n_tasks u32), SLOT_WF_WS (last tier only).
 int otg_launch_edit(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_task* d_tasks, uint32_t n_tasks,
                     int32_t* d_scores, uint64_t* d_cells, float* kernel_ms, uint64_t* launches)
 {
@@ -577,17 +577,23 @@ int otg_launch_edit_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_t
 {
   if (n_tasks == 0) return OTG_OK;
   uint32_t* cnt = (uint32_t*)otg_slot(ctx, SLOT_COUNTERS, 64 * sizeof(uint32_t));
-  uint32_t* todo = (uint32_t*)otg_slot(ctx, SLOT_TODO, 10 * (size_t)n_tasks * sizeof(uint32_t));
+  constexpr int NT = OTG_MYERS_TIERS;
+  uint32_t* todo = (uint32_t*)otg_slot(ctx, SLOT_TODO, (size_t)(NT + 4) * n_tasks * sizeof(uint32_t));
   if (!cnt || !todo) return OTG_ERR_HIP;
   HIP_TRY(ctx, hipMemsetAsync(cnt, 0, 8 * sizeof(uint32_t), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(cnt + 16, 0, 16 * sizeof(uint32_t), ctx->stream));
-  // lists[t] (t = 0..5) feed the bit-parallel tiers, lists[6] the wide wavefront tier, listG its overflow.  The
+  // lists[t] (t = 0..NT-1) feed the bit-parallel tiers, lists[NT] the wide wavefront tier, listG its overflow.  The
   // first kernel routes every pair it cannot finish to the tier matching its estimated distance; a tier that is too
   // narrow appends the pair to the next list.  cnt[32 + t] = length of lists[t].
   uint32_t* const lists = todo;
-  uint32_t* listG = todo + 7 * (size_t)n_tasks;
+  uint32_t* listG = todo + (size_t)(NT + 1) * n_tasks;
   uint32_t* const rc = cnt + 32;
-  HIP_TRY(ctx, hipMemsetAsync(rc, 0, 8 * sizeof(uint32_t), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(rc, 0, 16 * sizeof(uint32_t), ctx->stream));      // rc[0 .. NT], then (cnt + 44 ..) the counters of the sampling router
+  // The two three-block tiers pay on a full device (a pair pays for the band of its tier: <3,8> and <3,16> take what would run on tiers 1.45 x
+  // as costly — edit stage 723 -> 664 ms on the 1-10 kb shard) and cost a launch each — sort + a kernel that lasts as long as its longest pair —
+  // on a sparse list (a batch of 1 000 regions, the reassignment pass: +2.4 ms each): only passes with millions of pairs get them.
+  static const int tiers_env = getenv("OTG_EDIT_TIERS") ? atoi(getenv("OTG_EDIT_TIERS")) : 0;      // test switch: the tiers that run, as a bit mask (tier 0 and the last always do)
+  const uint32_t tier_mask = tiers_env ? (((uint32_t)tiers_env & 0xFFu) | 0x81u) : ((n_tasks >= 2000000u && !ctx->edit_sparse_pass) ? 0xFFu : 0xEBu);
   static const bool no_myers = getenv("OTG_NO_MYERS") != nullptr;
   static const bool no_route = getenv("OTG_NO_EDIT_ROUTE") != nullptr;
   // a tier that turns out too narrow costs about half of going one tier up straight away, so the cheapest choice sits a little below
@@ -603,8 +609,8 @@ int otg_launch_edit_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_t
       constexpr int CAP = 2048;                                // 2 x 2048 x u16 = 8 KB per wave -> 20 waves / CU
       uint32_t grid = std::min<uint32_t>((uint32_t)ctx->n_cu * 5, want);
       hipLaunchKernelGGL((wfa_edit_kernel_v2<CAP, WPB>), dim3(grid), dim3(WPB * 64), (size_t)CAP * 2 * WPB * sizeof(uint16_t), ctx->stream, d_arena, d_tasks,
-                         d_todo, d_n_todo, n_tasks, d_scores, d_cells, cnt + 0, rc + 6, lists + 6 * (size_t)n_tasks, 0.0f,
-                         (uint32_t*)nullptr, lists, n_tasks, route_margin);
+                         d_todo, d_n_todo, n_tasks, d_scores, d_cells, cnt + 0, rc + NT, lists + (size_t)NT * n_tasks, 0.0f,
+                         (uint32_t*)nullptr, lists, n_tasks, route_margin, tier_mask);
     } else {
       constexpr int CAP = 1024;
       uint32_t grid = std::min<uint32_t>((uint32_t)ctx->n_cu * 8, want);
@@ -612,28 +618,30 @@ int otg_launch_edit_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_t
       static const bool no_sample = getenv("OTG_NO_EDIT_SAMPLE") != nullptr;
       if (!no_route && !no_sample) {
         // tier choice from two 64-base samples per pair (one pair per lane); only what it leaves goes through the wavefront pass
-        uint32_t* wf_list = todo + 9 * (size_t)n_tasks;
-        HIP_TRY(ctx, hipMemsetAsync(cnt + 40, 0, 4 * sizeof(uint32_t), ctx->stream));
+        uint32_t* wf_list = todo + (size_t)(NT + 3) * n_tasks;
         const uint32_t rg = std::min<uint32_t>((n_tasks + 255) / 256, (uint32_t)ctx->n_cu * 16);
         hipLaunchKernelGGL(edit_route_kernel, dim3(rg), dim3(256), 0, ctx->stream, d_arena, d_tasks, d_todo, d_n_todo, n_tasks, 1.0f, rc, lists,
-                           n_tasks, route_margin, cnt + 40, wf_list);
-        in = wf_list; in_n = cnt + 40; in_imm = 0;
+                           n_tasks, route_margin, cnt + 44, wf_list, tier_mask);
+        in = wf_list; in_n = cnt + 44; in_imm = 0;
       }
       hipLaunchKernelGGL((wfa_edit_kernel_v2<CAP, WPB>), dim3(grid), dim3(WPB * 64), (size_t)CAP * 2 * WPB * sizeof(uint16_t), ctx->stream, d_arena, d_tasks,
                          in, in_n, in_imm, d_scores, d_cells, cnt + 0, rc + 0, lists, 1.0f,
-                         no_route ? (uint32_t*)nullptr : rc, lists, n_tasks, route_margin);
+                         no_route ? (uint32_t*)nullptr : rc, lists, n_tasks, route_margin, tier_mask);
     }
   }
   if (!no_myers) {
-    uint32_t* const tick[6] = {cnt + 2, cnt + 4, cnt + 6, cnt + 20, cnt + 22, cnt + 24};
+    uint32_t* const tick[NT] = {cnt + 2, cnt + 4, cnt + 6, cnt + 20, cnt + 22, cnt + 24, cnt + 26, cnt + 28};
     static const bool no_sort = getenv("OTG_NO_EDIT_SORT") != nullptr;
-    uint32_t* sorted = todo + 8 * (size_t)n_tasks;
-    uint32_t* hist = (uint32_t*)otg_slot(ctx, SLOT_ROWTAB, 6 * SORT_BUCKETS * sizeof(uint32_t));
+    uint32_t* sorted = todo + (size_t)(NT + 2) * n_tasks;
+    uint32_t* hist = (uint32_t*)otg_slot(ctx, SLOT_ROWTAB, NT * SORT_BUCKETS * sizeof(uint32_t));
     if (!hist) return OTG_ERR_HIP;
-    if (!no_sort) HIP_TRY(ctx, hipMemsetAsync(hist, 0, 6 * SORT_BUCKETS * sizeof(uint32_t), ctx->stream));
-    for (int tier = 0; tier < 6; ++tier) {
+    if (!no_sort) HIP_TRY(ctx, hipMemsetAsync(hist, 0, NT * SORT_BUCKETS * sizeof(uint32_t), ctx->stream));
+    for (int tier = 0; tier < NT; ++tier) {
+      if (!((tier_mask >> tier) & 1u)) continue;
+      int next = tier + 1;                       // where a pair goes whose band turns out too narrow: the next tier that runs
+      while (next < NT && !((tier_mask >> next) & 1u)) ++next;
       const uint32_t* in = lists + (size_t)tier * n_tasks;
-      if (!no_sort && tier < 4) {               // tiers that share a wave between pairs, and the whole-wave tier for its tail
+      if (!no_sort && tier < NT - 2) {               // tiers that share a wave between pairs, and the whole-wave tier for its tail
         uint32_t* h = hist + tier * SORT_BUCKETS;
         const uint32_t sg = std::min<uint32_t>((n_tasks + 2047) / 2048, (uint32_t)ctx->n_cu * 2);
         hipLaunchKernelGGL(K_sort_hist, dim3(sg), dim3(256), 0, ctx->stream, in, (const uint32_t*)(rc + tier), d_tasks, h);
@@ -642,17 +650,17 @@ int otg_launch_edit_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_t
         in = sorted;
       }
       const int rc_ = otg_launch_myers(ctx, tier, d_arena, d_tasks, in, rc + tier, n_tasks, d_scores, d_cells,
-                                       tick[tier], rc + tier + 1, lists + (size_t)(tier + 1) * n_tasks);
+                                       tick[tier], rc + next, lists + (size_t)next * n_tasks);
       if (rc_) return rc_;
     }
   }
-  const uint32_t* cur = lists + 6 * (size_t)n_tasks; const uint32_t* cur_n = rc + 6;
+  const uint32_t* cur = lists + (size_t)NT * n_tasks; const uint32_t* cur_n = rc + NT;
   {
     constexpr int CAP = 8192, WPB = 1;                         // 32 KB per wave -> 5 waves / CU, scores up to ~4000
     const size_t lds = (size_t)CAP * 2 * WPB * sizeof(uint16_t);
     uint32_t grid = (uint32_t)ctx->n_cu * 5;
     hipLaunchKernelGGL((wfa_edit_kernel_v2<CAP, WPB>), dim3(grid), dim3(WPB * 64), lds, ctx->stream, d_arena, d_tasks,
-                       cur, cur_n, 0u, d_scores, d_cells, cnt + 16, cnt + 17, listG, 0.0f, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, 1.0f);
+                       cur, cur_n, 0u, d_scores, d_cells, cnt + 16, cnt + 17, listG, 0.0f, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, 1.0f, 0u);
   }
   {
     // last tier: global-memory wavefront sized for the longest possible pair; only reached by huge inputs
@@ -669,12 +677,10 @@ int otg_launch_edit_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_t
   HIP_TRY(ctx, hipGetLastError());
   if (getenv("OTG_DEBUG")) {
     hipError_t er = hipStreamSynchronize(ctx->stream);
-    uint32_t h[40];
+    uint32_t h[48];
     (void)hipMemcpy(h, cnt, sizeof(h), hipMemcpyDeviceToHost);
-    uint32_t hw4[4] = {0, 0, 0, 0};
-    (void)hipMemcpy(hw4, cnt + 40, sizeof(hw4), hipMemcpyDeviceToHost);
-    fprintf(stderr, "[otg] edit: %s; wavefront pass input %u; inputs of the bit-parallel tiers 0..5: %u %u %u %u %u %u, wide wavefront tier %u, its overflow %u\n",
-            hipGetErrorString(er), hw4[0], h[32], h[33], h[34], h[35], h[36], h[37], h[38], h[17]);
+    fprintf(stderr, "[otg] edit: %s; wavefront pass input %u; inputs of the bit-parallel tiers 0..7: %u %u %u %u %u %u %u %u, wide wavefront tier %u, its overflow %u\n",
+            hipGetErrorString(er), h[44], h[32], h[33], h[34], h[35], h[36], h[37], h[38], h[39], h[40], h[17]);
   }
   if (kernel_ms) {
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));

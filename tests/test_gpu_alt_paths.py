@@ -22,6 +22,7 @@ CASES = [
     ("OTG_NO_MYERS", ["tests/test_gpu_edit.py::test_edit_small_mixed", "tests/test_gpu_edit.py::test_edit_long_ont"]),
     ("OTG_NO_EDIT_ROUTE OTG_NO_EDIT_SORT", ["tests/test_gpu_edit.py"]),
     ("OTG_NO_EDIT_SAMPLE", ["tests/test_gpu_edit.py"]),
+    ("OTG_EDIT_TIERS=255", ["tests/test_gpu_edit.py"]),                                 # all eight bit-parallel tiers (the two three-block ones only run on passes with millions of pairs otherwise)
     ("OTG_POA_V1 OTG_POA_NO_LDS", ["tests/test_gpu_poa.py", "tests/test_gpu_pipeline.py::test_ont_kb"]),   # first-generation POA (serial threading, Kahn sweep), global memory only
     ("OTG_POA_NO_LDS", ["tests/test_gpu_poa.py"]),                                       # second-generation POA on every graph (the op-string fuzz and the insertion stretches in global memory)
     ("OTG_POA_PIECE_MB=1", ["tests/test_gpu_poa.py", "tests/test_gpu_pipeline.py::test_ont_kb"]),         # graph images in many small pieces that reuse the work arrays

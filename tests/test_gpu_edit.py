@@ -142,9 +142,9 @@ def test_edit_band_edges(gpu, oracle):
     pairs just over it must move up a tier — either way the score equals the oracle's."""
     rng = np.random.default_rng(17)
     pairs, forms = [], []
-    for T in (456, 904, 976, 1936, 2016):
+    for T in (456, 904, 976, 1352, 1936, 2016, 2896):       # (1352 / 2896: the three-block tiers <3,8> / <3,16>)
         for trial in range(14 if T < 1000 else 8):
-            L = int(rng.integers(1400, 2600))
+            L = int(rng.integers(1400, 2600)) if T < 2500 else int(rng.integers(3200, 4200))
             core = rand_seq(rng, L)
             tot = T + int(rng.integers(-8, 9))
             d1 = int(rng.integers(0, tot + 1)) if trial % 3 else tot
