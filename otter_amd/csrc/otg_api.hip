@@ -116,6 +116,8 @@ void otg_destroy(otg_ctx* ctx)
   for (auto& b : ctx->pool) if (b.p) (void)hipFree(b.p);
   for (int i = 0; i < 5; ++i) { if (ctx->tier_stream[i]) (void)hipStreamDestroy(ctx->tier_stream[i]); if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]); }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->edit_hist) (void)hipHostFree(ctx->edit_hist);
+  for (int i = 0; i < 2; ++i) if (ctx->edit_hist_ev[i]) (void)hipEventDestroy(ctx->edit_hist_ev[i]);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -32,7 +32,13 @@ struct otg_ctx {
   // side streams of the gap-affine chain: on small batches the register tiers run next to each other (wfa_affine.hip); created on first use
   hipStream_t tier_stream[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  int edit_sparse_pass = 0;                       // set around an edit-distance pass whose todo list is a small share of its task slots (the reassignment pass)
+  // Which of the two optional bit-parallel edit tiers run (wfa_edit.hip): decided per KIND of pass (0 = distance matrix / operator-level call,
+  // 1 = reassignment; set around the call) from the tier loads the previous pass of that kind left behind (a job's batches are alike), copied to
+  // pinned host memory behind the chain — no host synchronisation; without history, from the number of task slots.
+  int edit_pass_kind = 0;
+  uint32_t* edit_hist = nullptr;                  // pinned: [kind][16] = tier input counts of the last pass
+  hipEvent_t edit_hist_ev[2] = {nullptr, nullptr};
+  uint32_t edit_hist_mask[2] = {0u, 0u};          // the mask that pass ran with (0: no history)
   double last_kernel_ms = 0.0;                    // HIP-event time of the kernels of the latest operator-level call that reports one (otg_last_kernel_ms)
   unsigned long long* affine_visited = nullptr;   // device counter: (score, diagonal) cells the exact gap-affine tiers visited (wfa_affine.hip)
 };

@@ -834,9 +834,9 @@ static int assemble_run_impl(otg_ctx* ctx, bool realign_only)
     hipLaunchKernelGGL(K_reassign_tasks, dim3(gr_blocks), dim3(64), 0, st, d_arena, d_reads, d_regions, NG, d_status, d_nvalid, (const int32_t*)B(B_FC), d_labels,
                        (const uint64_t*)B(B_RE_OFF), d_tasks, d_den, d_redist, d_todo, d_cnt + 24, rev_base);
     float kms = 0; uint64_t kl = 0;
-    ctx->edit_sparse_pass = 1;
+    ctx->edit_pass_kind = 1;
     rc = otg_launch_edit_todo(ctx, d_arena, d_tasks, d_todo, d_cnt + 24, (uint32_t)pl->n_re_slots, d_scores, d_cells, &kms, &kl);
-    ctx->edit_sparse_pass = 0;
+    ctx->edit_pass_kind = 0;
     if (rc) return rc;
     pl->stats.ms_edit_kernel += kms; pl->stats.edit_kernel_launches += kl;
     hipLaunchKernelGGL(K_dist_epilogue, dim3(1024), dim3(256), 0, st, d_todo, d_cnt + 24, d_scores, d_den, d_redist, d_cnt + 40);

@@ -589,11 +589,23 @@ int otg_launch_edit_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_t
   uint32_t* listG = todo + (size_t)(NT + 1) * n_tasks;
   uint32_t* const rc = cnt + 32;
   HIP_TRY(ctx, hipMemsetAsync(rc, 0, 16 * sizeof(uint32_t), ctx->stream));      // rc[0 .. NT], then (cnt + 44 ..) the counters of the sampling router
-  // The two three-block tiers pay on a full device (a pair pays for the band of its tier: <3,8> and <3,16> take what would run on tiers 1.45 x
-  // as costly — edit stage 723 -> 664 ms on the 1-10 kb shard) and cost a launch each — sort + a kernel that lasts as long as its longest pair —
-  // on a sparse list (a batch of 1 000 regions, the reassignment pass: +2.4 ms each): only passes with millions of pairs get them.
+  // The two three-block tiers pay where their lists are long (a pair pays for the band of its tier: <3,8> and <3,16> take what would run on tiers
+  // 1.45 x as costly — edit stage 723 -> 664 ms on the 1-10 kb shard, the reassignment pass of a batch with clipped reads likewise) and cost a
+  // launch each — sort + a kernel that lasts as long as its longest pair, ~2 ms — where they are short (a batch of 1 000 regions, the reassignment
+  // pass of fully spanning reads).  The batches of a job are alike, so each kind of pass decides from what its previous pass saw: an optional tier
+  // that ran stays while it got 20 000 pairs, one that did not run comes in when the tier above it got 40 000.  No history: by the task slots.
   static const int tiers_env = getenv("OTG_EDIT_TIERS") ? atoi(getenv("OTG_EDIT_TIERS")) : 0;      // test switch: the tiers that run, as a bit mask (tier 0 and the last always do)
-  const uint32_t tier_mask = tiers_env ? (((uint32_t)tiers_env & 0xFFu) | 0x81u) : ((n_tasks >= 2000000u && !ctx->edit_sparse_pass) ? 0xFFu : 0xEBu);
+  const int kind = ctx->edit_pass_kind & 1;
+  uint32_t tier_mask = (n_tasks >= 2000000u && kind == 0) ? 0xFFu : 0xEBu;
+  if (ctx->edit_hist && ctx->edit_hist_mask[kind] && hipEventQuery(ctx->edit_hist_ev[kind]) == hipSuccess) {
+    const uint32_t* h = ctx->edit_hist + 16 * kind;
+    const uint32_t was = ctx->edit_hist_mask[kind];
+    tier_mask = 0xEBu;
+    if ((was >> 2) & 1u ? h[2] >= 20000u : h[3] >= 40000u) tier_mask |= 1u << 2;
+    if ((was >> 4) & 1u ? h[4] >= 20000u : h[5] >= 40000u) tier_mask |= 1u << 4;
+  }
+  (void)hipGetLastError();
+  if (tiers_env) tier_mask = ((uint32_t)tiers_env & 0xFFu) | 0x81u;
   static const bool no_myers = getenv("OTG_NO_MYERS") != nullptr;
   static const bool no_route = getenv("OTG_NO_EDIT_ROUTE") != nullptr;
   // a tier that turns out too narrow costs about half of going one tier up straight away, so the cheapest choice sits a little below
@@ -674,13 +686,22 @@ int otg_launch_edit_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_t
                        (uint32_t*)nullptr, ws, gcap);
   }
   if (kernel_ms) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));      // after the LAST tier of the chain
+  if (!no_myers) {                    // what the tiers saw, for the next pass of this kind
+    if (!ctx->edit_hist) {
+      HIP_TRY(ctx, hipHostMalloc((void**)&ctx->edit_hist, 32 * sizeof(uint32_t), hipHostMallocDefault));
+      for (int i = 0; i < 2; ++i) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->edit_hist_ev[i], hipEventDisableTiming));
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->edit_hist + 16 * kind, rc, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->edit_hist_ev[kind], ctx->stream));
+    ctx->edit_hist_mask[kind] = tier_mask;
+  }
   HIP_TRY(ctx, hipGetLastError());
   if (getenv("OTG_DEBUG")) {
     hipError_t er = hipStreamSynchronize(ctx->stream);
     uint32_t h[48];
     (void)hipMemcpy(h, cnt, sizeof(h), hipMemcpyDeviceToHost);
-    fprintf(stderr, "[otg] edit: %s; wavefront pass input %u; inputs of the bit-parallel tiers 0..7: %u %u %u %u %u %u %u %u, wide wavefront tier %u, its overflow %u\n",
-            hipGetErrorString(er), h[44], h[32], h[33], h[34], h[35], h[36], h[37], h[38], h[39], h[40], h[17]);
+    fprintf(stderr, "[otg] edit (tiers %02x): %s; wavefront pass input %u; inputs of the bit-parallel tiers 0..7: %u %u %u %u %u %u %u %u, wide wavefront tier %u, its overflow %u\n",
+            tier_mask, hipGetErrorString(er), h[44], h[32], h[33], h[34], h[35], h[36], h[37], h[38], h[39], h[40], h[17]);
   }
   if (kernel_ms) {
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
