@@ -128,6 +128,8 @@ def cpu_baseline(batch, params, seconds, n_threads, runs=3, with_reference_conse
                 "sample": "first %d regions, %d threads, %s; %d run(s) of %.1f-%.1f s" % (n if (runs > 1 or n > n_threads) else n_threads, n_threads, label, len(rates), min(times), max(times))}
 
     out = dict(measure("oracle port (scalar C++ WFA, O(N+E) consensus)"), kind="port")
+    out["note"] = ("not the reference binary: its aligner (WFA2-lib, an un-vendored submodule) is absent from the image, so BASELINE.md 3.2's "
+                   "calibration of the port against a reference build cannot be done here")
     refp = os.path.join(ROOT, "oracle", "_ref", "libotter_ref.so")
     if with_reference_consensus and os.path.exists(refp):
         R = C.CDLL(refp)
