@@ -1,4 +1,5 @@
-"""File-to-text rate of otg_assemble_files for several batch sizes and numbers of hot-path contexts per device (OTG_DISPATCH_CONTEXTS).
+"""File-to-text rate of otg_assemble_files for several batch sizes (0 = the library's own batch plan) and numbers of hot-path contexts per device
+(OTG_DISPATCH_CONTEXTS).
 usage: python scripts/dispatch_probe.py [loci] [ingest_threads]"""
 import os
 import sys
@@ -18,12 +19,11 @@ fx = bamwrite.make_tr_fixture(tmp, R, depth=30, len_range=(1000, 5000), seed=7)
 print("fixture: %d loci in %.0f s" % (R, time.perf_counter() - t0), flush=True)
 for batch in (int(b) for b in os.environ.get("OTG_PROBE_BATCHES", "250,500,1000").split(",")):
     for nctx in (int(c) for c in os.environ.get("OTG_PROBE_CONTEXTS", "1,2,3,4").split(",")):
-        for stagger in (0,):
-            os.environ["OTG_DISPATCH_CONTEXTS"] = str(nctx)
-            best = None
-            for rep in range(3):
-                t1 = time.perf_counter()
-                txt, st = otter_amd.assemble_files(fx["bam"], fx["bed"], read_group="s1", batch_regions=batch, offset_l=1, offset_r=1, mapq=10, threads=T)
-                dt = time.perf_counter() - t1
-                best = dt if best is None or dt < best else best
-            print("batch %4d contexts %d (%d): %.3f s = %.0f regions/s (busy ms: ingest %.0f hot %.0f)" % (batch, nctx, stagger, best, R / best, st["ms_ingest"], st["ms_hot_path"]), flush=True)
+        os.environ["OTG_DISPATCH_CONTEXTS"] = str(nctx)
+        best = None
+        for rep in range(3):
+            t1 = time.perf_counter()
+            txt, st = otter_amd.assemble_files(fx["bam"], fx["bed"], read_group="s1", batch_regions=batch, offset_l=1, offset_r=1, mapq=10, threads=T)
+            dt = time.perf_counter() - t1
+            best = dt if best is None or dt < best else best
+        print("batch %4d contexts %d: %.3f s = %.0f regions/s (busy ms: ingest %.0f hot %.0f)" % (batch, nctx, best, R / best, st["ms_ingest"], st["ms_hot_path"]), flush=True)
