@@ -450,8 +450,8 @@ typedef struct otg_assemble_job {
   int32_t     reads_only;        /* --reads-only                                                     */
   otg_params  params;            /* heuristics (realign is set from fasta_path)                      */
   otg_ingest_opts ingest;        /* --offset, --mapq, --non-primary, --omit-nonspanning, --read-quality; .threads = -t (host ingest threads) */
-  uint32_t    batch_regions;     /* regions per batch; 0 = the library's plan: batches of 2048, smaller
-                                  * ones at both ends of a shard (256, 512, 1024 first; thirds at the end) */
+  uint32_t    batch_regions;     /* regions per batch; 0 = the library's plan: 256, 512, 1024 first, then
+                                  * batches of 2048, the last stretch in two equal halves                */
   int32_t     n_devices;         /* 0: device 0 only                                                 */
   const int32_t* devices;        /* HIP device ordinals, one shard each                              */
 } otg_assemble_job;

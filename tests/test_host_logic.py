@@ -48,7 +48,7 @@ def test_pack_and_tasks():
 def test_dispatcher_batch_plan():
     """otg_assemble_batch_plan (the cut of a shard into batches, include/otter_gpu.h): every region once and in order whatever the size; a
     requested size is kept; the library's own plan starts small (the device idles while the first batch is read), reaches full batches
-    of 2048 on a large shard and ends on smaller ones again."""
+    of 2048 on a large shard and ends on two equal halves (the two contexts of a device run out of work together)."""
     import otter_amd
     for n in (0, 1, 7, 255, 256, 1025, 2048, 4096, 10000, 12500, 100000, 123457):
         for req in (0, 1, 3, 1000, 2048, 5000):
@@ -60,5 +60,6 @@ def test_dispatcher_batch_plan():
                 assert max(plan, default=0) <= 2048
     plan = otter_amd.assemble_batch_plan(100000, 0)
     assert plan[:3] == [256, 512, 1024] and plan[3] == 2048 and plan.count(2048) >= 40
-    assert plan[-1] <= 512 and len(plan) <= 60
-    assert otter_amd.assemble_batch_plan(1000, 0) == [1000] or sum(otter_amd.assemble_batch_plan(1000, 0)) == 1000
+    assert abs(plan[-1] - plan[-2]) <= 1 and plan[-1] <= 2048 * 5 // 8 + 1 and len(plan) <= 60
+    assert otter_amd.assemble_batch_plan(10000, 0) == [256, 512, 1024, 2048, 2048, 2048, 1032, 1032]
+    assert otter_amd.assemble_batch_plan(1000, 0) == [1000]
