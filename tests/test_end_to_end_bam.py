@@ -230,3 +230,24 @@ def test_dispatcher_two_devices(gpu, tmp_path):
     two, st = otter_amd.assemble_files(fx["bam"], fx["bed"], batch_regions=7, devices=[0, 1], **kw)
     assert one == two and st["n_devices"] == 2
     otter_amd.assemble_files_release()
+
+
+@pytest.mark.gpu
+def test_dispatcher_batch_plan_of_the_library(gpu, tmp_path):
+    """With batch_regions = 0 the library cuts a shard by its own plan (small batches first, full ones, two equal halves at the end:
+    include/otter_gpu.h, otg_assemble_batch_plan).  On a BED long enough for the plan to have several batches of different sizes — also per
+    shard of a two-shard run — the text must be what one batch of the whole BED gives."""
+    from otter_amd import bamwrite
+    n = 1300
+    fx = bamwrite.make_tr_fixture(str(tmp_path), n, depth=8, len_range=(300, 700), seed=8)
+    plan = otter_amd.assemble_batch_plan(n, 0)
+    assert len(plan) >= 3 and sum(plan) == n and len(set(plan)) >= 2
+    kw = dict(read_group="s1", offset_l=1, offset_r=1, mapq=10, threads=8)
+    gpu.trim()
+    whole, st0 = otter_amd.assemble_files(fx["bam"], fx["bed"], batch_regions=n, **kw)
+    auto, st1 = otter_amd.assemble_files(fx["bam"], fx["bed"], batch_regions=0, **kw)
+    assert st0["n_regions"] == n and st0["n_regions_ok"] > 0.9 * n
+    assert auto == whole and st1["n_alleles"] == st0["n_alleles"]
+    two, st2 = otter_amd.assemble_files(fx["bam"], fx["bed"], batch_regions=0, devices=[0, 0], **kw)
+    assert two == whole and st2["n_devices"] == 2
+    otter_amd.assemble_files_release()
