@@ -1018,7 +1018,10 @@ __global__ __launch_bounds__(64) void poa_graph_lds_kernel(PoaDev P, const uint3
 }
 
 // global-memory instantiation over a list of graphs: those too large for the LDS kernel, then what the LDS kernel left behind
-__global__ __launch_bounds__(64, 4) void poa_graph_wave_kernel(PoaDev P, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count_ptr,
+#ifndef OTG_POA_WPEU
+#define OTG_POA_WPEU 4      // waves per SIMD the global-memory kernel is compiled for (measured on configs[1], stage ms at 3 / 4 / 5 / 6: 44.8 / 39.5 / 43.4 / 50.2)
+#endif
+__global__ __launch_bounds__(64, OTG_POA_WPEU) void poa_graph_wave_kernel(PoaDev P, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count_ptr,
                                                                uint32_t count_imm)
 {
   __shared__ uint32_t s_ops[64 * POA_WK], s_stage[64];
