@@ -641,6 +641,8 @@ int otg_launch_edit_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_t
                          no_route ? (uint32_t*)nullptr : rc, lists, n_tasks, route_margin, tier_mask);
     }
   }
+  uint32_t dbg_routed[16] = {0};
+  if (getenv("OTG_DEBUG")) { (void)hipStreamSynchronize(ctx->stream); (void)hipMemcpy(dbg_routed, rc, sizeof(dbg_routed), hipMemcpyDeviceToHost); }      // what the routers sent where, before any tier passed pairs on
   if (!no_myers) {
     uint32_t* const tick[NT] = {cnt + 2, cnt + 4, cnt + 6, cnt + 20, cnt + 22, cnt + 24, cnt + 26, cnt + 28};
     static const bool no_sort = getenv("OTG_NO_EDIT_SORT") != nullptr;
@@ -702,6 +704,8 @@ int otg_launch_edit_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_t
     (void)hipMemcpy(h, cnt, sizeof(h), hipMemcpyDeviceToHost);
     fprintf(stderr, "[otg] edit (tiers %02x): %s; wavefront pass input %u; inputs of the bit-parallel tiers 0..7: %u %u %u %u %u %u %u %u, wide wavefront tier %u, its overflow %u\n",
             tier_mask, hipGetErrorString(er), h[44], h[32], h[33], h[34], h[35], h[36], h[37], h[38], h[39], h[40], h[17]);
+    fprintf(stderr, "[otg] edit:   of which routed there directly: %u %u %u %u %u %u %u %u (the rest came up from the tier below: its band was too narrow)\n",
+            dbg_routed[0], dbg_routed[1], dbg_routed[2], dbg_routed[3], dbg_routed[4], dbg_routed[5], dbg_routed[6], dbg_routed[7]);
   }
   if (kernel_ms) {
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
