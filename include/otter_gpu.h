@@ -67,6 +67,13 @@ typedef struct otg_params {
   double  min_sim;              /* -s  0.9                                */
   double  gt_max_error;         /* genotype -e 0.025                      */
   double  gt_max_cosdis;        /* genotype -c 0.025                      */
+  /* Heuristic of BOTH aligners of the region pipeline (see otg_set_heuristic).  The reference never calls setHeuristic*
+   * (src/assemble.cpp:49-50): its aligners run WFA2-lib's default.  0 = OTG_HEURISTIC_NONE (exact; the default here),
+   * 1 = OTG_HEURISTIC_WFADAPTIVE with the three numbers below (WFA2-lib's own default values: 10, 50, 1).              */
+  int32_t heuristic;
+  int32_t heur_min_wavefront_length;
+  int32_t heur_max_distance_threshold;
+  int32_t heur_steps_between_cutoffs;
 } otg_params;
 
 void otg_params_default(otg_params* p);
@@ -84,6 +91,16 @@ int         otg_device_count(void);           /* number of visible HIP devices (
  * Chosen at otg_create by probing the host libm so cluster labels match the reference
  * running on this host (SURVEY.md §7.2 "FP determinism"). */
 int         otg_exp_variant(otg_ctx* ctx);
+
+/* Heuristic of the L1 aligner calls on this context — wfa::WFAligner::setHeuristicNone() /
+ * setHeuristicWFadaptive(min_wavefront_length, max_distance_threshold, steps_between_cutoffs) (bindings/cpp/WFAligner.hpp:107-122 of
+ * WFA2-lib).  OTG_HEURISTIC_NONE: exact alignment (default).  OTG_HEURISTIC_WFADAPTIVE: WFA2-lib's
+ * adaptive wavefront reduction — after each score, diagonals whose remaining distance to the end exceeds the best one by more than
+ * max_distance_threshold are dropped from both ends of the wavefront (scores >= the exact ones; op strings of a valid, possibly
+ * sub-optimal alignment).  The region pipeline takes its setting from otg_params instead.                                        */
+#define OTG_HEURISTIC_NONE        0
+#define OTG_HEURISTIC_WFADAPTIVE  1
+int otg_set_heuristic(otg_ctx* ctx, int strategy, int min_wavefront_length, int max_distance_threshold, int steps_between_cutoffs);
 
 /* ================================================================= L1: batched aligners
  * One task = one wfa::WFAligner call.  Sequences live in one byte arena (raw bytes, compared

@@ -57,7 +57,35 @@ struct Form {
  * end diagonal(s); the I / D wavefronts of that score are cut to the same range.
  * ------------------------------------------------------------------------------------------ */
 struct Heuristic { int on = 0, min_wf_len = 10, max_dist = 50, steps = 1; };
-static Heuristic g_heur;
+static Heuristic g_heur_global;                              /* oto_set_heuristic: the L1 entry points and scripts */
+static thread_local const Heuristic* t_heur = nullptr;       /* the pipeline entry points: otg_params.heuristic of the call in progress */
+#define g_heur (t_heur ? *t_heur : g_heur_global)
+struct HeurScope {                                           /* otg_params.heuristic != 0 overrides the process-wide setting for one call */
+  Heuristic h; const Heuristic* saved;
+  explicit HeurScope(const otg_params& P) : saved(t_heur) {
+    if (P.heuristic == OTG_HEURISTIC_WFADAPTIVE) {
+      h.on = 1; h.min_wf_len = P.heur_min_wavefront_length; h.max_dist = P.heur_max_distance_threshold;
+      h.steps = P.heur_steps_between_cutoffs < 1 ? 1 : P.heur_steps_between_cutoffs;
+      t_heur = &h;
+    }
+  }
+  ~HeurScope() { t_heur = saved; }
+};
+
+/* sizing statistics of the aligners (scripts/heuristic_widths.py; off unless switched on): per alignment the widest wavefront it computed,
+ * in power-of-two buckets, by kind (0 edit end-to-end, 1 edit ends-free, 2 affine end-to-end, 3 affine ends-free), + alignments and scores */
+static int g_width_stats_on = 0;
+static uint64_t g_width_hist[4][16];
+static uint64_t g_width_n[4], g_width_scores[4];
+static void width_stat(int kind, int maxw, int scores)
+{
+  if (!g_width_stats_on) return;
+  int b = 0;
+  while (b < 15 && (8 << b) < maxw) ++b;          /* bucket b: width <= 8 << b */
+  __atomic_fetch_add(&g_width_hist[kind][b], 1, __ATOMIC_RELAXED);
+  __atomic_fetch_add(&g_width_n[kind], 1, __ATOMIC_RELAXED);
+  __atomic_fetch_add(&g_width_scores[kind], (uint64_t)scores + 1, __ATOMIC_RELAXED);
+}
 
 /* trims [lo, hi] of an extended M wavefront; off(k) = offset (h) of diagonal k or negative */
 template <class Off>
@@ -109,9 +137,10 @@ int wfa_edit(const uint8_t* p, int pl, const uint8_t* t, int tl, const Form& f, 
   const int B = pl + 1;
   for (int k = lo; k <= hi; ++k) cur[k + B] = k > 0 ? k : 0;
   uint64_t W = 0;
-  int steps_wait = 0;
+  int steps_wait = 0, maxw = 0;
   for (int s = 0;; ++s) {
     W += (uint64_t)(hi - lo + 1);
+    maxw = std::max(maxw, hi - lo + 1);
     for (int k = lo; k <= hi; ++k) {
       int h = cur[k + B];
       if (h < 0) continue;
@@ -121,12 +150,14 @@ int wfa_edit(const uint8_t* p, int pl, const uint8_t* t, int tl, const Form& f, 
       if (f.endsfree) {
         if ((h >= tl && pl - v <= f.pef) || (v >= pl && tl - h <= f.tef)) {
           if (cells) *cells = W;
+          width_stat(1, maxw, s);
           return s;
         }
       }
     }
     if (!f.endsfree && kend >= lo && kend <= hi && cur[kend + B] >= tl) {
       if (cells) *cells = W;
+      width_stat(0, maxw, s);
       return s;
     }
     if (g_heur.on) {
@@ -178,7 +209,7 @@ int wfa_affine(const uint8_t* p, int pl, const uint8_t* t, int tl, int x, int o,
   const int kend = tl - pl;
   uint64_t W = 0;
   int s_end = -1, k_end = 0;
-  int steps_wait = 0;
+  int steps_wait = 0, maxw = 0;
   for (int s = 0;; ++s) {
     M.emplace_back(); I.emplace_back(); D.emplace_back(); BT.emplace_back();
     WF& m = M[s]; WF& iw = I[s]; WF& dw = D[s];
@@ -232,6 +263,11 @@ int wfa_affine(const uint8_t* p, int pl, const uint8_t* t, int tl, int x, int o,
       }
     }
     W += 3ull * (uint64_t)(m.hi - m.lo + 1);
+    if (g_width_stats_on) {      /* the window a band-following aligner must hold: every wavefront the next scores read */
+      int wlo = m.lo, whi = m.hi;
+      for (int b = 1; b <= o + e && s - b >= 0; ++b) if (!M[s - b].null()) { wlo = std::min(wlo, M[s - b].lo); whi = std::max(whi, M[s - b].hi); }
+      maxw = std::max(maxw, whi - wlo + 1);
+    }
     /* extend + termination */
     bool done = false;
     for (int k = m.lo; k <= m.hi && !done; ++k) {
@@ -264,6 +300,7 @@ int wfa_affine(const uint8_t* p, int pl, const uint8_t* t, int tl, int x, int o,
     }
   }
   if (cells) *cells = W;
+  width_stat(f.endsfree ? 3 : 2, maxw, s_end);
   if (!cigar) return s_end;
   /* backtrace: reverse op list with 'c' = gap close marker (WFA2's fake X) */
   std::string rev;
@@ -1544,6 +1581,7 @@ struct oto_result {
 oto_result* oto_assemble_batch(const otg_params* P, const uint8_t* arena, uint64_t, const otg_read* reads, uint32_t n_reads,
                                const otg_region* regions, uint32_t n_regions, uint32_t region_begin, uint32_t region_end)
 {
+  oto::HeurScope heur_scope(*P);
   oto_result* R = new oto_result();
   memset(&R->stats, 0, sizeof(R->stats));
   R->labels.assign(n_reads, -1);
@@ -1596,6 +1634,7 @@ oto_result* oto_assemble_batch(const otg_params* P, const uint8_t* arena, uint64
 void oto_realign_batch(const otg_params* P, const uint8_t* arena, uint64_t, const otg_read* reads, uint32_t n_reads,
                        const otg_region* regions, uint32_t n_regions, otg_read* out)
 {
+  oto::HeurScope heur_scope(*P);
   for (uint32_t i = 0; i < n_reads; ++i) out[i] = reads[i];
   for (uint32_t r = 0; r < n_regions; ++r) {
     const otg_region& G = regions[r];
@@ -1624,7 +1663,14 @@ void oto_assemble_free(oto_result* R) { delete R; }
  * scripts/heuristic_risk.py only */
 void oto_set_heuristic(int on, int min_wf_len, int max_dist, int steps)
 {
-  oto::g_heur.on = on; oto::g_heur.min_wf_len = min_wf_len; oto::g_heur.max_dist = max_dist; oto::g_heur.steps = steps < 1 ? 1 : steps;
+  oto::g_heur_global.on = on; oto::g_heur_global.min_wf_len = min_wf_len; oto::g_heur_global.max_dist = max_dist; oto::g_heur_global.steps = steps < 1 ? 1 : steps;
+}
+/* sizing statistics (see width_stat): on != 0 clears and starts, out = 4 x (16 buckets, alignments, scores) */
+void oto_width_stats(int on, uint64_t* out)
+{
+  if (out) for (int k = 0; k < 4; ++k) { memcpy(out + k * 18, oto::g_width_hist[k], 16 * 8); out[k * 18 + 16] = oto::g_width_n[k]; out[k * 18 + 17] = oto::g_width_scores[k]; }
+  if (on) { memset(oto::g_width_hist, 0, sizeof(oto::g_width_hist)); memset(oto::g_width_n, 0, sizeof(oto::g_width_n)); memset(oto::g_width_scores, 0, sizeof(oto::g_width_scores)); }
+  oto::g_width_stats_on = on;
 }
 void oto_set_poa_hook(void* fn) { oto::g_poa_hook = (oto::oto_poa_hook_t)fn; }
 uint32_t oto_result_n_alleles(oto_result* R) { return R->alleles.size(); }
@@ -1650,6 +1696,7 @@ void oto_params_default(otg_params* p)
   p->min_cov_fraction2_l = 500; p->mismatch = 4; p->gap_open = 6; p->gap_ext = 2; p->realign = 0;
   p->bandwidth_short = 0.01; p->bandwidth_long = 0.015; p->max_error = 0.01; p->min_cov_fraction = 0.2;
   p->min_cov_fraction2_f = 0.1; p->min_sim = 0.9; p->gt_max_error = 0.025; p->gt_max_cosdis = 0.025;
+  p->heuristic = OTG_HEURISTIC_NONE; p->heur_min_wavefront_length = 10; p->heur_max_distance_threshold = 50; p->heur_steps_between_cutoffs = 1;
 }
 
 

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libotter_gpu.so")
 
 EXPORTS = [
-    "otg_params_default", "otg_create", "otg_destroy", "otg_trim", "otg_last_error", "otg_device_count", "otg_exp_variant",
+    "otg_params_default", "otg_create", "otg_destroy", "otg_trim", "otg_last_error", "otg_device_count", "otg_exp_variant", "otg_set_heuristic",
     "otg_edit_distance_batch", "otg_affine_align_batch", "otg_cluster_batch", "otg_poa_consensus_batch",
     "otg_genotype_cluster_batch", "otg_last_kernel_ms", "otg_assemble_submit", "otg_assemble_run", "otg_assemble_result_sizes",
     "otg_assemble_collect", "otg_assemble_device_results", "otg_assemble_stats", "otg_assemble_realign", "otg_assemble_collect_reads",
@@ -96,6 +96,11 @@ class Context:
         return self._L.otg_exp_variant(self._h)
 
     # ------------------------------------------------------------------ L1
+    def set_heuristic(self, strategy=abi.OTG_HEURISTIC_NONE, min_wavefront_length=10, max_distance_threshold=50, steps_between_cutoffs=1):
+        """Heuristic of the L1 aligner calls on this context: wfa::WFAligner::setHeuristicNone / setHeuristicWFadaptive."""
+        self._check(self._L.otg_set_heuristic(self._h, int(strategy), int(min_wavefront_length), int(max_distance_threshold), int(steps_between_cutoffs)),
+                    "otg_set_heuristic")
+
     def edit_distance_batch(self, arena, tasks, want_cells=False):
         n = len(tasks)
         scores = np.zeros(n, dtype=np.int32)

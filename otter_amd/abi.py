@@ -24,7 +24,13 @@ class otg_params(C.Structure):
         ("bandwidth_short", C.c_double), ("bandwidth_long", C.c_double), ("max_error", C.c_double),
         ("min_cov_fraction", C.c_double), ("min_cov_fraction2_f", C.c_double), ("min_sim", C.c_double),
         ("gt_max_error", C.c_double), ("gt_max_cosdis", C.c_double),
+        ("heuristic", C.c_int32), ("heur_min_wavefront_length", C.c_int32), ("heur_max_distance_threshold", C.c_int32),
+        ("heur_steps_between_cutoffs", C.c_int32),
     ]
+
+
+OTG_HEURISTIC_NONE = 0
+OTG_HEURISTIC_WFADAPTIVE = 1
 
 
 def default_params(**kw):
@@ -32,7 +38,8 @@ def default_params(**kw):
     p = otg_params(max_alleles=2, ignore_haps=1, max_cov=200, flank=100, bandwidth_length=500,
                    min_cov_fraction2_l=500, mismatch=4, gap_open=6, gap_ext=2, realign=0,
                    bandwidth_short=0.01, bandwidth_long=0.015, max_error=0.01, min_cov_fraction=0.2,
-                   min_cov_fraction2_f=0.1, min_sim=0.9, gt_max_error=0.025, gt_max_cosdis=0.025)
+                   min_cov_fraction2_f=0.1, min_sim=0.9, gt_max_error=0.025, gt_max_cosdis=0.025,
+                   heuristic=OTG_HEURISTIC_NONE, heur_min_wavefront_length=10, heur_max_distance_threshold=50, heur_steps_between_cutoffs=1)
     for k, v in kw.items():
         if not hasattr(p, k):
             raise AttributeError(k)

@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libotter_gpu.so")
-SOURCES = ["otg_api.hip", "wfa_edit.hip", "myers_edit.hip", "wfa_affine.hip", "wfa_affine_reg.hip", "cluster.hip", "poa.hip", "pipeline.hip", "emit.hip", "ingest.hip", "bedfa.hip", "dispatch.hip", "gather.hip"]
+SOURCES = ["otg_api.hip", "wfa_edit.hip", "myers_edit.hip", "wfa_affine.hip", "wfa_affine_reg.hip", "wfa_adaptive.hip", "cluster.hip", "poa.hip", "pipeline.hip", "emit.hip", "ingest.hip", "bedfa.hip", "dispatch.hip", "gather.hip"]
 # -ffp-contract=off: the reference's clustering decisions are FP64 comparisons made without FMA
 # contraction; fused operations are written explicitly where glibc uses them.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",

@@ -58,6 +58,21 @@ void otg_params_default(otg_params* p)
   p->min_cov_fraction2_l = 500; p->mismatch = 4; p->gap_open = 6; p->gap_ext = 2; p->realign = 0;
   p->bandwidth_short = 0.01; p->bandwidth_long = 0.015; p->max_error = 0.01; p->min_cov_fraction = 0.2;
   p->min_cov_fraction2_f = 0.1; p->min_sim = 0.9; p->gt_max_error = 0.025; p->gt_max_cosdis = 0.025;
+  p->heuristic = OTG_HEURISTIC_NONE; p->heur_min_wavefront_length = 10; p->heur_max_distance_threshold = 50; p->heur_steps_between_cutoffs = 1;
+}
+
+int otg_set_heuristic(otg_ctx* ctx, int strategy, int min_wavefront_length, int max_distance_threshold, int steps_between_cutoffs)
+{
+  if (!ctx) return otg_fail(nullptr, OTG_ERR_NO_DEVICE, "otg_set_heuristic: no context");
+  if (strategy != OTG_HEURISTIC_NONE && strategy != OTG_HEURISTIC_WFADAPTIVE) return otg_fail(ctx, OTG_ERR_ARG, "otg_set_heuristic: unknown strategy %d", strategy);
+  if (strategy == OTG_HEURISTIC_WFADAPTIVE && (min_wavefront_length < 0 || max_distance_threshold < 0))
+    return otg_fail(ctx, OTG_ERR_ARG, "otg_set_heuristic: negative wavefront length or distance threshold");
+  ctx->heur_strategy = strategy;
+  if (strategy == OTG_HEURISTIC_WFADAPTIVE) {
+    ctx->heur_min_wf_len = min_wavefront_length; ctx->heur_max_dist = max_distance_threshold;
+    ctx->heur_steps = steps_between_cutoffs < 1 ? 1 : steps_between_cutoffs;
+  }
+  return OTG_OK;
 }
 
 int otg_device_count(void)

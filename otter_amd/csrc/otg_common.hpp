@@ -41,6 +41,8 @@ struct otg_ctx {
   uint32_t edit_hist_mask[2] = {0u, 0u};          // the mask that pass ran with (0: no history)
   double last_kernel_ms = 0.0;                    // HIP-event time of the kernels of the latest operator-level call that reports one (otg_last_kernel_ms)
   unsigned long long* affine_visited = nullptr;   // device counter: (score, diagonal) cells the exact gap-affine tiers visited (wfa_affine.hip)
+  // aligner heuristic of the L1 calls and of the running pipeline (otg_set_heuristic / otg_params.heuristic; wfa_adaptive.hip)
+  int heur_strategy = OTG_HEURISTIC_NONE, heur_min_wf_len = 10, heur_max_dist = 50, heur_steps = 1;
 };
 
 extern thread_local std::string g_otg_err;
@@ -216,6 +218,16 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
 int otg_launch_affine(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_task* d_tasks, uint32_t n_tasks,
                       int x, int o, int e, int32_t* d_scores, const uint64_t* d_cig_off, uint32_t* d_cig_len,
                       uint8_t* d_cig_arena, uint64_t* d_cells);
+
+// wfa_adaptive.hip — the same two chains under wfadaptive(min_wf_len, max_dist, steps); otg_launch_edit_todo / otg_launch_affine_todo hand
+// over to them when ctx->heur_strategy says so
+int otg_launch_edit_adaptive_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_task* d_tasks, const uint32_t* d_todo,
+                                  const uint32_t* d_n_todo, uint32_t n_task_slots, int32_t* d_scores, uint64_t* d_cells,
+                                  float* kernel_ms, uint64_t* launches);
+int otg_launch_affine_adaptive_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_task* d_tasks, const uint32_t* d_todo,
+                                    const uint32_t* d_n_todo, uint32_t n_task_slots, int x, int o, int e, int32_t* d_scores,
+                                    const uint64_t* d_cig_off, uint32_t* d_cig_len, uint8_t* d_cig_arena, uint64_t* d_cells,
+                                    float* kernel_ms, uint64_t* launches);
 
 // cluster.hip
 int otg_launch_cluster(otg_ctx* ctx, const otg_params* P, const double* d_dist, const uint64_t* d_dist_off,

@@ -730,11 +730,31 @@ int otg_assemble_collect_reads(otg_ctx* ctx, otg_read* reads_out, uint32_t n_rea
   return OTG_OK;
 }
 
+static int assemble_run_body(otg_ctx* ctx, bool realign_only);
+
+// the pipeline's aligners run under the heuristic of the submitted otg_params, whatever otg_set_heuristic left on the context for the L1 calls
 static int assemble_run_impl(otg_ctx* ctx, bool realign_only)
 {
   if (!ctx) return otg_fail(nullptr, OTG_ERR_NO_DEVICE, "otg_assemble_run: no context");
   Pipeline* pl = ctx->pipe;
   if (!pl) return otg_fail(ctx, OTG_ERR_ARG, "otg_assemble_run: nothing submitted");
+  const int sv[4] = {ctx->heur_strategy, ctx->heur_min_wf_len, ctx->heur_max_dist, ctx->heur_steps};
+  const otg_params& P = pl->P;
+  if (P.heuristic != OTG_HEURISTIC_NONE && P.heuristic != OTG_HEURISTIC_WFADAPTIVE) return otg_fail(ctx, OTG_ERR_ARG, "otg_assemble_run: unknown heuristic %d in otg_params", P.heuristic);
+  ctx->heur_strategy = P.heuristic;
+  if (P.heuristic == OTG_HEURISTIC_WFADAPTIVE) {
+    if (P.heur_min_wavefront_length < 0 || P.heur_max_distance_threshold < 0) return otg_fail(ctx, OTG_ERR_ARG, "otg_assemble_run: negative heuristic parameter in otg_params");
+    ctx->heur_min_wf_len = P.heur_min_wavefront_length; ctx->heur_max_dist = P.heur_max_distance_threshold;
+    ctx->heur_steps = P.heur_steps_between_cutoffs < 1 ? 1 : P.heur_steps_between_cutoffs;
+  }
+  const int rc = assemble_run_body(ctx, realign_only);
+  ctx->heur_strategy = sv[0]; ctx->heur_min_wf_len = sv[1]; ctx->heur_max_dist = sv[2]; ctx->heur_steps = sv[3];
+  return rc;
+}
+
+static int assemble_run_body(otg_ctx* ctx, bool realign_only)
+{
+  Pipeline* pl = ctx->pipe;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const otg_params& P = pl->P;
   const uint32_t NR = pl->n_reads, NG = pl->n_regions;
@@ -828,7 +848,8 @@ static int assemble_run_impl(otg_ctx* ctx, bool realign_only)
   {
     Timer t(ctx);
     static const bool no_rev = getenv("OTG_NO_REASSIGN_REV") != nullptr;
-    const uint64_t rev_base = no_rev ? 0 : pl->rev_base;
+    // (under the adaptive heuristic an alignment and its mirror image are different computations: no reversed copies there)
+    const uint64_t rev_base = (no_rev || ctx->heur_strategy != OTG_HEURISTIC_NONE) ? 0 : pl->rev_base;
     if (rev_base) hipLaunchKernelGGL(K_reverse_reads, dim3(std::min<uint32_t>((NR + 3) / 4, (uint32_t)ctx->n_cu * 32)), dim3(256), 0, st, d_arena, d_reads, d_regions, d_rr, NR,
                                      d_status, d_nvalid, rev_base);
     hipLaunchKernelGGL(K_reassign_tasks, dim3(gr_blocks), dim3(64), 0, st, d_arena, d_reads, d_regions, NG, d_status, d_nvalid, (const int32_t*)B(B_FC), d_labels,

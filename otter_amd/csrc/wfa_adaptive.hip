@@ -1,0 +1,736 @@
+// wfa_adaptive.hip — the wavefront aligners under WFA2-lib's adaptive wavefront reduction, wf_heuristic_wfadaptive(min_wavefront_length,
+// max_distance_threshold, steps_between_cutoffs) (gfx950).
+//
+// Why it exists: the reference constructs WFAlignerEdit(Score, MemoryMed) and WFAlignerGapAffine(4,6,2, Alignment, MemoryMed)
+// (src/assemble.cpp:49-50) and never calls setHeuristic*, so every distance (src/analignments.cpp:70-71,88-97) and every op string
+// (src/analignments.cpp:25,31,37,268-280) inherits WFA2-lib's DEFAULT heuristic — which that un-vendored library build may set to
+// wfadaptive(10, 50, 1).  Exact mode stays the default of this library; this file is the
+// documented switch: otg_set_heuristic / otg_params.heuristic (the adapter's setHeuristicWFadaptive / setHeuristicNone).
+//
+// Semantics (WFA2-lib wavefront_heuristic.c, wavefront_heuristic_cufoff -> wfadaptive; the test-side CPU restatement holds the same rule): after the M wavefront of a score has been extended and the
+// end test has failed, every `steps` scores, if the wavefront spans at least `min_wf_len` diagonals: left(k) = what is left to align
+// from the offset of diagonal k (end-to-end max(plen - v, tlen - h); ends-free the smaller of the two free-end variants); diagonals
+// whose left(k) exceeds the smallest by more than `max_dist` are dropped from both ends of the wavefront, never past the end
+// diagonal(s); the I / D wavefronts of that score are cut to the same range.  The cut reads the offset of EVERY live diagonal, so none
+// of the exact chain's devices applies here (score bound, diamond, bit-parallel tiers, reversed sequences): these kernels run the
+// plain wavefront recurrence, score by score, on the diagonals the cut leaves.
+//
+// What the cut buys: a wavefront no longer grows by two diagonals per score.  On the tandem-repeat workloads it stays 50-500 diagonals
+// wide (shifts by a repeat unit extend as far as the main diagonal, so they survive the cut; scripts/heuristic_widths.py), against
+// thousands in exact mode.  Mapping: ONE wave64 per alignment, lanes = diagonals, chunks of 64 diagonals swept in ascending order;
+// the wavefronts live in LDS in a MODULAR window (slot = k mod CAP: the live range drifts across the diagonals as the alignment
+// proceeds, a fixed window would have to span the whole drift), 16-bit offsets; tiers by window size, the last one keeps int32 rows in
+// HBM and takes any length and any penalties.  The smallest `left` is gathered while the diagonals finish their extension (per-lane
+// minimum + one wave reduction per score); the cut itself is two ballots over the end chunks.
+#include "wfa_affine_common.hpp"
+#include <algorithm>
+#include <cstdlib>
+#include <mutex>
+
+using namespace otg_affine;
+
+namespace {
+
+constexpr int BIG = 1 << 30;
+
+struct Heur { int min_wf_len, max_dist, steps; };
+
+__device__ __forceinline__ int wave_min_i32(int v) { return -otg_wave_max_i32(-v); }      // |v| <= 2^30 here
+__device__ __forceinline__ int dpp_shr1(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x138, 0xf, 0xf, false); }   // lane i <- lane i-1
+
+// what is left to align from offset h of diagonal k (the distance the cut compares)
+__device__ __forceinline__ int left_to_align(int h, int k, int pl, int tl, bool ef, int pef, int tef)
+{
+  if (h < 0) return BIG;
+  const int lv = pl - (h - k), lh = tl - h;
+  if (!ef) return imax(lv, lh);
+  return imin(imax(lh, lv - pef), imax(lv, lh - tef));
+}
+
+// The cut.  [lo, hi] = range of the extended M wavefront, mind = smallest left_to_align over it, off(k) = offset of diagonal k (called
+// for lo <= k <= hi only).  Wave-uniform control flow; returns the trimmed range in lo / hi.
+template <class Off>
+__device__ __forceinline__ void wfadaptive_cut(const Heur& H, int& steps_wait, int mind, int pl, int tl, bool ef, int pef, int tef,
+                                               int& lo, int& hi, int lane, Off off)
+{
+  --steps_wait;
+  if (steps_wait > 0) return;
+  if (hi - lo + 1 < H.min_wf_len) return;
+  const int kend = tl - pl;
+  const int min_k = ef ? kend - tef : kend, max_k = ef ? kend + pef : kend;
+  const int top_limit = imin(min_k - 1, hi);
+  int nlo = lo;
+  if (top_limit > lo) {
+    nlo = top_limit;
+    for (int c = lo; c < top_limit; c += 64) {
+      const int k = c + lane;
+      bool ok = false;
+      if (k < top_limit) ok = left_to_align(off(k), k, pl, tl, ef, pef, tef) - mind <= H.max_dist;
+      const unsigned long long b = __ballot(ok);
+      if (b) { nlo = c + (int)__builtin_ctzll(b); break; }
+    }
+  }
+  const int bottom_limit = imax(max_k + 1, nlo);
+  int nhi = hi;
+  if (hi > bottom_limit) {
+    nhi = bottom_limit;
+    for (int c = hi; c > bottom_limit; c -= 64) {
+      const int k = c - 63 + lane;                      // this chunk covers [c - 63, c]
+      bool ok = false;
+      if (k > bottom_limit) ok = left_to_align(off(k), k, pl, tl, ef, pef, tef) - mind <= H.max_dist;
+      const unsigned long long b = __ballot(ok);
+      if (b) { nhi = c - (int)__builtin_clzll(b); break; }
+    }
+  }
+  lo = nlo; hi = nhi;
+  steps_wait = H.steps;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Edit distance, score only.  Replaces WFAlignerEdit(Score, MemoryMed)::alignEnd2End / alignEndsFree + getAlignmentScore() under the
+// heuristic.  The wavefront is updated IN PLACE (ascending sweep: the left neighbour of lane 0 is carried in a scalar, the right
+// neighbour of lane 63 is still the old value); the extend step probes 8 bytes in the sweep and leaves longer runs to a
+// ballot-compacted LDS queue drained 16 -> 64 -> wave-cooperative 512 bytes per pass.
+template <int CAP>
+struct EditLds {
+  volatile lds_u16* wf;
+  __device__ __forceinline__ bool fits(int pl, int tl) const { return pl < 65535 && tl < 65535; }
+  __device__ __forceinline__ int cap() const { return CAP; }
+  __device__ __forceinline__ int rd(int k) const { const int x = wf[k & (CAP - 1)]; return x == 0xFFFF ? OTG_NULL_OFF : x; }
+  __device__ __forceinline__ void wr(int k, int h) const { wf[k & (CAP - 1)] = (uint16_t)(h < 0 ? 0xFFFF : h); }
+  __device__ __forceinline__ void sync() const {}
+};
+struct EditGlobal {
+  volatile int32_t* wf; int kb; int gcap;
+  __device__ __forceinline__ bool fits(int pl, int tl) const { return pl + tl + 3 <= gcap; }
+  __device__ __forceinline__ int cap() const { return gcap; }
+  __device__ __forceinline__ int rd(int k) const { return wf[k + kb]; }
+  __device__ __forceinline__ void wr(int k, int h) const { wf[k + kb] = h < 0 ? OTG_NULL_OFF : h; }
+  __device__ __forceinline__ void sync() const { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+};
+
+template <int CAP, int QCAP, int WPB>
+__global__ __launch_bounds__(WPB * 64) void wfa_edit_adaptive_kernel(
+    const uint8_t* __restrict__ arena, const otg_align_task* __restrict__ tasks,
+    const uint32_t* __restrict__ todo, const uint32_t* __restrict__ n_todo_ptr, uint32_t n_todo_imm,
+    int32_t* __restrict__ scores, uint64_t* __restrict__ cells,
+    uint32_t* __restrict__ ticket, uint32_t* __restrict__ n_overflow, uint32_t* __restrict__ overflow_list,
+    Heur H, int32_t* gws, int gcap)
+{
+  constexpr bool GLOBAL_WF = CAP == 0;
+  constexpr int LCAP = GLOBAL_WF ? 2 : CAP;
+  __shared__ uint16_t s_wf[WPB][LCAP];
+  __shared__ uint32_t s_q[WPB][QCAP];
+  const int lane = threadIdx.x & 63;
+  const int wib = threadIdx.x >> 6;
+  volatile lds_u32* queue = (volatile lds_u32*)&s_q[wib][0];
+  const uint32_t n_todo = n_todo_ptr ? *n_todo_ptr : n_todo_imm;
+
+  for (;;) {
+    const uint32_t tk = otg_wave_atomic_add(ticket, 1u);
+    if (tk >= n_todo) break;
+    const uint32_t ti = todo ? todo[tk] : tk;
+    const otg_align_task t = tasks[ti];
+    const uint8_t* P = arena + t.pattern_off;
+    const uint8_t* T = arena + t.text_off;
+    const int pl = (int)t.pattern_len, tl = (int)t.text_len;
+    const bool ef = t.endsfree != 0;
+    const int pef = ef ? t.pattern_end_free : 0, tef = ef ? t.text_end_free : 0;
+    const int kend = tl - pl;
+    int res_s = 0;
+    uint64_t res_W = 0;
+    auto body = [&](auto st) -> int {
+      int lo = ef ? -t.pattern_begin_free : 0, hi = ef ? t.text_begin_free : 0;
+      if (lo < -pl) lo = -pl;
+      if (hi > tl) hi = tl;
+      int plo = lo, phi = hi;                       // range of the previous score's wavefront (after its cut)
+      int s = 0, steps_wait = 0;
+      uint64_t W = 0;
+      bool done = false, overflow = !st.fits(pl, tl);
+      while (!overflow) {
+        if (hi - lo + 1 > st.cap()) { overflow = true; break; }
+        W += (uint64_t)(hi - lo + 1);
+        int carry = OTG_NULL_OFF;
+        int dmin = BIG;                             // per lane: smallest left_to_align among the diagonals this lane finished
+        bool fin_l = false;
+        int qn = 0;
+        auto finished = [&](int h, int k) {         // diagonal k is fully extended at offset h
+          dmin = imin(dmin, left_to_align(h, k, pl, tl, ef, pef, tef));
+          if (ef) { const int v = h - k; fin_l = fin_l || (h >= tl && pl - v <= pef) || (v >= pl && tl - h <= tef); }
+        };
+        auto drain = [&]() {
+          st.sync();
+          int pass = 0;
+          while (qn > 0) {
+            if (qn <= 4 && pass > 0) {
+              for (int q = 0; q < qn; ++q) {
+                const int k = lo + __builtin_amdgcn_readfirstlane((int)queue[q]);
+                int h = __builtin_amdgcn_readfirstlane(st.rd(k));
+                const int v = h - k;
+                const int m = otg_wave_match(P, T, v, h, imin(pl - v, tl - h), lane);
+                h += m;
+                st.wr(k, h);                      // the same value from every lane
+                finished(h, k);
+              }
+              qn = 0;
+              st.sync();
+              break;
+            }
+            int wq = 0;
+            for (int q0 = 0; q0 < qn; q0 += 64) {
+              const bool act = q0 + lane < qn;
+              int k = 0, h = 0, v = 0;
+              bool more = false;
+              if (act) {
+                k = lo + (int)queue[q0 + lane];
+                h = st.rd(k);
+                v = h - k;
+                const int rem = imin(pl - v, tl - h);
+                int m, full;
+                if (pass == 0) {
+                  const uint64_t xl = otg_load8(P + v) ^ otg_load8(T + h), xh = otg_load8(P + v + 8) ^ otg_load8(T + h + 8);
+                  m = xl ? (__builtin_ctzll(xl) >> 3) : (xh ? 8 + (__builtin_ctzll(xh) >> 3) : 16);
+                  m = imin(m, rem); full = 16;
+                } else { m = otg_match64(P, T, v, h, rem); full = 64; }
+                v += m; h += m;
+                more = (m == full) && v < pl && h < tl;
+                st.wr(k, h);
+                if (!more) finished(h, k);
+              }
+              const unsigned long long mm = __ballot(more);
+              if (more) {
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+                queue[wq + rank] = (uint32_t)(k - lo);
+              }
+              wq += __builtin_popcountll(mm);
+            }
+            qn = wq; ++pass;
+            st.sync();
+          }
+        };
+        // ---- sweep
+        for (int c = lo; c <= hi; c += 64) {
+          const int k = c + lane;
+          const bool in = k <= hi;
+          int mx;
+          if (s == 0) {
+            mx = k > 0 ? k : 0;
+          } else {
+            int o = OTG_NULL_OFF, r = OTG_NULL_OFF;
+            if (k >= plo && k <= phi) o = st.rd(k);
+            if (k + 1 >= plo && k + 1 <= phi) r = st.rd(k + 1);
+            int l = dpp_shr1(o);
+            if (lane == 0) l = carry;
+            carry = __builtin_amdgcn_readlane(o, 63);
+            const int a = l + 1, b = o + 1;
+            mx = a > b ? a : b;
+            mx = r > mx ? r : mx;
+          }
+          int h = mx, v = mx - k;
+          const bool valid = in && mx >= 0 && h <= tl && v <= pl;
+          bool more = false;
+          if (valid && v < pl && h < tl) {
+            const uint64_t x = otg_load8(P + v) ^ otg_load8(T + h);
+            int m = x ? (__builtin_ctzll(x) >> 3) : 8;
+            m = imin(m, imin(pl - v, tl - h));
+            v += m; h += m;
+            more = (m == 8) && v < pl && h < tl;
+          }
+          if (in) st.wr(k, valid ? h : OTG_NULL_OFF);
+          if (valid && !more) finished(h, k);
+          const unsigned long long mm = __ballot(more);
+          if (more) {
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+            queue[qn + rank] = (uint32_t)(k - lo);
+          }
+          qn += __builtin_popcountll(mm);
+          if (qn + 64 > QCAP) drain();
+        }
+        drain();
+        // ---- end test on the fully extended wavefront
+        bool any_done;
+        if (ef) any_done = __ballot(fin_l) != 0ull;
+        else {
+          any_done = false;
+          if (kend >= lo && kend <= hi) { const int x = __builtin_amdgcn_readfirstlane(st.rd(kend)); any_done = x >= tl; }
+        }
+        if (any_done) { done = true; break; }
+        // ---- the cut
+        const int mind = wave_min_i32(dmin);
+        wfadaptive_cut(H, steps_wait, mind, pl, tl, ef, pef, tef, lo, hi, lane, [&](int k) { return st.rd(k); });
+        plo = lo; phi = hi;
+        lo = lo - 1 < -pl ? -pl : lo - 1;
+        hi = hi + 1 > tl ? tl : hi + 1;
+        ++s;
+        if (s > pl + tl + 2) break;             // cannot happen: the end diagonal is never cut and gains at least one base per score
+      }
+      res_s = s; res_W = W;
+      return done ? 0 : (overflow ? 1 : 2);
+    };
+    int status;
+    if constexpr (GLOBAL_WF) status = body(EditGlobal{(volatile int32_t*)(gws + (size_t)(blockIdx.x * WPB + wib) * (size_t)gcap), pl + 1, gcap});
+    else status = body(EditLds<CAP>{(volatile lds_u16*)&s_wf[wib][0]});
+    // wave-uniform tail: every lane stores the same value to the same address
+    if (status == 0) {
+      scores[ti] = res_s;
+      if (cells) cells[ti] = res_W;
+    } else if (status == 1 && overflow_list) {
+      const uint32_t q = otg_wave_atomic_add(n_overflow, 1u);
+      overflow_list[q] = ti;
+    } else {
+      scores[ti] = -1;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Gap-affine, full op string.  Replaces WFAlignerGapAffine(x, o, e, Alignment, MemoryMed)::alignEnd2End / alignEndsFree +
+// getAlignmentCigar() under the heuristic.  Recurrence, provenance bytes, row table and backtrace as in the exact chain's generic kernel
+// (wfa_affine.hip), scores walked in units of g = gcd(x, o + e, e); every read of a history
+// row is predicated on that row's OWN range (each score's wavefronts were cut to their own range), which is also what makes the
+// modular window safe: two diagonals share a slot only if they are CAP apart, and no row is wider than CAP.
+//   LDS policy (penalties (4,6,2) -> (2,4,1) only): M ring of 5 rows, I and D rings of 2, signed 16-bit offsets (I / D offsets run
+//   past the text end like the reference's do — up to pl + tl — so the pair must satisfy pl + tl < 32767);
+//   global policy: int32 rings in HBM / L2, any penalties, any lengths.
+template <int CAP>
+struct AffLds {
+  volatile lds_i16* m; volatile lds_i16* i; volatile lds_i16* d;      // [rm][CAP], [ri][CAP], [ri][CAP]
+  __device__ __forceinline__ bool fits(int pl, int tl, int xs, int oes, int es) const { return pl + tl < 32767 && xs == 2 && oes == 4 && es == 1; }
+  __device__ __forceinline__ int cap() const { return CAP; }
+  static __device__ __forceinline__ int ld(volatile lds_i16* row, int k) { const int x = row[k & (CAP - 1)]; return x < 0 ? OTG_NULL_OFF : x; }
+  static __device__ __forceinline__ void stv(volatile lds_i16* row, int k, int h) { row[k & (CAP - 1)] = (int16_t)(h < 0 ? -32768 : h); }
+  __device__ __forceinline__ int rdM(int r, int k) const { return ld(m + r * CAP, k); }
+  __device__ __forceinline__ int rdI(int r, int k) const { return ld(i + r * CAP, k); }
+  __device__ __forceinline__ int rdD(int r, int k) const { return ld(d + r * CAP, k); }
+  __device__ __forceinline__ void wrM(int r, int k, int h) const { stv(m + r * CAP, k, h); }
+  __device__ __forceinline__ void wrI(int r, int k, int h) const { stv(i + r * CAP, k, h); }
+  __device__ __forceinline__ void wrD(int r, int k, int h) const { stv(d + r * CAP, k, h); }
+  __device__ __forceinline__ void sync() const {}
+};
+struct AffGlobal {
+  volatile int32_t* m; volatile int32_t* i; volatile int32_t* d; int capa; int kb;
+  __device__ __forceinline__ bool fits(int pl, int tl, int, int, int) const { return pl + tl + 3 <= capa; }
+  __device__ __forceinline__ int cap() const { return capa; }
+  __device__ __forceinline__ int rdM(int r, int k) const { return m[(size_t)r * capa + k + kb]; }
+  __device__ __forceinline__ int rdI(int r, int k) const { return i[(size_t)r * capa + k + kb]; }
+  __device__ __forceinline__ int rdD(int r, int k) const { return d[(size_t)r * capa + k + kb]; }
+  __device__ __forceinline__ void wrM(int r, int k, int h) const { m[(size_t)r * capa + k + kb] = h < 0 ? OTG_NULL_OFF : h; }
+  __device__ __forceinline__ void wrI(int r, int k, int h) const { i[(size_t)r * capa + k + kb] = h < 0 ? OTG_NULL_OFF : h; }
+  __device__ __forceinline__ void wrD(int r, int k, int h) const { d[(size_t)r * capa + k + kb] = h < 0 ? OTG_NULL_OFF : h; }
+  __device__ __forceinline__ void sync() const { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+};
+
+// CAP > 0: LDS policy with a window of CAP diagonals; CAP == 0: global policy.  RMAX = ring depth the LDS range tables hold.
+template <int CAP, int QCAP, int WPB, int RMAX>
+__global__ __launch_bounds__(WPB * 64) void wfa_affine_adaptive_kernel(
+    const uint8_t* __restrict__ arena, const otg_align_task* __restrict__ tasks,
+    const uint32_t* __restrict__ todo, const uint32_t* __restrict__ n_todo_ptr, uint32_t n_todo_imm,
+    int xs, int oes, int es, int g,
+    int32_t* __restrict__ scores, const uint64_t* __restrict__ cig_off, uint32_t* __restrict__ cig_len,
+    uint8_t* __restrict__ cig_arena, uint64_t* __restrict__ cells,
+    uint32_t* __restrict__ ticket, uint32_t* __restrict__ n_overflow, uint32_t* __restrict__ overflow_list,
+    AffWs ws, Heur H)
+{
+  constexpr bool GLOBAL_WF = CAP == 0;
+  constexpr int LCAP = GLOBAL_WF ? 2 : CAP;
+  constexpr int QWORDS = QCAP < 512 ? 512 : QCAP;            // the backtrace stages its window (2 KB) in the queue
+  __shared__ __attribute__((aligned(16))) int16_t s_rows[WPB][9][LCAP];      // M 0..4, I 5..6, D 7..8
+  __shared__ __attribute__((aligned(16))) uint32_t s_q[WPB][QWORDS];
+  __shared__ int s_rng[WPB][6][RMAX];                         // mlo, mhi, ilo, ihi, dlo, dhi per ring row
+  const int lane = threadIdx.x & 63;
+  const int wib = threadIdx.x >> 6;
+  uint8_t* my = ws.base + (size_t)(blockIdx.x * WPB + wib) * ws.stride;
+  int64_t* rowtab = (int64_t*)(my + ws.off_rowtab);
+  uint8_t* rev = my + ws.off_rev;
+  uint8_t* slab = my + ws.off_slab;
+  volatile __attribute__((address_space(3))) int* mlo = (volatile __attribute__((address_space(3))) int*)&s_rng[wib][0][0];
+  volatile __attribute__((address_space(3))) int* mhi = mlo + RMAX;
+  volatile __attribute__((address_space(3))) int* ilo = mlo + 2 * RMAX;
+  volatile __attribute__((address_space(3))) int* ihi = mlo + 3 * RMAX;
+  volatile __attribute__((address_space(3))) int* dlo = mlo + 4 * RMAX;
+  volatile __attribute__((address_space(3))) int* dhi = mlo + 5 * RMAX;
+  auto U = [](int x) { return __builtin_amdgcn_readfirstlane(x); };
+  volatile lds_u32* queue = (volatile lds_u32*)&s_q[wib][0];
+  const uint32_t n_todo = n_todo_ptr ? *n_todo_ptr : n_todo_imm;
+  const int rm = ws.rm, ri = ws.ri;
+
+  for (;;) {
+    const uint32_t tk = otg_wave_atomic_add(ticket, 1u);
+    if (tk >= n_todo) break;
+    const uint32_t ti = todo ? todo[tk] : tk;
+    const otg_align_task t = tasks[ti];
+    const uint8_t* P = arena + t.pattern_off;
+    const uint8_t* T = arena + t.text_off;
+    const int pl = (int)t.pattern_len, tl = (int)t.text_len;
+    const bool ef = t.endsfree != 0;
+    const int pef = ef ? t.pattern_end_free : 0, tef = ef ? t.text_end_free : 0;
+    const int kend = tl - pl;
+    int s_end = -1, k_end = 0;
+    uint64_t W = 0;
+    bool fail = false;
+
+    auto forward = [&](auto st) {
+      fail = !st.fits(pl, tl, xs, oes, es) || rm > RMAX || ri > RMAX;
+      size_t slab_top = 0;
+      int steps_wait = 0;
+      for (int s = 0; !fail; ++s) {
+        if (s >= ws.nrows) { fail = true; break; }
+        const int sm = s % rm, si = s % ri;
+        int lo, hi;
+        int qx = -1, qo = -1, qe = -1;
+        int mxlo = 1, mxhi = 0, molo = 1, mohi = 0, ielo = 1, iehi = 0, delo = 1, dehi = 0;
+        if (s == 0) {
+          lo = ef ? imax(-t.pattern_begin_free, -pl) : 0;
+          hi = ef ? imin(t.text_begin_free, tl) : 0;
+        } else {
+          lo = 1 << 30; hi = -(1 << 30);
+          if (s - xs >= 0) { qx = (s - xs) % rm; mxlo = U(mlo[qx]); mxhi = U(mhi[qx]); }
+          if (s - oes >= 0) { qo = (s - oes) % rm; molo = U(mlo[qo]); mohi = U(mhi[qo]); }
+          if (s - es >= 0) { qe = (s - es) % ri; ielo = U(ilo[qe]); iehi = U(ihi[qe]); delo = U(dlo[qe]); dehi = U(dhi[qe]); }
+          if (mxhi >= mxlo) { lo = imin(lo, mxlo); hi = imax(hi, mxhi); }
+          if (mohi >= molo) { lo = imin(lo, molo - 1); hi = imax(hi, mohi + 1); }
+          if (iehi >= ielo) { lo = imin(lo, ielo + 1); hi = imax(hi, iehi + 1); }
+          if (dehi >= delo) { lo = imin(lo, delo - 1); hi = imax(hi, dehi - 1); }
+          if (lo < -pl) lo = -pl;
+          if (hi > tl) hi = tl;
+        }
+        if (hi < lo) {       // null wavefront: this score is not reachable (the reference skips the heuristic too)
+          mlo[sm] = 1; mhi[sm] = 0; ilo[si] = 1; ihi[si] = 0; dlo[si] = 1; dhi[si] = 0;
+          rowtab[s] = -1;
+          if (s > 2 * (oes + es * (pl + tl)) + 8) fail = true;
+          continue;
+        }
+        const int width = hi - lo + 1;
+        if (width > st.cap() || slab_top + (size_t)width > ws.slab_bytes) { fail = true; break; }
+        uint8_t* btrow = slab + slab_top - lo;     // btrow[k]
+        rowtab[s] = (int64_t)slab_top - lo;      // wave-uniform store
+        slab_top += (size_t)width;
+        W += 3ull * (uint64_t)width;
+        int dmin = BIG, kfin = BIG;
+        int qn = 0;
+        auto finished = [&](int h, int k) {
+          dmin = imin(dmin, left_to_align(h, k, pl, tl, ef, pef, tef));
+          if (ef) { const int v = h - k; if ((h >= tl && pl - v <= pef) || (v >= pl && tl - h <= tef)) kfin = imin(kfin, k); }
+        };
+        auto drain = [&]() {
+          st.sync();
+          int pass = 0;
+          while (qn > 0) {
+            if (qn <= 4 && pass > 0) {
+              for (int e = 0; e < qn; ++e) {
+                const int kk = lo + U((int)queue[e]);
+                int h = U(st.rdM(sm, kk));
+                const int v = h - kk;
+                const int m = otg_wave_match(P, T, v, h, imin(pl - v, tl - h), lane);
+                h += m;
+                st.wrM(sm, kk, h);                // the same value from every lane
+                finished(h, kk);
+              }
+              qn = 0;
+              st.sync();
+              break;
+            }
+            int wq = 0;
+            for (int q0 = 0; q0 < qn; q0 += 64) {
+              const bool act = q0 + lane < qn;
+              int kk = 0, h = 0, v = 0;
+              bool more = false;
+              if (act) {
+                kk = lo + (int)queue[q0 + lane];
+                h = st.rdM(sm, kk);
+                v = h - kk;
+                const int rem = imin(pl - v, tl - h);
+                int m, full;
+                if (pass == 0) {
+                  const uint64_t xl = otg_load8(P + v) ^ otg_load8(T + h), xh = otg_load8(P + v + 8) ^ otg_load8(T + h + 8);
+                  m = xl ? (__builtin_ctzll(xl) >> 3) : (xh ? 8 + (__builtin_ctzll(xh) >> 3) : 16);
+                  m = imin(m, rem); full = 16;
+                } else { m = otg_match64(P, T, v, h, rem); full = 64; }
+                v += m; h += m;
+                more = (m == full) && v < pl && h < tl;
+                st.wrM(sm, kk, h);
+                if (!more) finished(h, kk);
+              }
+              const unsigned long long mm = __ballot(more);
+              if (more) {
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+                queue[wq + rank] = (uint32_t)(kk - lo);
+              }
+              wq += __builtin_popcountll(mm);
+            }
+            qn = wq; ++pass;
+            st.sync();
+          }
+        };
+        for (int c = lo; c <= hi; c += 64) {
+          const int k = c + lane;
+          const bool in = k <= hi;
+          int mx, ins = OTG_NULL_OFF, del = OTG_NULL_OFF;
+          uint32_t bits = 0;
+          if (s == 0) {
+            mx = k > 0 ? k : 0;
+          } else {
+            int io = OTG_NULL_OFF, dop = OTG_NULL_OFF, ix = OTG_NULL_OFF, dx = OTG_NULL_OFF, mm = OTG_NULL_OFF;
+            if (in) {
+              if (k - 1 >= molo && k - 1 <= mohi) io = st.rdM(qo, k - 1);
+              if (k + 1 >= molo && k + 1 <= mohi) dop = st.rdM(qo, k + 1);
+              if (k - 1 >= ielo && k - 1 <= iehi) ix = st.rdI(qe, k - 1);
+              if (k + 1 >= delo && k + 1 <= dehi) dx = st.rdD(qe, k + 1);
+              if (k >= mxlo && k <= mxhi) mm = st.rdM(qx, k);
+            }
+            if (ix >= io) { ins = ix; bits |= 4u; } else ins = io;
+            ins += 1;
+            if (dx >= dop) { del = dx; bits |= 8u; } else del = dop;
+            const int mis = mm + 1;
+            mx = imax(del, imax(mis, ins));
+            uint32_t org = 0;
+            if (mx == ins) org = 2;
+            if (mx == del) org = 1;
+            if (mx == mis) org = 0;
+            bits |= org;
+            if (ins < 0) ins = OTG_NULL_OFF;
+            if (del < 0) del = OTG_NULL_OFF;
+          }
+          int h = mx, v = mx - k;
+          const bool valid = in && mx >= 0 && h <= tl && v <= pl;
+          bool more = false;
+          if (valid && v < pl && h < tl) {
+            const uint64_t xx = otg_load8(P + v) ^ otg_load8(T + h);
+            int m = xx ? (__builtin_ctzll(xx) >> 3) : 8;
+            m = imin(m, imin(pl - v, tl - h));
+            v += m; h += m;
+            more = (m == 8) && v < pl && h < tl;
+          }
+          if (in) {
+            st.wrM(sm, k, valid ? h : OTG_NULL_OFF);
+            if (s > 0) { st.wrI(si, k, ins); st.wrD(si, k, del); }
+            btrow[k] = (uint8_t)bits;
+          }
+          if (valid && !more) finished(h, k);
+          const unsigned long long mq = __ballot(more);
+          if (more) {
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mq, 0u));
+            queue[qn + rank] = (uint32_t)(k - lo);
+          }
+          qn += __builtin_popcountll(mq);
+          if (qn + 64 > QCAP) drain();
+        }
+        drain();
+        // termination on the fully extended wavefront: end-to-end the end diagonal; ends-free the lowest diagonal that qualifies
+        bool done = false;
+        if (!ef) {
+          if (kend >= lo && kend <= hi) { const int x = U(st.rdM(sm, kend)); if (x >= tl) { done = true; k_end = kend; } }
+        } else {
+          const int kf = wave_min_i32(kfin);
+          if (kf != BIG) { done = true; k_end = kf; }
+        }
+        if (done) { s_end = s; break; }
+        // the cut: M[s], and the score's I / D wavefronts to the same range
+        int clo = lo, chi = hi;
+        const int mind = wave_min_i32(dmin);
+        wfadaptive_cut(H, steps_wait, mind, pl, tl, ef, pef, tef, clo, chi, lane, [&](int k) { return st.rdM(sm, k); });
+        mlo[sm] = clo; mhi[sm] = chi;
+        if (s == 0) { ilo[si] = 1; ihi[si] = 0; dlo[si] = 1; dhi[si] = 0; }       // no I / D wavefront at score 0
+        else { ilo[si] = clo; ihi[si] = chi; dlo[si] = clo; dhi[si] = chi; }
+        st.sync();
+      }
+    };
+    if constexpr (GLOBAL_WF) {
+      int32_t* ringM = (int32_t*)my;
+      int32_t* ringI = ringM + (size_t)ws.rm * ws.capa;
+      int32_t* ringD = ringI + (size_t)ws.ri * ws.capa;
+      forward(AffGlobal{ringM, ringI, ringD, ws.capa, pl + 1});
+    } else {
+      volatile lds_i16* rows = (volatile lds_i16*)&s_rows[wib][0][0];
+      forward(AffLds<CAP>{rows, rows + 5 * CAP, rows + 7 * CAP});
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");        // row table and provenance rows: written by lane 0 / every lane, read by all
+
+    if (fail || s_end < 0) {
+      if (overflow_list) { const uint32_t q = otg_wave_atomic_add(n_overflow, 1u); overflow_list[q] = ti; }
+      else { scores[ti] = -1; cig_len[ti] = 0; }
+      continue;
+    }
+    if (!backtrace_unpack<false>(P, pl, T, tl, s_end, k_end, xs, oes, es, rowtab, slab, rev, ws.rev_cap, cig_arena + cig_off[ti], lane, &scores[ti], &cig_len[ti], g,
+                                 (volatile lds_u32*)&s_q[wib][0], EqBytes{P, T})) continue;
+    if (cells) cells[ti] = W;
+  }
+}
+
+int gcd3(int a, int b, int c)
+{
+  auto g2 = [](int x, int y) { while (y) { int t = x % y; x = y; y = t; } return x; };
+  return g2(g2(a, b), c);
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------------------
+// Launch chains.  Same contracts as otg_launch_edit_todo / otg_launch_affine_todo (which hand over to these when the context's heuristic is
+// wfadaptive).  Counters: SLOT_COUNTERS words 112..127 (free of the exact chains' words).
+int otg_launch_edit_adaptive_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_task* d_tasks, const uint32_t* d_todo,
+                                  const uint32_t* d_n_todo, uint32_t n_tasks, int32_t* d_scores, uint64_t* d_cells,
+                                  float* kernel_ms, uint64_t* launches)
+{
+  if (n_tasks == 0) return OTG_OK;
+  if (ctx->pool[SLOT_COUNTERS].cap < 128 * sizeof(uint32_t)) ctx->affine_visited = nullptr;      // (it points into this slot; the exact chain sets it up again)
+  uint32_t* cnt = (uint32_t*)otg_slot(ctx, SLOT_COUNTERS, 128 * sizeof(uint32_t));
+  uint32_t* lists = (uint32_t*)otg_slot(ctx, SLOT_TODO, 3 * (size_t)n_tasks * sizeof(uint32_t));
+  if (!cnt || !lists) return OTG_ERR_HIP;
+  uint32_t* c = cnt + 112;                    // c[0..3] tickets of the four tiers, c[4..6] lengths of the overflow lists
+  HIP_TRY(ctx, hipMemsetAsync(c, 0, 8 * sizeof(uint32_t), ctx->stream));
+  const Heur H{ctx->heur_min_wf_len, ctx->heur_max_dist, ctx->heur_steps < 1 ? 1 : ctx->heur_steps};
+  const uint32_t ncu = (uint32_t)ctx->n_cu;
+  static const int only = getenv("OTG_ADAPTIVE_EDIT_TIERS") ? atoi(getenv("OTG_ADAPTIVE_EDIT_TIERS")) : 15;      // test switch: bit t = tier t runs (the last one always does)
+  if (kernel_ms) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  const uint32_t* in = d_todo; const uint32_t* in_n = d_n_todo; uint32_t in_imm = n_tasks;
+  uint32_t* l0 = lists; uint32_t* l1 = lists + n_tasks; uint32_t* l2 = lists + 2 * (size_t)n_tasks;
+  if (only & 1) {       // window of 256 diagonals: 2.5 KB of LDS per wave, 8 waves per SIMD by registers
+    constexpr int WPB = 4;
+    const uint32_t grid = std::min<uint32_t>(ncu * 8, (n_tasks + WPB - 1) / WPB);
+    hipLaunchKernelGGL((wfa_edit_adaptive_kernel<256, 512, WPB>), dim3(grid), dim3(WPB * 64), 0, ctx->stream, d_arena, d_tasks, in, in_n, in_imm,
+                       d_scores, d_cells, c + 0, c + 4, l0, H, (int32_t*)nullptr, 0);
+    in = l0; in_n = c + 4; in_imm = 0;
+  }
+  if (only & 2) {       // 2048 diagonals: 12 KB per wave
+    constexpr int WPB = 2;
+    const uint32_t grid = std::min<uint32_t>(ncu * 6, (n_tasks + WPB - 1) / WPB);
+    hipLaunchKernelGGL((wfa_edit_adaptive_kernel<2048, 2048, WPB>), dim3(grid), dim3(WPB * 64), 0, ctx->stream, d_arena, d_tasks, in, in_n, in_imm,
+                       d_scores, d_cells, c + 1, c + 5, l1, H, (int32_t*)nullptr, 0);
+    in = l1; in_n = c + 5; in_imm = 0;
+  }
+  if (only & 4) {       // 16384 diagonals: 40 KB per wave
+    constexpr int WPB = 1;
+    const uint32_t grid = std::min<uint32_t>(ncu * 3, n_tasks);
+    hipLaunchKernelGGL((wfa_edit_adaptive_kernel<16384, 2048, WPB>), dim3(grid), dim3(WPB * 64), 0, ctx->stream, d_arena, d_tasks, in, in_n, in_imm,
+                       d_scores, d_cells, c + 2, c + 6, l2, H, (int32_t*)nullptr, 0);
+    in = l2; in_n = c + 6; in_imm = 0;
+  }
+  {                     // int32 wavefront in HBM, sized for the longest pair of the batch
+    constexpr int WPB = 4;
+    const uint32_t grid = ncu;
+    const int gcap = (int)(2 * (size_t)ctx->max_seq_len + 4);
+    int32_t* ws = (int32_t*)otg_slot(ctx, SLOT_WF_WS, (size_t)grid * WPB * (size_t)gcap * sizeof(int32_t));
+    if (!ws) return OTG_ERR_HIP;
+    hipLaunchKernelGGL((wfa_edit_adaptive_kernel<0, 2048, WPB>), dim3(grid), dim3(WPB * 64), 0, ctx->stream, d_arena, d_tasks, in, in_n, in_imm,
+                       d_scores, d_cells, c + 3, c + 7, (uint32_t*)nullptr, H, ws, gcap);
+  }
+  if (kernel_ms) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  HIP_TRY(ctx, hipGetLastError());
+  if (getenv("OTG_DEBUG")) {
+    hipError_t er = hipStreamSynchronize(ctx->stream);
+    uint32_t h[8];
+    (void)hipMemcpy(h, c, sizeof(h), hipMemcpyDeviceToHost);
+    fprintf(stderr, "[otg] edit, wfadaptive(%d,%d,%d): %s; the 256-diagonal window passes on %u pairs, the 2048 one %u, the 16384 one %u\n",
+            H.min_wf_len, H.max_dist, H.steps, hipGetErrorString(er), h[4], h[5], h[6]);
+  }
+  if (kernel_ms) {
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *kernel_ms += ms;
+    if (launches) *launches += 1;
+  }
+  return OTG_OK;
+}
+
+int otg_launch_affine_adaptive_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_task* d_tasks, const uint32_t* d_todo,
+                                    const uint32_t* d_n_todo, uint32_t n_tasks, int x, int o, int e, int32_t* d_scores,
+                                    const uint64_t* d_cig_off, uint32_t* d_cig_len, uint8_t* d_cig_arena, uint64_t* d_cells,
+                                    float* kernel_ms, uint64_t* launches)
+{
+  if (n_tasks == 0) return OTG_OK;
+  if (x <= 0 || e <= 0 || o < 0) return otg_fail(ctx, OTG_ERR_ARG, "affine penalties must satisfy x>0, o>=0, e>0");
+  const int g = gcd3(x, o + e, e);
+  const int xs = x / g, oes = (o + e) / g, es = e / g;
+  if (std::max(xs, oes) + 1 > 64 || es + 1 > 64) return otg_fail(ctx, OTG_ERR_ARG, "affine penalties too large after gcd reduction");
+  if (ctx->pool[SLOT_COUNTERS].cap < 128 * sizeof(uint32_t)) ctx->affine_visited = nullptr;
+  uint32_t* cnt = (uint32_t*)otg_slot(ctx, SLOT_COUNTERS, 128 * sizeof(uint32_t));
+  uint32_t* lists = (uint32_t*)otg_slot(ctx, SLOT_TODO, 2 * (size_t)n_tasks * sizeof(uint32_t));
+  if (!cnt || !lists) return OTG_ERR_HIP;
+  uint32_t* c = cnt + 120;                    // c[0..2] tickets, c[3..4] lengths of the overflow lists
+  HIP_TRY(ctx, hipMemsetAsync(c, 0, 8 * sizeof(uint32_t), ctx->stream));
+  const Heur H{ctx->heur_min_wf_len, ctx->heur_max_dist, ctx->heur_steps < 1 ? 1 : ctx->heur_steps};
+  const uint32_t ncu = (uint32_t)ctx->n_cu;
+  const size_t maxlen = ((size_t)ctx->max_seq_len + 4095) & ~(size_t)4095;
+  static const int only = getenv("OTG_ADAPTIVE_AFFINE_TIERS") ? atoi(getenv("OTG_ADAPTIVE_AFFINE_TIERS")) : 7;
+
+  AffWs ws;
+  ws.capa = (int)(2 * maxlen + 16) & ~1;
+  ws.rm = std::max(xs, oes) + 1;
+  ws.ri = es + 1;
+  ws.nrows = (int)(2 * (size_t)oes + (size_t)es * 2 * maxlen + 16);
+  ws.rev_cap = 4 * maxlen + 64;
+  ws.dbg = 0; ws.visited = nullptr;
+  // LDS tiers: no rings in HBM, only row table + reversed op list + provenance slab
+  auto lds_ws = [&](size_t slab) {
+    AffWs w = ws;
+    w.off_rowtab = 0;
+    w.off_rev = ((size_t)w.nrows * sizeof(int64_t) + 255) & ~(size_t)255;
+    w.off_slab = (w.off_rev + w.rev_cap + 255) & ~(size_t)255;
+    w.slab_bytes = slab & ~(size_t)255;
+    w.stride = w.off_slab + w.slab_bytes;
+    return w;
+  };
+  constexpr int WPB0 = 4, WPB1 = 1, WPB2 = 4;
+  // provenance: a row per score, as wide as the wavefront.  Mean width under the cut ~100 diagonals, scores ~0.4 per base
+  // (gcd units): 40 x maxlen bytes hold the typical alignment of the first tier four times over; the second tier gets 16 x that.
+  AffWs w0 = lds_ws(std::max<size_t>((size_t)160 * maxlen, (size_t)1 << 19));
+  AffWs w1 = lds_ws(std::max<size_t>((size_t)2560 * maxlen, (size_t)1 << 23));
+  uint32_t grid0 = std::min<uint32_t>(ncu * 4, (n_tasks + WPB0 - 1) / WPB0), grid1 = std::min<uint32_t>(ncu * 2, n_tasks), grid2 = 2;
+  AffWs w2 = ws;
+  {
+    const size_t ring_bytes = (size_t)(ws.rm + 2 * ws.ri) * ws.capa * sizeof(int32_t);
+    w2.off_rowtab = (ring_bytes + 255) & ~(size_t)255;
+    w2.off_rev = (w2.off_rowtab + (size_t)ws.nrows * sizeof(int64_t) + 255) & ~(size_t)255;
+    w2.off_slab = (w2.off_rev + ws.rev_cap + 255) & ~(size_t)255;
+  }
+  {
+    std::lock_guard<std::mutex> alloc_lock(otg_device_mutex(ctx->device));
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+    const size_t budget = std::min<size_t>((size_t)(total_b * 0.15), (size_t)((free_b + ctx->pool[SLOT_WF_WS].cap) * 0.8));
+    while (grid1 > 8 && w1.stride * grid1 * WPB1 > budget / 2) grid1 /= 2;
+    while (grid0 > 8 && w0.stride * grid0 * WPB0 > budget / 2) grid0 /= 2;
+    // the generic tier: the worst case of the longest pair of the batch (every diagonal at every score), as far as the budget goes
+    size_t slab2 = std::min<size_t>((size_t)2 * maxlen * (size_t)ws.nrows, budget / (grid2 * WPB2));
+    if (slab2 > w2.off_slab + 256) slab2 -= w2.off_slab + 256;
+    w2.slab_bytes = slab2 & ~(size_t)255; w2.stride = w2.off_slab + w2.slab_bytes;
+    const size_t need = std::max(std::max(w0.stride * grid0 * WPB0, w1.stride * grid1 * WPB1), w2.stride * (size_t)grid2 * WPB2);
+    uint8_t* wsp = (uint8_t*)otg_slot(ctx, SLOT_WF_WS, need);
+    if (!wsp) return OTG_ERR_HIP;
+    w0.base = w1.base = w2.base = wsp;
+  }
+  if (kernel_ms) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  const uint32_t* in = d_todo; const uint32_t* in_n = d_n_todo; uint32_t in_imm = n_tasks;
+  uint32_t* l0 = lists; uint32_t* l1 = lists + n_tasks;
+  if (only & 1) {
+    hipLaunchKernelGGL((wfa_affine_adaptive_kernel<256, 512, WPB0, 8>), dim3(grid0), dim3(WPB0 * 64), 0, ctx->stream, d_arena, d_tasks, in, in_n, in_imm,
+                       xs, oes, es, g, d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, c + 0, c + 3, l0, w0, H);
+    in = l0; in_n = c + 3; in_imm = 0;
+  }
+  if (only & 2) {
+    hipLaunchKernelGGL((wfa_affine_adaptive_kernel<2048, 2048, WPB1, 8>), dim3(grid1), dim3(WPB1 * 64), 0, ctx->stream, d_arena, d_tasks, in, in_n, in_imm,
+                       xs, oes, es, g, d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, c + 1, c + 4, l1, w1, H);
+    in = l1; in_n = c + 4; in_imm = 0;
+  }
+  hipLaunchKernelGGL((wfa_affine_adaptive_kernel<0, 2048, WPB2, 64>), dim3(grid2), dim3(WPB2 * 64), 0, ctx->stream, d_arena, d_tasks, in, in_n, in_imm,
+                     xs, oes, es, g, d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, c + 2, c + 5, (uint32_t*)nullptr, w2, H);
+  if (kernel_ms) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  HIP_TRY(ctx, hipGetLastError());
+  if (getenv("OTG_DEBUG")) {
+    hipError_t er = hipStreamSynchronize(ctx->stream);
+    uint32_t h[8];
+    (void)hipMemcpy(h, c, sizeof(h), hipMemcpyDeviceToHost);
+    fprintf(stderr, "[otg] affine, wfadaptive(%d,%d,%d): %s; the 256-diagonal window passes on %u alignments, the 2048 one %u; %u / %u alignments in flight, %.2f / %.2f MB each\n",
+            H.min_wf_len, H.max_dist, H.steps, hipGetErrorString(er), h[3], h[4], grid0 * WPB0, grid1 * WPB1, (double)w0.stride / 1e6, (double)w1.stride / 1e6);
+  }
+  if (kernel_ms) {
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *kernel_ms += ms;
+    if (launches) *launches += 1;
+  }
+  return OTG_OK;
+}

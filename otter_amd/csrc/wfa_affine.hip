@@ -849,6 +849,9 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
                            float* kernel_ms, uint64_t* launches)
 {
   if (n_tasks == 0) return OTG_OK;
+  if (ctx->heur_strategy == OTG_HEURISTIC_WFADAPTIVE)
+    return otg_launch_affine_adaptive_todo(ctx, d_arena, d_tasks, d_todo, d_n_todo, n_tasks, x, o, e, d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells,
+                                           kernel_ms, launches);
   if (x <= 0 || e <= 0 || o < 0) return otg_fail(ctx, OTG_ERR_ARG, "affine penalties must satisfy x>0, o>=0, e>0");
   const int g = gcd3(x, o + e, e);
   const int xs = x / g, oes = (o + e) / g, es = e / g;

@@ -576,6 +576,8 @@ int otg_launch_edit_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_t
 
 {
   if (n_tasks == 0) return OTG_OK;
+  if (ctx->heur_strategy == OTG_HEURISTIC_WFADAPTIVE)
+    return otg_launch_edit_adaptive_todo(ctx, d_arena, d_tasks, d_todo, d_n_todo, n_tasks, d_scores, d_cells, kernel_ms, launches);
   uint32_t* cnt = (uint32_t*)otg_slot(ctx, SLOT_COUNTERS, 64 * sizeof(uint32_t));
   constexpr int NT = OTG_MYERS_TIERS;
   uint32_t* todo = (uint32_t*)otg_slot(ctx, SLOT_TODO, (size_t)(NT + 4) * n_tasks * sizeof(uint32_t));

@@ -47,6 +47,11 @@ def ref():
     return _ref
 
 
+def set_heuristic(on, min_wf_len=10, max_dist=50, steps=1):
+    """Process-wide heuristic of the oracle's L1 aligners (0 = exact); the pipeline entry points take theirs from otg_params."""
+    lib().oto_set_heuristic(int(on), int(min_wf_len), int(max_dist), int(steps))
+
+
 def _b(s):
     return np.frombuffer(s if isinstance(s, (bytes, bytearray)) else s.encode(), dtype=np.uint8)
 
