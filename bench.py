@@ -11,7 +11,9 @@ line also carries, under `config`:
   host_to_host   the same batch from host memory to records in host memory (SURVEY §8d's kernel-path metric: submit + run + collect);
   legs           configs[2] (the same with -r and soft-clipped divergent flanks), configs[4] (north_star's shape: 1-10 kb regions, the
                  12 500-region shard one GPU owns of the 100 000-region 8-GPU job) and configs[3] (otter genotype's allele clustering,
-                 5 000 regions x 101 alleles), each with value / ms_per_step / stage_ms / roofline (/ cpu_baseline);
+                 5 000 regions x 101 alleles), each with value / ms_per_step / stage_ms / roofline (/ cpu_baseline); and
+                 configs[1]_adaptive: the timed workload again with both aligners under wfadaptive(10, 50, 1) (otg_params.heuristic — the mode
+                 the reference's binary runs in if its WFA2-lib build defaults to it; `cpu_baseline.adaptive` is the oracle in that mode);
   e2e            BED + BAM -> SAM text through the library's dispatcher on 10 000 loci of configs[1]'s shape.
 --config N makes another configuration the timed one; --no-legs / --e2e-regions 0 / --no-cpu-baseline switch the extras off.
 
@@ -48,7 +50,9 @@ def parse_args():
     ap.add_argument("--regions", type=int, default=None, help="regions per GPU (default: the config's own count; config 4: 100000/8)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU work per cpu_baseline run (3 runs per kind)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-legs", action="store_true", help="skip the configs[2] / [3] / [4] legs (N = 1 only has them)")
+    ap.add_argument("--no-legs", action="store_true", help="skip the configs[2] / [3] / [4] / adaptive legs (N = 1 has them all; N > 1 the configs[4] shard)")
+    ap.add_argument("--heuristic", choices=("none", "wfadaptive"), default="none",
+                    help="aligner mode of the TIMED workload: none = exact (the contract), wfadaptive = WFA2-lib's adaptive reduction (10, 50, 1)")
     ap.add_argument("--leg-steps", type=int, default=3)
     ap.add_argument("--e2e-regions", type=int, default=10000, help="regions of the file-to-text leg (BED + BAM -> SAM text through otg_assemble_files); 0: skip")
     return ap.parse_args()
@@ -88,7 +92,7 @@ def spawn_ranks(n):
 
 
 # ------------------------------------------------------------------------------------------------ CPU baselines
-def cpu_baseline(batch, params, seconds, n_threads, runs=3, with_reference_consensus=True):
+def cpu_baseline(batch, params, seconds, n_threads, runs=3, with_reference_consensus=True, adaptive_params=None):
     """The CPU oracle (oracle/libotter_oracle.so, a port of the reference algorithm) on a bounded sample of the same workload, all host
     threads (ctypes releases the GIL; static contiguous split as the reference's thread pool).  Two kinds, `runs` runs each, median:
       port                 — the port as it is (O(N+E) consensus): BASELINE.md §3 baseline B
@@ -101,6 +105,8 @@ def cpu_baseline(batch, params, seconds, n_threads, runs=3, with_reference_conse
     L = oracle_lib.lib()
     n_regions = len(batch["regions"])
 
+    cur = [params]
+
     def run(n_sample):
         bounds = [(i * n_sample // n_threads, (i + 1) * n_sample // n_threads) for i in range(n_threads)]
         done = [0] * n_threads
@@ -108,7 +114,7 @@ def cpu_baseline(batch, params, seconds, n_threads, runs=3, with_reference_conse
         def work(i):
             a, b = bounds[i]
             if b > a:
-                r = oracle_lib.assemble_batch(params, batch, region_range=(a, b))
+                r = oracle_lib.assemble_batch(cur[0], batch, region_range=(a, b))
                 done[i] = int((r["regions"]["n_alleles"][a:b] > 0).sum())
         t0 = time.perf_counter()
         th = [threading.Thread(target=work, args=(i,)) for i in range(n_threads)]
@@ -140,6 +146,12 @@ def cpu_baseline(batch, params, seconds, n_threads, runs=3, with_reference_conse
             out["reference_consensus"] = dict(a, kind="port + reference PPOA")
         finally:
             L.oto_set_poa_hook(None)
+    if adaptive_params is not None:      # the same port with both aligners under wfadaptive(10, 50, 1): what a reference whose WFA2-lib defaults to it would cost
+        cur[0] = adaptive_params
+        try:
+            out["adaptive"] = dict(measure("oracle port under wfadaptive(10,50,1) in both aligners"), kind="port, adaptive aligners")
+        finally:
+            cur[0] = params
     return out
 
 
@@ -217,7 +229,7 @@ def pmc_for(cfg, n_regions):
     return None
 
 
-def roofline(kstats, cfg, n_regions):
+def roofline(kstats, cfg, n_regions, adaptive=False):
     """The dominant kernel chain by HIP-event time (events on the library's own stream).  `frac` = SURVEY §8(d)'s algorithmic bytes / time against
     the HBM peak, as the contract defines it — a work-equivalent rate: the kernels keep wavefronts in registers and visit a fraction of the
     counted cells.  Beside it what the implementation must move at least (`impl_min_bytes`: sequences + one provenance byte per VISITED cell
@@ -240,7 +252,9 @@ def roofline(kstats, cfg, n_regions):
         out["impl_min_bytes"] = impl_min // kl
         out["affine_visited_cells"] = visited
         out["affine_visited_cells_per_s"] = round(visited / (ak * 1e-3), 1) if ak > 0 else None
-    pm = pmc_for(cfg, n_regions)
+    if adaptive:
+        out["note"] = "frac = SURVEY 8(d) bytes of the wavefront cells the adaptive aligner evaluates (counted by the kernels, equal to the oracle's count) / time"
+    pm = None if adaptive else pmc_for(cfg, n_regions)
     if pm:
         out["traffic"] = pm.get("traffic_bytes_per_launch", {}).get(kname)
         ph = pm.get("physical", {}).get(kname, {})
@@ -353,8 +367,9 @@ def run_rank(args):
         return 0
 
     # ---- an assemble workload resident in HBM: K timed steps (+ the host-to-host passes)
-    def assemble_run(c, b, steps, warmup, h2h_passes):
-        params = abi.default_params(realign=1 if synth.CONFIGS[c].get("realign") else 0)
+    def assemble_run(c, b, steps, warmup, h2h_passes, heuristic="none"):
+        params = abi.default_params(realign=1 if synth.CONFIGS[c].get("realign") else 0,
+                                    heuristic=abi.OTG_HEURISTIC_WFADAPTIVE if heuristic == "wfadaptive" else abi.OTG_HEURISTIC_NONE)
         t_sub = time.perf_counter()
         ctx.assemble_submit(params, b)       # H2D: inputs are resident in HBM from here on
         submit_ms = (time.perf_counter() - t_sub) * 1000.0
@@ -397,7 +412,7 @@ def run_rank(args):
             h2h = (time.perf_counter() - t1) / h2h_passes
         return {"dt": dt, "kstats": kstats, "info": info, "submit_ms": submit_ms, "h2h_s": h2h, "params": params}
 
-    r = assemble_run(cfg, batch, args.steps, args.warmup, min(3, max(1, args.steps)))
+    r = assemble_run(cfg, batch, args.steps, args.warmup, min(3, max(1, args.steps)), args.heuristic)
     st = r["kstats"][-1]
     regions_ok = int(st["n_regions_ok"])
     dt = r["dt"]
@@ -424,6 +439,7 @@ def run_rank(args):
         "config": {"workload": synth.config_workload(cfg, n_regions, world), "baseline_config": cfg,
                    "regions_per_gpu": n_regions, "reads_per_region": synth.CONFIGS[cfg]["n_reads"],
                    "parallelism": "static BED shard x%d + RCCL gather" % world, "world_size_rccl": world_seen,
+                   "aligner_heuristic": "none (exact)" if args.heuristic == "none" else "wfadaptive(10,50,1)",
                    "timed_region": "otg_assemble_run + " + ("RCCL gather to rank 0 + one D2H" if world > 1 else "otg_assemble_collect (D2H of the records)") + "; inputs resident in HBM",
                    "stage_ms": stage_ms(st),
                    "edit_pairs": int(st["edit_tasks"]), "affine_alignments": int(st["affine_tasks"]),
@@ -441,12 +457,25 @@ def run_rank(args):
         out["config"]["collect_ms_last_step"] = round(info.get("collect_ms", 0.0), 2)
     if not args.no_cpu_baseline and world == 1:        # rank 0 at N=1 only
         try:
-            out["cpu_baseline"] = cpu_baseline(batch, r["params"], args.cpu_seconds, nth)
+            pa = abi.default_params(realign=r["params"].realign, heuristic=abi.OTG_HEURISTIC_WFADAPTIVE)
+            out["cpu_baseline"] = cpu_baseline(batch, r["params"], args.cpu_seconds, nth, adaptive_params=pa if args.heuristic == "none" else None)
         except Exception as e:  # the oracle is only a reported baseline; never fail the bench line on it
             out["cpu_baseline"] = {"value": None, "unit": "regions/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
     # ---- the other BASELINE configurations (N = 1): same timed region, fewer steps
     if want_legs:
         legs = {}
+        try:         # the timed workload again under the adaptive heuristic
+            lr = assemble_run(cfg, batch, args.leg_steps, 1, 1, "wfadaptive" if args.heuristic == "none" else "none")
+            ls = lr["kstats"][-1]
+            legs["configs[%d]_%s" % (cfg, "adaptive" if args.heuristic == "none" else "exact")] = {
+                "workload": synth.config_workload(cfg, n_regions, 1), "aligner_heuristic": "wfadaptive(10,50,1)" if args.heuristic == "none" else "none (exact)",
+                "value": round(int(ls["n_regions_ok"]) * args.leg_steps / lr["dt"], 2), "unit": "regions/s",
+                "ms_per_step": round(lr["dt"] * 1000.0 / args.leg_steps, 2), "steps": args.leg_steps, "stage_ms": stage_ms(ls),
+                "host_to_host_regions_per_s": round(int(ls["n_regions_ok"]) / lr["h2h_s"], 2), "allele_records": lr["info"].get("records"),
+                "edit_pairs": int(ls["edit_tasks"]), "affine_alignments": int(ls["affine_tasks"]), "wavefront_cells": int(ls["edit_cells"]) + int(ls["affine_cells"]),
+                "roofline": roofline(lr["kstats"], cfg, n_regions, adaptive=args.heuristic == "none")}
+        except Exception as e:
+            legs["configs[%d]_adaptive" % cfg] = {"error": repr(e)}
         for c in (2, 4):
             try:
                 b = legs_in[c]

@@ -14,7 +14,11 @@
  * of `-lwfacpp` (Makefile:5) runs its alignments on the MI355X — one alignment per call, i.e. at kernel-launch latency: a correctness drop-in
  * for the operator boundary.  Throughput needs the region-level boundary (otg_assemble_*, include/otter_gpu.h), which batches all
  * alignments of thousands of regions per launch.  Enumerators and their values are those of WFA2-lib v2.3.x (recovered from the debug
- * bundle test/ppoa_test.dSYM).  Exact mode only (no heuristic), like the rest of this library.
+ * bundle test/ppoa_test.dSYM).  Heuristics: setHeuristicNone() (the default of THIS adapter: exact alignment) and
+ * setHeuristicWFadaptive(min_wavefront_length, max_distance_threshold, steps_between_cutoffs) — WFAligner.hpp:107-122 of WFA2-lib.  otter
+ * calls neither (src/assemble.cpp:49-50), i.e. it runs WFA2-lib's own default; a build that wants the adaptive default of WFA2-lib v2.3
+ * defines OTG_ADAPTER_DEFAULT_WFADAPTIVE (aligners then start in wfadaptive(10, 50, 1)).  The banded / x-drop / z-drop strategies are not
+ * provided (nothing in otter reaches them).
  *
  * One otg_ctx per aligner object, created on first use; without a HIP device every align call returns StatusOOM (there is no CPU fallback)
  * and strError() says why.  Not thread-safe per object — as the reference uses it: one aligner pair per worker thread.
@@ -42,6 +46,13 @@ class WFAligner {
   {
     return run(pattern, text, 1, pattern_begin_free, pattern_end_free, text_begin_free, text_end_free);
   }
+  // Heuristic of the following align calls (WFAligner.hpp:107-122 of WFA2-lib)
+  void setHeuristicNone() { heur_ = OTG_HEURISTIC_NONE; heur_dirty_ = true; }
+  void setHeuristicWFadaptive(const int min_wavefront_length, const int max_distance_threshold, const int steps_between_cutoffs = 1)
+  {
+    heur_ = OTG_HEURISTIC_WFADAPTIVE; heur_p_[0] = min_wavefront_length; heur_p_[1] = max_distance_threshold; heur_p_[2] = steps_between_cutoffs;
+    heur_dirty_ = true;
+  }
   int getAlignmentScore() { return score_; }
   int getAlignmentStatus() { return (int)status_; }
   std::string getAlignmentCigar() { return cigar_; }
@@ -62,6 +73,10 @@ class WFAligner {
   {
     score_ = 0; cigar_.clear(); status_ = StatusOOM;
     if (!ctx_ && otg_create(0, &ctx_) != OTG_OK) { const char* m = otg_last_error(nullptr); error_ = m ? m : "otg_create failed"; ctx_ = nullptr; return status_; }
+    if (heur_dirty_) {
+      if (otg_set_heuristic(ctx_, heur_, heur_p_[0], heur_p_[1], heur_p_[2]) != OTG_OK) { const char* m = otg_last_error(ctx_); error_ = m ? m : "otg_set_heuristic failed"; return status_; }
+      heur_dirty_ = false;
+    }
     // one arena: pattern, text, 64 bytes of slack (the kernels' 8-byte probes may read past an end)
     arena_.assign(pattern.size() + text.size() + 64, 0);
     if (!pattern.empty()) arena_.replace(0, pattern.size(), pattern);
@@ -86,6 +101,13 @@ class WFAligner {
     return status_;
   }
   otg_ctx* ctx_ = nullptr;
+#ifdef OTG_ADAPTER_DEFAULT_WFADAPTIVE
+  int heur_ = OTG_HEURISTIC_WFADAPTIVE;
+#else
+  int heur_ = OTG_HEURISTIC_NONE;
+#endif
+  int heur_p_[3] = {10, 50, 1};
+  bool heur_dirty_ = true;
   AlignmentScope scope_;
   AlignmentStatus status_ = StatusSuccessful;
   int score_ = 0;

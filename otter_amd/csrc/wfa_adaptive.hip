@@ -284,6 +284,217 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_adaptive_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Both sequences of a pair packed to 2 bits per base in LDS (word q = bases 16 q .. 16 q + 15, code (byte >> 1) & 3; pattern at word 0,
+// text at word offT): a probe compares 32 bases with six LDS reads instead of two HBM round trips — under the cut a wave advances one
+// score at a time and every score ends in a probe, so the probe latency IS the kernel's speed.  A pair with a byte outside ACGT, or too
+// long for the wave's share of LDS, is not packed (`ok` false) and runs on the byte probes of the generic kernels.
+struct PackedPair {
+  volatile lds_u32* SQ; int offT; bool ok;
+  // seqw = words of LDS this wave owns for the pair (dynamic shared memory, sized by the launcher from the batch's longest read)
+  __device__ __forceinline__ void init(const uint8_t* P, int pl, const uint8_t* T, int tl, int lane, int seqw)
+  {
+    offT = (pl + 15) / 16 + 3;
+    ok = offT + (tl + 15) / 16 + 3 <= seqw;
+    if (!ok) return;
+    bool bad = false;
+    auto pack = [&](const uint8_t* S, int len, int woff) {
+      for (int q = lane; q < (len + 15) / 16 + 3; q += 64) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int b0 = 16 * q + 8 * j;
+          const uint64_t x = b0 < len ? otg_load8(S + b0) : 0ull;        // (the arena has 64 bytes of slack behind its last sequence)
+#pragma unroll
+          for (int t2 = 0; t2 < 8; ++t2) {
+            const uint32_t c = (uint32_t)(x >> (8 * t2)) & 0xffu;
+            const uint32_t code = (c >> 1) & 3u;
+            if (b0 + t2 < len && c != ((0x47544341u >> (8 * code)) & 0xffu)) bad = true;
+            w |= code << (2 * (8 * j + t2));
+          }
+        }
+        SQ[woff + q] = w;
+      }
+    };
+    pack(P, pl, 0);
+    pack(T, tl, offT);
+    ok = __ballot(bad) == 0ull;
+  }
+  __device__ __forceinline__ uint64_t ld32(int woff, int pos) const
+  {
+    const int w = woff + (pos >> 4);
+    const uint32_t sh = (uint32_t)(pos & 15) * 2u;
+    const uint32_t d0 = SQ[w], d1 = SQ[w + 1], d2 = SQ[w + 2];
+    return (uint64_t)__builtin_amdgcn_alignbit(d1, d0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32);
+  }
+  // equal bases from pattern position v / text position h on, at most 32 and at most rem (0 <= v, h; rem >= 0)
+  __device__ __forceinline__ int match32(int v, int h, int rem) const
+  {
+    const uint64_t xx = ld32(0, v) ^ ld32(offT, h);
+    const int m = xx ? (int)(__builtin_ctzll(xx) >> 1) : 32;
+    return imin(m, rem);
+  }
+};
+
+// The fast edit tier: window of CAP diagonals (signed 16-bit offsets, null = -32768) + the packed pair in LDS.  Invariant that removes every
+// range test from the sweep: a slot of the window is non-null only while its diagonal is inside the live range — the window is null-filled per
+// pair, and the diagonals a cut drops are nulled right there — so the recurrence reads its neighbours unconditionally.
+template <int CAP, int QCAP, int WPB>
+__global__ __launch_bounds__(WPB * 64) void wfa_edit_adaptive_lds_kernel(
+    const uint8_t* __restrict__ arena, const otg_align_task* __restrict__ tasks,
+    const uint32_t* __restrict__ todo, const uint32_t* __restrict__ n_todo_ptr, uint32_t n_todo_imm,
+    int32_t* __restrict__ scores, uint64_t* __restrict__ cells,
+    uint32_t* __restrict__ ticket, uint32_t* __restrict__ n_overflow, uint32_t* __restrict__ overflow_list, Heur H, int seqw)
+{
+  __shared__ __attribute__((aligned(16))) int16_t s_wf[WPB][CAP];
+  __shared__ uint16_t s_q[WPB][QCAP];
+  extern __shared__ uint32_t s_dyn[];                         // [WPB][seqw]: the packed pairs
+  const int lane = threadIdx.x & 63;
+  const int wib = threadIdx.x >> 6;
+  volatile lds_i16* wf = (volatile lds_i16*)&s_wf[wib][0];
+  volatile lds_u32* wf32 = (volatile lds_u32*)&s_wf[wib][0];
+  volatile lds_u16* queue = (volatile lds_u16*)&s_q[wib][0];
+  const uint32_t n_todo = n_todo_ptr ? *n_todo_ptr : n_todo_imm;
+  constexpr int MASK = CAP - 1;
+  constexpr int NUL = -32768;
+
+  for (;;) {
+    const uint32_t tk = otg_wave_atomic_add(ticket, 1u);
+    if (tk >= n_todo) break;
+    const uint32_t ti = todo ? todo[tk] : tk;
+    const otg_align_task t = tasks[ti];
+    const uint8_t* P = arena + t.pattern_off;
+    const uint8_t* T = arena + t.text_off;
+    const int pl = (int)t.pattern_len, tl = (int)t.text_len;
+    const bool ef = t.endsfree != 0;
+    const int pef = ef ? t.pattern_end_free : 0, tef = ef ? t.text_end_free : 0;
+    const int kend = tl - pl;
+    int lo = ef ? -t.pattern_begin_free : 0, hi = ef ? t.text_begin_free : 0;
+    if (lo < -pl) lo = -pl;
+    if (hi > tl) hi = tl;
+    bool overflow = pl > 32766 || tl > 32766 || hi - lo + 3 > CAP;
+    PackedPair pk{(volatile lds_u32*)(s_dyn + (size_t)wib * seqw), 0, false};
+    if (!overflow) { pk.init(P, pl, T, tl, lane, seqw); overflow = !pk.ok; }
+    int s = 0, steps_wait = 0;
+    uint64_t W = 0;
+    bool done = false;
+    if (!overflow) for (int q = lane; q < CAP / 2; q += 64) wf32[q] = 0x80008000u;
+    while (!overflow) {
+      if (hi - lo + 3 > CAP) { overflow = true; break; }          // (the sweep also reads the slot above hi: it must not alias lo)
+      W += (uint64_t)(hi - lo + 1);
+      int carry = NUL;
+      int dmin = BIG;
+      bool fin_l = false;
+      int qn = 0;
+      auto finished = [&](int h, int k) {
+        dmin = imin(dmin, left_to_align(h, k, pl, tl, ef, pef, tef));
+        if (ef) { const int v = h - k; fin_l = fin_l || (h >= tl && pl - v <= pef) || (v >= pl && tl - h <= tef); }
+      };
+      auto drain = [&]() {
+        int pass = 0;
+        while (qn > 0) {
+          if (qn <= 4 && pass > 0) {
+            for (int q = 0; q < qn; ++q) {
+              const int k = lo + __builtin_amdgcn_readfirstlane((int)queue[q]);
+              int h = __builtin_amdgcn_readfirstlane((int)wf[k & MASK]);
+              const int v = h - k;
+              h += otg_wave_match(P, T, v, h, imin(pl - v, tl - h), lane);
+              wf[k & MASK] = (int16_t)h;              // the same value from every lane
+              finished(h, k);
+            }
+            qn = 0;
+            break;
+          }
+          int wq = 0;
+          for (int q0 = 0; q0 < qn; q0 += 64) {
+            const bool act = q0 + lane < qn;
+            int k = 0, h = 0, v = 0;
+            bool more = false;
+            if (act) {
+              k = lo + (int)queue[q0 + lane];
+              h = wf[k & MASK];
+              v = h - k;
+              const int m = pk.match32(v, h, imin(pl - v, tl - h));
+              v += m; h += m;
+              more = (m == 32) && v < pl && h < tl;
+              wf[k & MASK] = (int16_t)h;
+              if (!more) finished(h, k);
+            }
+            const unsigned long long mm = __ballot(more);
+            if (more) {
+              const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+              queue[wq + rank] = (uint16_t)(k - lo);
+            }
+            wq += __builtin_popcountll(mm);
+          }
+          qn = wq; ++pass;
+        }
+      };
+      // ---- sweep
+      for (int c = lo; c <= hi; c += 64) {
+        const int k = c + lane;
+        const bool in = k <= hi;
+        int mx;
+        if (s == 0) {
+          mx = k > 0 ? k : 0;
+        } else {
+          const int o = wf[k & MASK], r = wf[(k + 1) & MASK];          // null outside the live range: no range tests
+          int l = dpp_shr1(o);
+          if (lane == 0) l = carry;
+          carry = __builtin_amdgcn_readlane(o, 63);
+          mx = imax(imax(l + 1, o + 1), r);
+        }
+        int h = mx, v = mx - k;
+        const bool valid = in && mx >= 0 && h <= tl && v <= pl;
+        bool more = false;
+        if (valid && v < pl && h < tl) {
+          const int m = pk.match32(v, h, imin(pl - v, tl - h));
+          v += m; h += m;
+          more = (m == 32) && v < pl && h < tl;
+        }
+        if (in) wf[k & MASK] = (int16_t)(valid ? h : NUL);
+        if (valid && !more) finished(h, k);
+        const unsigned long long mm = __ballot(more);
+        if (more) {
+          const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+          queue[qn + rank] = (uint16_t)(k - lo);
+        }
+        qn += __builtin_popcountll(mm);
+        if (qn + 64 > QCAP) drain();
+      }
+      drain();
+      // ---- end test on the fully extended wavefront
+      bool any_done;
+      if (ef) any_done = __ballot(fin_l) != 0ull;
+      else {
+        any_done = false;
+        if (kend >= lo && kend <= hi) { const int x = __builtin_amdgcn_readfirstlane((int)wf[kend & MASK]); any_done = x >= tl; }
+      }
+      if (any_done) { done = true; break; }
+      // ---- the cut; what it drops is nulled (the invariant above)
+      const int olo = lo, ohi = hi;
+      const int mind = wave_min_i32(dmin);
+      wfadaptive_cut(H, steps_wait, mind, pl, tl, ef, pef, tef, lo, hi, lane, [&](int k) { const int x = wf[k & MASK]; return x < 0 ? OTG_NULL_OFF : x; });
+      for (int c = olo; c < lo; c += 64) if (c + lane < lo) wf[(c + lane) & MASK] = (int16_t)NUL;
+      for (int c = hi + 1; c <= ohi; c += 64) if (c + lane <= ohi) wf[(c + lane) & MASK] = (int16_t)NUL;
+      lo = lo - 1 < -pl ? -pl : lo - 1;
+      hi = hi + 1 > tl ? tl : hi + 1;
+      ++s;
+      if (s > pl + tl + 2) break;
+    }
+    // wave-uniform tail: every lane stores the same value to the same address
+    if (done) {
+      scores[ti] = s;
+      if (cells) cells[ti] = W;
+    } else if (overflow && overflow_list) {
+      const uint32_t q = otg_wave_atomic_add(n_overflow, 1u);
+      overflow_list[q] = ti;
+    } else {
+      scores[ti] = -1;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Gap-affine, full op string.  Replaces WFAlignerGapAffine(x, o, e, Alignment, MemoryMed)::alignEnd2End / alignEndsFree +
 // getAlignmentCigar() under the heuristic.  Recurrence, provenance bytes, row table and backtrace as in the exact chain's generic kernel
 // (wfa_affine.hip), scores walked in units of g = gcd(x, o + e, e); every read of a history
@@ -329,7 +540,7 @@ __global__ __launch_bounds__(WPB * 64) void wfa_affine_adaptive_kernel(
     int32_t* __restrict__ scores, const uint64_t* __restrict__ cig_off, uint32_t* __restrict__ cig_len,
     uint8_t* __restrict__ cig_arena, uint64_t* __restrict__ cells,
     uint32_t* __restrict__ ticket, uint32_t* __restrict__ n_overflow, uint32_t* __restrict__ overflow_list,
-    AffWs ws, Heur H)
+    AffWs ws, Heur H, int seqw)
 {
   constexpr bool GLOBAL_WF = CAP == 0;
   constexpr int LCAP = GLOBAL_WF ? 2 : CAP;
@@ -337,6 +548,7 @@ __global__ __launch_bounds__(WPB * 64) void wfa_affine_adaptive_kernel(
   __shared__ __attribute__((aligned(16))) int16_t s_rows[WPB][9][LCAP];      // M 0..4, I 5..6, D 7..8
   __shared__ __attribute__((aligned(16))) uint32_t s_q[WPB][QWORDS];
   __shared__ int s_rng[WPB][6][RMAX];                         // mlo, mhi, ilo, ihi, dlo, dhi per ring row
+  extern __shared__ uint32_t s_dyn[];                         // [WPB][seqw]: the pair packed to 2 bits per base (seqw == 0: byte probes from HBM only)
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
   uint8_t* my = ws.base + (size_t)(blockIdx.x * WPB + wib) * ws.stride;
@@ -352,7 +564,8 @@ __global__ __launch_bounds__(WPB * 64) void wfa_affine_adaptive_kernel(
   auto U = [](int x) { return __builtin_amdgcn_readfirstlane(x); };
   volatile lds_u32* queue = (volatile lds_u32*)&s_q[wib][0];
   const uint32_t n_todo = n_todo_ptr ? *n_todo_ptr : n_todo_imm;
-  const int rm = ws.rm, ri = ws.ri;
+  // the LDS policy only takes the penalties (2,4,1): ring depths 5 and 2 at compile time (a remainder by a run-time divisor is ~40 instructions)
+  const int rm = GLOBAL_WF ? ws.rm : 5, ri = GLOBAL_WF ? ws.ri : 2;
 
   for (;;) {
     const uint32_t tk = otg_wave_atomic_add(ticket, 1u);
@@ -368,9 +581,11 @@ __global__ __launch_bounds__(WPB * 64) void wfa_affine_adaptive_kernel(
     int s_end = -1, k_end = 0;
     uint64_t W = 0;
     bool fail = false;
+    PackedPair pk{(volatile lds_u32*)(s_dyn + (size_t)wib * seqw), 0, false};
+    if (seqw > 0 && pl + tl < 32767) pk.init(P, pl, T, tl, lane, seqw);
 
     auto forward = [&](auto st) {
-      fail = !st.fits(pl, tl, xs, oes, es) || rm > RMAX || ri > RMAX;
+      fail = !st.fits(pl, tl, xs, oes, es) || ws.rm > RMAX || ws.ri > RMAX;
       size_t slab_top = 0;
       int steps_wait = 0;
       for (int s = 0; !fail; ++s) {
@@ -441,7 +656,8 @@ __global__ __launch_bounds__(WPB * 64) void wfa_affine_adaptive_kernel(
                 v = h - kk;
                 const int rem = imin(pl - v, tl - h);
                 int m, full;
-                if (pass == 0) {
+                if (pk.ok) { m = pk.match32(v, h, rem); full = 32; }
+                else if (pass == 0) {
                   const uint64_t xl = otg_load8(P + v) ^ otg_load8(T + h), xh = otg_load8(P + v + 8) ^ otg_load8(T + h + 8);
                   m = xl ? (__builtin_ctzll(xl) >> 3) : (xh ? 8 + (__builtin_ctzll(xh) >> 3) : 16);
                   m = imin(m, rem); full = 16;
@@ -495,11 +711,15 @@ __global__ __launch_bounds__(WPB * 64) void wfa_affine_adaptive_kernel(
           const bool valid = in && mx >= 0 && h <= tl && v <= pl;
           bool more = false;
           if (valid && v < pl && h < tl) {
-            const uint64_t xx = otg_load8(P + v) ^ otg_load8(T + h);
-            int m = xx ? (__builtin_ctzll(xx) >> 3) : 8;
-            m = imin(m, imin(pl - v, tl - h));
+            int m, full;
+            if (pk.ok) { m = pk.match32(v, h, imin(pl - v, tl - h)); full = 32; }
+            else {
+              const uint64_t xx = otg_load8(P + v) ^ otg_load8(T + h);
+              m = xx ? (__builtin_ctzll(xx) >> 3) : 8;
+              m = imin(m, imin(pl - v, tl - h)); full = 8;
+            }
             v += m; h += m;
-            more = (m == 8) && v < pl && h < tl;
+            more = (m == full) && v < pl && h < tl;
           }
           if (in) {
             st.wrM(sm, k, valid ? h : OTG_NULL_OFF);
@@ -567,7 +787,7 @@ int gcd3(int a, int b, int c)
 
 // ---------------------------------------------------------------------------------------------------
 // Launch chains.  Same contracts as otg_launch_edit_todo / otg_launch_affine_todo (which hand over to these when the context's heuristic is
-// wfadaptive).  Counters: SLOT_COUNTERS words 112..127 (free of the exact chains' words).
+// wfadaptive).  Counters: SLOT_COUNTERS words 108..127 (free of the exact chains' words).
 int otg_launch_edit_adaptive_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_task* d_tasks, const uint32_t* d_todo,
                                   const uint32_t* d_n_todo, uint32_t n_tasks, int32_t* d_scores, uint64_t* d_cells,
                                   float* kernel_ms, uint64_t* launches)
@@ -575,36 +795,50 @@ int otg_launch_edit_adaptive_todo(otg_ctx* ctx, const uint8_t* d_arena, const ot
   if (n_tasks == 0) return OTG_OK;
   if (ctx->pool[SLOT_COUNTERS].cap < 128 * sizeof(uint32_t)) ctx->affine_visited = nullptr;      // (it points into this slot; the exact chain sets it up again)
   uint32_t* cnt = (uint32_t*)otg_slot(ctx, SLOT_COUNTERS, 128 * sizeof(uint32_t));
-  uint32_t* lists = (uint32_t*)otg_slot(ctx, SLOT_TODO, 3 * (size_t)n_tasks * sizeof(uint32_t));
+  uint32_t* lists = (uint32_t*)otg_slot(ctx, SLOT_TODO, 4 * (size_t)n_tasks * sizeof(uint32_t));
   if (!cnt || !lists) return OTG_ERR_HIP;
-  uint32_t* c = cnt + 112;                    // c[0..3] tickets of the four tiers, c[4..6] lengths of the overflow lists
-  HIP_TRY(ctx, hipMemsetAsync(c, 0, 8 * sizeof(uint32_t), ctx->stream));
+  uint32_t* c = cnt + 108;                    // c[0..3] tickets of the first four tiers, c[4..7] lengths of their overflow lists, c[8..9] the last tier's
+  HIP_TRY(ctx, hipMemsetAsync(c, 0, 10 * sizeof(uint32_t), ctx->stream));
   const Heur H{ctx->heur_min_wf_len, ctx->heur_max_dist, ctx->heur_steps < 1 ? 1 : ctx->heur_steps};
   const uint32_t ncu = (uint32_t)ctx->n_cu;
-  static const int only = getenv("OTG_ADAPTIVE_EDIT_TIERS") ? atoi(getenv("OTG_ADAPTIVE_EDIT_TIERS")) : 15;      // test switch: bit t = tier t runs (the last one always does)
+  static const int only = getenv("OTG_ADAPTIVE_EDIT_TIERS") ? atoi(getenv("OTG_ADAPTIVE_EDIT_TIERS")) : 15;      // bit t = tier t runs (packed 1024, packed 4096, bytes 2048, bytes 16384); the HBM tier always does      // test switch: bit t = tier t runs (the last one always does)
   if (kernel_ms) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   const uint32_t* in = d_todo; const uint32_t* in_n = d_n_todo; uint32_t in_imm = n_tasks;
   uint32_t* l0 = lists; uint32_t* l1 = lists + n_tasks; uint32_t* l2 = lists + 2 * (size_t)n_tasks;
-  if (only & 1) {       // window of 256 diagonals: 2.5 KB of LDS per wave, 8 waves per SIMD by registers
+  uint32_t* l3 = lists + 3 * (size_t)n_tasks;
+  // words of LDS per wave for the packed pair: two reads of the batch's longest length (at most 32 KB: 2 x 32766 bases is what 16-bit offsets hold anyway)
+  const int seqw = (int)std::min<size_t>(2 * (((size_t)ctx->max_seq_len + 15) / 16 + 3) + 2, 8192);
+  if (only & 1) {       // fast tier: window of 1024 diagonals (3 KB of LDS per wave) + the packed pair
     constexpr int WPB = 4;
-    const uint32_t grid = std::min<uint32_t>(ncu * 8, (n_tasks + WPB - 1) / WPB);
-    hipLaunchKernelGGL((wfa_edit_adaptive_kernel<256, 512, WPB>), dim3(grid), dim3(WPB * 64), 0, ctx->stream, d_arena, d_tasks, in, in_n, in_imm,
-                       d_scores, d_cells, c + 0, c + 4, l0, H, (int32_t*)nullptr, 0);
+    const size_t dyn = (size_t)WPB * seqw * 4;
+    const uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(8, (uint32_t)((160 * 1024) / (WPB * 3072 + dyn))));
+    const uint32_t grid = std::min<uint32_t>(ncu * per_cu, (n_tasks + WPB - 1) / WPB);
+    hipLaunchKernelGGL((wfa_edit_adaptive_lds_kernel<1024, 512, WPB>), dim3(grid), dim3(WPB * 64), dyn, ctx->stream, d_arena, d_tasks, in, in_n, in_imm,
+                       d_scores, d_cells, c + 0, c + 4, l0, H, seqw);
     in = l0; in_n = c + 4; in_imm = 0;
   }
-  if (only & 2) {       // 2048 diagonals: 12 KB per wave
+  if (only & 2) {       // fast tier, 4096 diagonals: 10 KB per wave + the packed pair
+    constexpr int WPB = 2;
+    const size_t dyn = (size_t)WPB * seqw * 4;
+    const uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(8, (uint32_t)((160 * 1024) / (WPB * 10240 + dyn))));
+    const uint32_t grid = std::min<uint32_t>(ncu * per_cu, (n_tasks + WPB - 1) / WPB);
+    hipLaunchKernelGGL((wfa_edit_adaptive_lds_kernel<4096, 1024, WPB>), dim3(grid), dim3(WPB * 64), dyn, ctx->stream, d_arena, d_tasks, in, in_n, in_imm,
+                       d_scores, d_cells, c + 1, c + 5, l1, H, seqw);
+    in = l1; in_n = c + 5; in_imm = 0;
+  }
+  if (only & 4) {       // byte probes (pairs with bytes outside ACGT, pairs too long to pack), 2048 diagonals
     constexpr int WPB = 2;
     const uint32_t grid = std::min<uint32_t>(ncu * 6, (n_tasks + WPB - 1) / WPB);
     hipLaunchKernelGGL((wfa_edit_adaptive_kernel<2048, 2048, WPB>), dim3(grid), dim3(WPB * 64), 0, ctx->stream, d_arena, d_tasks, in, in_n, in_imm,
-                       d_scores, d_cells, c + 1, c + 5, l1, H, (int32_t*)nullptr, 0);
-    in = l1; in_n = c + 5; in_imm = 0;
+                       d_scores, d_cells, c + 2, c + 6, l2, H, (int32_t*)nullptr, 0);
+    in = l2; in_n = c + 6; in_imm = 0;
   }
-  if (only & 4) {       // 16384 diagonals: 40 KB per wave
+  if (only & 8) {       // 16384 diagonals: 40 KB per wave
     constexpr int WPB = 1;
     const uint32_t grid = std::min<uint32_t>(ncu * 3, n_tasks);
     hipLaunchKernelGGL((wfa_edit_adaptive_kernel<16384, 2048, WPB>), dim3(grid), dim3(WPB * 64), 0, ctx->stream, d_arena, d_tasks, in, in_n, in_imm,
-                       d_scores, d_cells, c + 2, c + 6, l2, H, (int32_t*)nullptr, 0);
-    in = l2; in_n = c + 6; in_imm = 0;
+                       d_scores, d_cells, c + 3, c + 7, l3, H, (int32_t*)nullptr, 0);
+    in = l3; in_n = c + 7; in_imm = 0;
   }
   {                     // int32 wavefront in HBM, sized for the longest pair of the batch
     constexpr int WPB = 4;
@@ -613,16 +847,16 @@ int otg_launch_edit_adaptive_todo(otg_ctx* ctx, const uint8_t* d_arena, const ot
     int32_t* ws = (int32_t*)otg_slot(ctx, SLOT_WF_WS, (size_t)grid * WPB * (size_t)gcap * sizeof(int32_t));
     if (!ws) return OTG_ERR_HIP;
     hipLaunchKernelGGL((wfa_edit_adaptive_kernel<0, 2048, WPB>), dim3(grid), dim3(WPB * 64), 0, ctx->stream, d_arena, d_tasks, in, in_n, in_imm,
-                       d_scores, d_cells, c + 3, c + 7, (uint32_t*)nullptr, H, ws, gcap);
+                       d_scores, d_cells, c + 8, c + 9, (uint32_t*)nullptr, H, ws, gcap);
   }
   if (kernel_ms) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   HIP_TRY(ctx, hipGetLastError());
   if (getenv("OTG_DEBUG")) {
     hipError_t er = hipStreamSynchronize(ctx->stream);
-    uint32_t h[8];
+    uint32_t h[10];
     (void)hipMemcpy(h, c, sizeof(h), hipMemcpyDeviceToHost);
-    fprintf(stderr, "[otg] edit, wfadaptive(%d,%d,%d): %s; the 256-diagonal window passes on %u pairs, the 2048 one %u, the 16384 one %u\n",
-            H.min_wf_len, H.max_dist, H.steps, hipGetErrorString(er), h[4], h[5], h[6]);
+    fprintf(stderr, "[otg] edit, wfadaptive(%d,%d,%d): %s; the packed 1024-diagonal tier passes on %u pairs, the packed 4096 one %u, the byte-probe 2048 one %u, the 16384 one %u\n",
+            H.min_wf_len, H.max_dist, H.steps, hipGetErrorString(er), h[4], h[5], h[6], h[7]);
   }
   if (kernel_ms) {
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
@@ -673,11 +907,15 @@ int otg_launch_affine_adaptive_todo(otg_ctx* ctx, const uint8_t* d_arena, const 
     return w;
   };
   constexpr int WPB0 = 4, WPB1 = 1, WPB2 = 4;
+  const int seqw = (int)std::min<size_t>(2 * (((size_t)ctx->max_seq_len + 15) / 16 + 3) + 2, 8192);      // LDS words per wave for the packed pair
   // provenance: a row per score, as wide as the wavefront.  Mean width under the cut ~100 diagonals, scores ~0.4 per base
   // (gcd units): 40 x maxlen bytes hold the typical alignment of the first tier four times over; the second tier gets 16 x that.
   AffWs w0 = lds_ws(std::max<size_t>((size_t)160 * maxlen, (size_t)1 << 19));
   AffWs w1 = lds_ws(std::max<size_t>((size_t)2560 * maxlen, (size_t)1 << 23));
-  uint32_t grid0 = std::min<uint32_t>(ncu * 4, (n_tasks + WPB0 - 1) / WPB0), grid1 = std::min<uint32_t>(ncu * 2, n_tasks), grid2 = 2;
+  // blocks per CU by LDS: rows 9 x CAP x 2 B + queue + range tables + the packed pair
+  const uint32_t pc0 = std::max<uint32_t>(1, std::min<uint32_t>(6, (uint32_t)((160 * 1024) / (WPB0 * (9 * 256 * 2 + 2048 + 256 + (size_t)seqw * 4)))));
+  const uint32_t pc1 = std::max<uint32_t>(1, std::min<uint32_t>(8, (uint32_t)((160 * 1024) / (WPB1 * (9 * 1024 * 2 + 4096 + 256 + (size_t)seqw * 4)))));
+  uint32_t grid0 = std::min<uint32_t>(ncu * pc0, (n_tasks + WPB0 - 1) / WPB0), grid1 = std::min<uint32_t>(ncu * pc1, n_tasks), grid2 = 8;
   AffWs w2 = ws;
   {
     const size_t ring_bytes = (size_t)(ws.rm + 2 * ws.ri) * ws.capa * sizeof(int32_t);
@@ -705,24 +943,24 @@ int otg_launch_affine_adaptive_todo(otg_ctx* ctx, const uint8_t* d_arena, const 
   const uint32_t* in = d_todo; const uint32_t* in_n = d_n_todo; uint32_t in_imm = n_tasks;
   uint32_t* l0 = lists; uint32_t* l1 = lists + n_tasks;
   if (only & 1) {
-    hipLaunchKernelGGL((wfa_affine_adaptive_kernel<256, 512, WPB0, 8>), dim3(grid0), dim3(WPB0 * 64), 0, ctx->stream, d_arena, d_tasks, in, in_n, in_imm,
-                       xs, oes, es, g, d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, c + 0, c + 3, l0, w0, H);
+    hipLaunchKernelGGL((wfa_affine_adaptive_kernel<256, 512, WPB0, 8>), dim3(grid0), dim3(WPB0 * 64), (size_t)WPB0 * seqw * 4, ctx->stream, d_arena, d_tasks, in, in_n, in_imm,
+                       xs, oes, es, g, d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, c + 0, c + 3, l0, w0, H, seqw);
     in = l0; in_n = c + 3; in_imm = 0;
   }
   if (only & 2) {
-    hipLaunchKernelGGL((wfa_affine_adaptive_kernel<2048, 2048, WPB1, 8>), dim3(grid1), dim3(WPB1 * 64), 0, ctx->stream, d_arena, d_tasks, in, in_n, in_imm,
-                       xs, oes, es, g, d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, c + 1, c + 4, l1, w1, H);
+    hipLaunchKernelGGL((wfa_affine_adaptive_kernel<1024, 1024, WPB1, 8>), dim3(grid1), dim3(WPB1 * 64), (size_t)WPB1 * seqw * 4, ctx->stream, d_arena, d_tasks, in, in_n, in_imm,
+                       xs, oes, es, g, d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, c + 1, c + 4, l1, w1, H, seqw);
     in = l1; in_n = c + 4; in_imm = 0;
   }
   hipLaunchKernelGGL((wfa_affine_adaptive_kernel<0, 2048, WPB2, 64>), dim3(grid2), dim3(WPB2 * 64), 0, ctx->stream, d_arena, d_tasks, in, in_n, in_imm,
-                     xs, oes, es, g, d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, c + 2, c + 5, (uint32_t*)nullptr, w2, H);
+                     xs, oes, es, g, d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, c + 2, c + 5, (uint32_t*)nullptr, w2, H, 0);
   if (kernel_ms) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   HIP_TRY(ctx, hipGetLastError());
   if (getenv("OTG_DEBUG")) {
     hipError_t er = hipStreamSynchronize(ctx->stream);
     uint32_t h[8];
     (void)hipMemcpy(h, c, sizeof(h), hipMemcpyDeviceToHost);
-    fprintf(stderr, "[otg] affine, wfadaptive(%d,%d,%d): %s; the 256-diagonal window passes on %u alignments, the 2048 one %u; %u / %u alignments in flight, %.2f / %.2f MB each\n",
+    fprintf(stderr, "[otg] affine, wfadaptive(%d,%d,%d): %s; the 256-diagonal window passes on %u alignments, the 1024 one %u; %u / %u alignments in flight, %.2f / %.2f MB each\n",
             H.min_wf_len, H.max_dist, H.steps, hipGetErrorString(er), h[3], h[4], grid0 * WPB0, grid1 * WPB1, (double)w0.stride / 1e6, (double)w1.stride / 1e6);
   }
   if (kernel_ms) {

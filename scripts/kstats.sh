@@ -1,10 +1,11 @@
 #!/bin/bash
-# usage: scripts/kstats.sh <tag> <config> [regions]
+# usage: scripts/kstats.sh <tag> <config> [regions] [extra bench.py arguments, e.g. "--heuristic wfadaptive --no-legs"]
 # rocprofv3 kernel stats of the bench command; prints the top kernels (per-launch average in ms) and keeps the csv + bench line
-tag=$1; cfg=${2:-1}; regions=${3:-}
+tag=$1; cfg=${2:-1}; regions=${3:-}; extra=${4:-}
 cd /tmp && export TMPDIR=/tmp
 ARGS="--config $cfg --steps 2 --warmup 1 --no-cpu-baseline --e2e-regions 0"
 if [ -n "$regions" ]; then ARGS="$ARGS --regions $regions"; fi
+ARGS="$ARGS $extra"
 timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$tag -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS > $GRAFT_REPO_ROOT/gpurun_out/prof_$tag.log 2>&1
 cd $GRAFT_REPO_ROOT
 python3 - <<PY

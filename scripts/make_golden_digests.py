@@ -8,6 +8,7 @@ spending oracle time there.  Fixtures are data only: sizes, flags, hashes.
     python scripts/make_golden_digests.py 1 1250          # configs[1], first 1250 regions (5 chunks)
     python scripts/make_golden_digests.py 2 1000
     python scripts/make_golden_digests.py 4 1000
+    python scripts/make_golden_digests.py 1 1250 --heuristic      # the same under wfadaptive(10, 50, 1) -> digest_c1_adaptive.npz
 """
 import os
 import sys
@@ -25,11 +26,14 @@ from otter_amd import abi, synth  # noqa: E402
 
 
 def main():
-    cfg, n = int(sys.argv[1]), int(sys.argv[2])
-    threads = int(sys.argv[3]) if len(sys.argv) > 3 else (os.cpu_count() or 1)
+    adaptive = "--heuristic" in sys.argv
+    argv = [a for a in sys.argv if a != "--heuristic"]
+    cfg, n = int(argv[1]), int(argv[2])
+    threads = int(argv[3]) if len(argv) > 3 else (os.cpu_count() or 1)
     assert n % synth.CHUNK == 0, "whole chunks only: a chunk is the unit the generator seeds"
     b = synth.config_batch(cfg, n, workers=min(8, threads))
-    P = abi.default_params(realign=1 if synth.CONFIGS[cfg].get("realign") else 0)
+    P = abi.default_params(realign=1 if synth.CONFIGS[cfg].get("realign") else 0,
+                           heuristic=abi.OTG_HEURISTIC_WFADAPTIVE if adaptive else abi.OTG_HEURISTIC_NONE)      # (10, 50, 1): WFA2-lib's own values
     O.lib()
     step = 4
     jobs = [(a, min(a + step, n)) for a in range(0, n, step)]
@@ -54,7 +58,7 @@ def main():
     out = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
     out.update(cfg=np.array([cfg]), n_regions=np.array([n]), seed=np.array([synth.SEED]), first_chunk=np.array([0]),
                input_sha=digests._sha16(b["arena"].tobytes() + b["reads"].tobytes() + b["regions"].tobytes()))
-    path = os.path.join(ROOT, "tests", "golden", "digest_c%d.npz" % cfg)
+    path = os.path.join(ROOT, "tests", "golden", "digest_c%d%s.npz" % (cfg, "_adaptive" if adaptive else ""))
     np.savez_compressed(path, **out)
     print("%s: %d regions, %d allele records, oracle time %.0f s on %d threads" % (path, n, len(out["alleles"]), time.time() - t0, threads))
 

@@ -32,7 +32,9 @@ def test_adapter_builds_and_fails_loudly_without_a_device(tmp_path):
 
 
 @pytest.mark.gpu
-def test_adapter_equals_the_oracle(oracle, tmp_path):
+@pytest.mark.parametrize("mode", [(), ("none",), ("wfadaptive", "10", "50", "1"), ("wfadaptive", "4", "20", "2")], ids=["default", "none", "wfadaptive", "wfadaptive-4-20-2"])
+def test_adapter_equals_the_oracle(oracle, tmp_path, mode):
+    """setHeuristicNone / setHeuristicWFadaptive on the adapter against the oracle in the same mode (the default of the adapter is exact)"""
     exe = build(str(tmp_path))
     rng = np.random.default_rng(61)
     pairs, forms = [(b"", b""), (b"A", b""), (b"", b"ACGT"), (b"ACTGGA", b"ACCGA")], [None] * 4
@@ -46,13 +48,18 @@ def test_adapter_equals_the_oracle(oracle, tmp_path):
             f = [(0, d, 0, 0), (d, 0, 0, 0), (d // 2, d // 2, 0, 0)][(i // 3) % 3] if d >= 0 else [(0, 0, 0, -d), (0, 0, -d, 0)][(i // 3) % 2]
         pairs.append((a, b)); forms.append(f)
     text = b"".join(b"%s %s %d %d %d %d %d\n" % ((a or b"-"), (b or b"-"), *((1,) + tuple(f) if f else (0, 0, 0, 0, 0))) for (a, b), f in zip(pairs, forms))
-    r = subprocess.run([exe], input=text, capture_output=True, timeout=600)
+    r = subprocess.run([exe] + list(mode), input=text, capture_output=True, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-500:]
     lines = r.stdout.decode().split("\n")[:-1]
     assert len(lines) == len(pairs)
     arena, tasks = pair_tasks(pairs, forms)
-    ed = oracle.edit_distance_batch(arena, tasks)
-    sc, cg = oracle.affine_align_batch(arena, tasks)
+    if mode and mode[0] == "wfadaptive":
+        oracle.set_heuristic(1, *[int(x) for x in mode[1:]])
+    try:
+        ed = oracle.edit_distance_batch(arena, tasks)
+        sc, cg = oracle.affine_align_batch(arena, tasks)
+    finally:
+        oracle.set_heuristic(0)
     for i, ln in enumerate(lines):
         st1, e1, st2, s2, c = ln.split(" ")
         assert (int(st1), int(st2)) == (0, 0)
