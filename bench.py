@@ -229,11 +229,29 @@ def pmc_for(cfg, n_regions):
     return None
 
 
+VALU_PEAK = os.path.join(ROOT, "profiles", "r04_valu_peak.json")     # scripts/probes/valu_peak.hip on the MI355X
+
+
+def valu_ceiling():
+    """What the chip's vector ALUs sustain, from the committed micro-benchmark: wave64 instructions per second of the 4-cycle class at 8 waves per
+    SIMD (packed 16-bit, three-operand, DPP, compares, min / max ...; the plain 32-bit VOP2 class issues 1.85 x as fast and is counted at its own
+    cost, see scripts/pmc_summarize.py).  The unit of `achieved` / `peak` is therefore 4-cycle-class instruction slots per second."""
+    try:
+        d = json.load(open(VALU_PEAK))
+        r = [c["wave_insts_per_s"] for c in d["classes"] if c["class"] in ("v_pk_add_u16", "v_pk_max_i16", "v_alignbit_b32", "v_max_i32", "v_cmp_gt_i32 (vcc)") and c["waves_per_simd"] == 8]
+        clk = [c["shader_clock_mhz"] for c in d["classes"] if c["waves_per_simd"] == 8]
+        return {"slots_per_s": sum(r) / len(r), "clock_mhz": sum(clk) / len(clk), "source": "profiles/r04_valu_peak.json (scripts/probes/valu_peak.hip)"}
+    except Exception:
+        return None
+
+
 def roofline(kstats, cfg, n_regions, adaptive=False):
-    """The dominant kernel chain by HIP-event time (events on the library's own stream).  `frac` = SURVEY §8(d)'s algorithmic bytes / time against
-    the HBM peak, as the contract defines it — a work-equivalent rate: the kernels keep wavefronts in registers and visit a fraction of the
-    counted cells.  Beside it what the implementation must move at least (`impl_min_bytes`: sequences + one provenance byte per VISITED cell
-    + op strings + records), what it does move (`traffic`, PMC) and the resource that binds (`binding`: VALU issue, PMC)."""
+    """The dominant kernel chain by HIP-event time (events on the library's own stream).  These kernels are integer wavefront sweeps whose state lives
+    in registers / LDS: what binds them is vector-instruction issue, not HBM.  So the headline object is `bound: "valu"`: `achieved` = the SIMD issue
+    slots the chain's vector instructions held per second (PMC instruction counts of exactly this workload, each instruction class at its measured issue
+    cost — profiles/pmc_summary.json — divided by the chain's duration measured live here), `peak` = what the micro-benchmark sustains.  SURVEY 8(d)'s
+    figure — algorithmic bytes of the REFERENCE's un-pruned wavefronts / time against 8 TB/s, a work-equivalent rate that can exceed 1 — and the
+    physical HBM traffic stay beside it under `hbm`."""
     import numpy as np
     st = kstats[-1]
     ek = float(np.mean([s["ms_edit_kernel"] for s in kstats])); el = max(1, int(st["edit_kernel_launches"]))
@@ -241,30 +259,42 @@ def roofline(kstats, cfg, n_regions, adaptive=False):
     e_bytes = int(st["edit_seq_bytes"]) + 4 * int(st["edit_cells"])
     a_bytes = int(st["affine_seq_bytes"]) + 4 * int(st["affine_cells"]) + (int(st["affine_cells"]) + 1) // 2
     kname, kbytes, kms, kl = ("wfa_edit_kernel", e_bytes, ek, el) if ek >= ak else ("wfa_affine_kernel", a_bytes, ak, al)
-    achieved = (kbytes / kl) / (kms / kl * 1e-3) / 1e9 if kms > 0 else 0.0
+    hbm_rate = (kbytes / kl) / (kms / kl * 1e-3) / 1e9 if kms > 0 else 0.0
     visited = int(st["affine_visited_cells"])
-    out = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-           "traffic": None, "algorithmic_bytes_per_launch": kbytes // kl, "avg_launch_ms": round(kms / kl, 3),
-           "chain_ms": {"edit": round(ek, 2), "affine": round(ak, 2)},
-           "note": "frac = SURVEY 8(d) bytes of the reference's un-pruned wavefronts / time: work-equivalent, not bytes moved"}
-    if kname == "wfa_affine_kernel":
+    hbm = {"algorithmic_bytes_per_launch": kbytes // kl, "achieved": round(hbm_rate, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac_work_equivalent": round(hbm_rate / HBM_PEAK_GBS, 4),
+           "note": "SURVEY 8(d): bytes of the reference's un-pruned, HBM-resident wavefronts / time — work-equivalent, not bytes moved (the kernels keep wavefronts in registers / LDS and "
+                   + ("evaluate only the cells the adaptive cut leaves)" if adaptive else "visit a fraction of the counted cells)")}
+    out = {"bound": "valu", "kernel": kname, "achieved": None, "peak": None, "unit": "G issue slots/s (wave64 instructions at the 4-cycle class's cost)", "frac": None,
+           "traffic": None, "avg_launch_ms": round(kms / kl, 3), "chain_ms": {"edit": round(ek, 2), "affine": round(ak, 2)}, "hbm": hbm}
+    if kname == "wfa_affine_kernel" and not adaptive:
         impl_min = int(st["affine_seq_bytes"]) + visited + int(st["affine_seq_bytes"]) // 2 + int(st["allele_bytes"])
-        out["impl_min_bytes"] = impl_min // kl
+        hbm["impl_min_bytes"] = impl_min // kl
         out["affine_visited_cells"] = visited
         out["affine_visited_cells_per_s"] = round(visited / (ak * 1e-3), 1) if ak > 0 else None
-    if adaptive:
-        out["note"] = "frac = SURVEY 8(d) bytes of the wavefront cells the adaptive aligner evaluates (counted by the kernels, equal to the oracle's count) / time"
+    ceil = valu_ceiling()
+    if ceil:
+        out["peak"] = round(ceil["slots_per_s"] / 1e9, 2)
+        out["peak_source"] = ceil["source"]
     pm = None if adaptive else pmc_for(cfg, n_regions)
     if pm:
-        out["traffic"] = pm.get("traffic_bytes_per_launch", {}).get(kname)
         ph = pm.get("physical", {}).get(kname, {})
-        out["binding"] = {"resource": "valu", "valu_busy": ph.get("valu_busy"), "wait_any_frac": ph.get("wait_any_frac"),
-                          "valu_insts_per_visited_cell": ph.get("valu_insts_per_visited_cell"), "lds_bank_conflict_rate": ph.get("lds_bank_conflict_rate"),
-                          "source": pm.get("source")}
-        if out.get("impl_min_bytes") and out["traffic"]:
-            out["traffic_over_impl_min"] = round(float(out["traffic"]) / out["impl_min_bytes"], 2)
+        out["traffic"] = pm.get("traffic_bytes_per_launch", {}).get(kname)
+        cyc = ph.get("valu_simd_cycles")                 # SIMD cycles the chain's vector instructions held, all launches of the profiled process
+        nl = max(1, int(ph.get("launches", 1)))
+        if cyc and ceil and kms > 0:
+            slots = cyc / 4.15 / nl                      # per chain launch, in 4-cycle-class slots
+            out["achieved"] = round(slots / (kms / kl * 1e-3) / 1e9, 2)
+            out["frac"] = round(out["achieved"] / out["peak"], 4)
+            out["valu_slots_per_launch"] = round(slots, 1)
+        out["binding"] = {"resource": "valu issue", "valu_busy_in_the_profiled_run": ph.get("valu_busy"), "valu_fast_class_share": ph.get("valu_fast_share"), "salu_busy": ph.get("salu_busy"),
+                          "wait_any_frac": ph.get("wait_any_frac"), "valu_insts_per_visited_cell": ph.get("valu_insts_per_visited_cell"),
+                          "lds_bank_conflict_rate": ph.get("lds_bank_conflict_rate"), "source": pm.get("source")}
+        if hbm.get("impl_min_bytes") and out["traffic"]:
+            hbm["traffic_over_impl_min"] = round(float(out["traffic"]) / hbm["impl_min_bytes"], 2)
         if out["traffic"] and kms > 0:       # the physical HBM fraction: bytes the counters saw / chain time / peak
-            out["traffic_frac_of_hbm_peak"] = round(float(out["traffic"]) / (kms / kl * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            hbm["traffic_frac_of_hbm_peak"] = round(float(out["traffic"]) / (kms / kl * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    else:
+        out["note"] = "no PMC instruction counts for exactly this workload in profiles/pmc_summary.json (scripts/pmc_bench.sh): achieved / frac not computed"
     return out
 
 

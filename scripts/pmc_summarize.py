@@ -4,8 +4,15 @@
 Per kernel and for the two kernel chains bench.py reports on (edit = router + capped wavefront pass + bit-parallel tiers; affine = bound pass +
 exact tiers), per LAUNCH of the chain (edit: 2 per step = distance matrix + reassignment; affine: 1 per step without -r, 2 with):
   traffic  = 2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes; the x2 is gfx950's FETCH_SIZE correction, MI355X_MICROARCH.md §HBM)
-  valu_busy = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x kernel cycles), kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs
-              (SQ_ACTIVE_INST_* count quad-cycles; one wave64 VALU instruction holds its SIMD for one quad-cycle)
+  valu_busy = SIMD cycles the vector instructions held / (1024 SIMDs x kernel cycles), kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs.  A wave64 vector
+              instruction does not always hold its SIMD for 4 cycles on gfx950: the plain 32-bit VOP1 / VOP2 integer operations take 2.24, everything
+              else 4.15 (v_swap_b32 twice that) — measured by scripts/probes/valu_peak.hip (profiles/r04_valu_peak.json).  The counters tell the two
+              classes apart: SQ_ACTIVE_INST_VALU counts one per instruction pass whatever its class, SQ_ACTIVE_INST_VALU2 reads 0.464 per fast
+              instruction and 0 for the others (the same probe under rocprofv3: scripts/probes/valu_peak_pmc2.sh, profiles/r04_valu_peak_pmc.txt).
+              So: fast = VALU2 / 0.464; cycles = 2.24 x fast + 4.15 x (ACTIVE_INST_VALU - fast).  (Round 3 multiplied every instruction by 4 and
+              read 1.07-1.33 for kernels rich in fast instructions.)
+  salu_busy = SQ_INSTS_SALU x 1.09 cycles / (256 CUs x kernel cycles): the scalar unit is one per CU and issues ~0.92 instructions per cycle
+              (the probe's s_add_u32 loop) — the second ceiling of these integer kernels
   salu_per_valu, lds_bank_conflict_rate = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE (north_star's figure), wait fractions of wave-cycles.
 usage: python3 scripts/pmc_summarize.py <config> [regions] [tag]"""
 import collections
@@ -22,7 +29,7 @@ from otter_amd import synth  # noqa: E402
 
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 regions = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2] else (synth.CONFIGS[cfg]["n_regions"] // 8 if cfg == 4 else synth.CONFIGS[cfg]["n_regions"])
-tag = sys.argv[3] if len(sys.argv) > 3 else "r03"
+tag = sys.argv[3] if len(sys.argv) > 3 else "r04"
 src = os.path.join(ROOT, "gpurun_out", "pmc_bench_c%d" % cfg)
 
 
@@ -59,12 +66,24 @@ def group_of(k):
     return None
 
 
+C_FAST, C_SLOW, VALU2_PER_FAST, SALU_CYC = 2.24, 4.15, 0.464, 1.09      # profiles/r04_valu_peak.json, profiles/r04_valu_peak_pmc.txt
+
+
 def derive(c, n_launch):
     out = {"launches": n_launch}
     cyc = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
     if cyc > 0:
         out["kernel_cycles"] = cyc
-        out["valu_busy"] = round(4.0 * c.get("SQ_ACTIVE_INST_VALU", 0.0) / (1024.0 * cyc), 4)
+        act = c.get("SQ_ACTIVE_INST_VALU", 0.0)
+        if "SQ_ACTIVE_INST_VALU2" in c:
+            fast = min(act, c["SQ_ACTIVE_INST_VALU2"] / VALU2_PER_FAST)
+            out["valu_fast_share"] = round(fast / act, 4) if act else 0.0
+            out["valu_simd_cycles"] = C_FAST * fast + C_SLOW * (act - fast)
+            out["valu_busy"] = round(out["valu_simd_cycles"] / (1024.0 * cyc), 4)
+        else:                     # no class split measured: every instruction at the slow class's cost = an upper bound of the busy share
+            out["valu_busy_upper_bound"] = round(C_SLOW * act / (1024.0 * cyc), 4)
+        if c.get("SQ_INSTS_SALU"):
+            out["salu_busy"] = round(SALU_CYC * c["SQ_INSTS_SALU"] / (256.0 * cyc), 4)
         out["salu_busy_per_cu"] = round(4.0 * c.get("SQ_ACTIVE_INST_SCA", 0.0) / (256.0 * cyc) / 4.0, 4)
         out["lds_busy"] = round(c.get("SQ_LDS_IDX_ACTIVE", 0.0) / (256.0 * cyc), 4)
     if c.get("SQ_INSTS_VALU"):
@@ -117,7 +136,7 @@ for g, c in groups.items():
         d["valu_insts_per_visited_cell"] = round(d["valu_insts"] / (float(visited) * chain_launches[g]), 4)
     d["bound"] = "valu"
     d["frac"] = d.get("valu_busy")
-    d["what"] = "share of the chip's VALU issue slots (1024 SIMDs x kernel cycles) the chain's kernels used, summed over its kernels"
+    d["what"] = "share of the chip's SIMD cycles (1024 SIMDs x kernel cycles) the chain's vector instructions held, each class at its measured issue cost"
     physical[g] = d
     if "traffic_bytes" in d:
         traffic[g] = d["traffic_bytes"] / chain_launches[g]
@@ -131,9 +150,11 @@ json.dump(allc, open(path, "w"), indent=1, sort_keys=True)
 dst = os.path.join(ROOT, "profiles", "%s_pmc_c%d" % (tag, cfg))
 os.makedirs(dst, exist_ok=True)
 json.dump({k: dict(v) for k, v in agg.items()}, open(os.path.join(dst, "counters_by_kernel.json"), "w"), indent=1, sort_keys=True)
-print("%-48s %5s %9s %7s %7s %7s %8s %9s" % ("kernel", "n", "valu_busy", "salu/v", "lds_bc", "wait", "waves/S", "traffic"))
+lines = ["%-48s %5s %9s %9s %8s %7s %7s %7s %8s %9s" % ("kernel", "n", "valu_busy", "salu_busy", "fast_shr", "salu/v", "lds_bc", "wait", "waves/S", "traffic")]
 for k, d in sorted(kernels.items(), key=lambda kv: -kv[1].get("kernel_cycles", 0)):
-    print("%-48s %5d %9s %7s %7s %7s %8s %9.3g" % (k[:48], d["launches"], d.get("valu_busy"), d.get("salu_per_valu"), d.get("lds_bank_conflict_rate"),
-                                              d.get("wait_any_frac"), d.get("waves_per_simd"), d.get("traffic_bytes", 0.0)))
+    lines.append("%-48s %5d %9s %9s %8s %7s %7s %7s %8s %9.3g" % (k[:48], d["launches"], d.get("valu_busy", d.get("valu_busy_upper_bound")), d.get("salu_busy"), d.get("valu_fast_share"),
+                                                             d.get("salu_per_valu"), d.get("lds_bank_conflict_rate"), d.get("wait_any_frac"), d.get("waves_per_simd"), d.get("traffic_bytes", 0.0)))
+print("\n".join(lines))
+open(os.path.join(dst, "table.txt"), "w").write("\n".join(lines) + "\n")
 for g, d in physical.items():
     print(g, json.dumps({k: v for k, v in d.items() if k != "what"}))

@@ -20,15 +20,18 @@
 #define REP64(I) REP8(I) REP8(I) REP8(I) REP8(I) REP8(I) REP8(I) REP8(I) REP8(I)
 
 enum Cls { ADD_U32, PK_ADD_U16, PK_MAX_I16, PK_SUB_U16_CLAMP, CNDMASK, ALIGNBIT, DPP_ROW_SHR, DPP_WAVE_SHR, BITOP, CMP, LSHL_B64, ADD_CO_PAIR, SWAP, MIX_SALU, BFE, FFBL,
-           AND_B32, XOR_B32, MAX_I32, MIN_U32, SUB_U32, LSHL_B32, LSHR_B32, MOV_B32, ADD3, MAX3, CNDMASK_SGPR, CMP_CNDMASK, CMP_SGPR, MAD_U24, PERM, BFI, ADD_E64, ADD_DPP, READLANE, SALU_ONLY, MAX_I32_DPP, MIN3, MED3, OR3, LSHL_ADD, N_CLS };
+           AND_B32, XOR_B32, MAX_I32, MIN_U32, SUB_U32, LSHL_B32, LSHR_B32, MOV_B32, ADD3, MAX3, CNDMASK_SGPR, CMP_CNDMASK, CMP_SGPR, MAD_U24, PERM, BFI, ADD_E64, ADD_DPP, READLANE, SALU_ONLY, MAX_I32_DPP, MIN3, MED3, OR3, LSHL_ADD,
+           OR_B32, LSHL_ADD_U64, MOV_B64, WRITELANE, ASHR_I32, ADD_SDWA, MIN_I32, READFIRSTLANE, MBCNT, NOT_B32, SUBREV, BFREV, MUL_LO, BITOP3, LSHL_OR, LSHR_B64, CMP_EQ_E32, MAX_U32, N_CLS };
 static const char* NAME[N_CLS] = {"v_add_u32", "v_pk_add_u16", "v_pk_max_i16", "v_pk_sub_u16 clamp", "v_cndmask_b32", "v_alignbit_b32", "v_mov_b32 dpp row_shr:1",
                                   "v_mov_b32 dpp wave_shr:1", "v_and_or_b32", "v_cmp_gt_i32 (vcc)", "v_lshlrev_b64", "v_add_co_u32 + v_addc_co_u32", "v_swap_b32",
                                   "v_add_u32 + s_add_u32 interleaved (counts the vector half)", "v_bfe_u32", "v_ffbl_b32",
                                   "v_and_b32", "v_xor_b32", "v_max_i32", "v_min_u32", "v_sub_u32", "v_lshlrev_b32", "v_lshrrev_b32", "v_mov_b32", "v_add3_u32", "v_max3_i32",
                                   "v_cndmask_b32 (mask in an SGPR pair)", "v_cmp_gt_i32 vcc + v_cndmask_b32 vcc (pairs)", "v_cmp_gt_i32 into an SGPR pair", "v_mad_u32_u24", "v_perm_b32",
                                   "v_bfi_b32", "v_add_u32_e64", "v_add_u32 dpp row_shr:1", "v_readlane_b32 (scalar result)", "s_add_u32 alone (scalar instructions per second)",
-                                  "v_max_i32 dpp row_shr:1", "v_min3_i32", "v_med3_i32", "v_or3_b32", "v_lshl_add_u32"};
-static const int PER_SLOT[N_CLS] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 1, 1, 1, 1,  1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};      // vector instructions per slot of the block
+                                  "v_max_i32 dpp row_shr:1", "v_min3_i32", "v_med3_i32", "v_or3_b32", "v_lshl_add_u32",
+                                  "v_or_b32", "v_lshl_add_u64", "v_mov_b64", "v_writelane_b32", "v_ashrrev_i32", "v_add_u32_sdwa", "v_min_i32", "v_readfirstlane_b32", "v_mbcnt_lo + v_mbcnt_hi", "v_not_b32",
+                                  "v_subrev_u32", "v_bfrev_b32", "v_mul_lo_u32", "v_bitop3_b32", "v_lshl_or_b32", "v_lshrrev_b64", "v_cmp_eq_u32 (vcc)", "v_max_u32"};
+static const int PER_SLOT[N_CLS] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 1, 1, 1, 1,  1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,  1, 1, 1, 1, 1, 1, 1, 1, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1};      // vector instructions per slot of the block
 
 template <int C>
 __global__ __launch_bounds__(256) void probe(int iters, unsigned* out, unsigned long long* clk)
@@ -131,9 +134,29 @@ __global__ __launch_bounds__(256) void probe(int iters, unsigned* out, unsigned 
 #define I_MED3(n) asm volatile("v_med3_i32 %0, %0, %1, %2" : "+v"(a##n) : "v"(b), "v"(c));
 #define I_OR3(n) asm volatile("v_or3_b32 %0, %0, %1, %2" : "+v"(a##n) : "v"(b), "v"(c));
 #define I_LSHL_ADD(n) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(a##n) : "v"(b));
+#define I_OR_B32(n) asm volatile("v_or_b32 %0, %0, %1" : "+v"(a##n) : "v"(b));
+#define I_LSHL_ADD_U64(n) asm volatile("v_lshl_add_u64 %0, %0, 1, %1" : "+v"(w0) : "v"(w1));
+#define I_MOV_B64(n) asm volatile("v_mov_b64 %0, %1" : "+v"(w0) : "v"(w1));
+#define I_WRITELANE(n) asm volatile("v_writelane_b32 %0, %1, 3" : "+v"(a##n) : "s"(s0));
+#define I_ASHR_I32(n) asm volatile("v_ashrrev_i32 %0, 1, %0" : "+v"(a##n));
+#define I_ADD_SDWA(n) asm volatile("v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "+v"(a##n) : "v"(b));
+#define I_MIN_I32(n) asm volatile("v_min_i32 %0, %0, %1" : "+v"(a##n) : "v"(b));
+#define I_READFIRSTLANE(n) asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(s0) : "v"(a##n));
+#define I_MBCNT(n) asm volatile("v_mbcnt_lo_u32_b32 %0, %1, 0\n\tv_mbcnt_hi_u32_b32 %0, %1, %0" : "+v"(a##n) : "v"(b));
+#define I_NOT_B32(n) asm volatile("v_not_b32 %0, %0" : "+v"(a##n));
+#define I_SUBREV(n) asm volatile("v_subrev_u32 %0, %0, %1" : "+v"(a##n) : "v"(b));
+#define I_BFREV(n) asm volatile("v_bfrev_b32 %0, %0" : "+v"(a##n));
+#define I_MUL_LO(n) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a##n) : "v"(b));
+#define I_BITOP3(n) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(a##n) : "v"(b), "v"(c));
+#define I_LSHL_OR(n) asm volatile("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(a##n) : "v"(b));
+#define I_LSHR_B64(n) asm volatile("v_lshrrev_b64 %0, 1, %0" : "+v"(w0));
+#define I_CMP_EQ_E32(n) asm volatile("v_cmp_eq_u32 vcc, %0, %1" : : "v"(a##n), "v"(b) : "vcc");
+#define I_MAX_U32(n) asm volatile("v_max_u32 %0, %0, %1" : "+v"(a##n) : "v"(b));
     SIMPLE(AND_B32, 0) SIMPLE(XOR_B32, 0) SIMPLE(MAX_I32, 0) SIMPLE(MIN_U32, 0) SIMPLE(SUB_U32, 0) SIMPLE(LSHL_B32, 0) SIMPLE(LSHR_B32, 0) SIMPLE(MOV_B32, 0)
     SIMPLE(ADD3, 0) SIMPLE(MAX3, 0) SIMPLE(CNDMASK_SGPR, 0) SIMPLE(CMP_CNDMASK, 0) SIMPLE(CMP_SGPR, 0) SIMPLE(MAD_U24, 0) SIMPLE(PERM, 0) SIMPLE(BFI, 0)
     SIMPLE(ADD_E64, 0) SIMPLE(ADD_DPP, 0) SIMPLE(READLANE, 0) SIMPLE(SALU_ONLY, 0) SIMPLE(MAX_I32_DPP, 0) SIMPLE(MIN3, 0) SIMPLE(MED3, 0) SIMPLE(OR3, 0) SIMPLE(LSHL_ADD, 0)
+    SIMPLE(OR_B32, 0) SIMPLE(LSHL_ADD_U64, 0) SIMPLE(MOV_B64, 0) SIMPLE(WRITELANE, 0) SIMPLE(ASHR_I32, 0) SIMPLE(ADD_SDWA, 0) SIMPLE(MIN_I32, 0) SIMPLE(READFIRSTLANE, 0) SIMPLE(MBCNT, 0)
+    SIMPLE(NOT_B32, 0) SIMPLE(SUBREV, 0) SIMPLE(BFREV, 0) SIMPLE(MUL_LO, 0) SIMPLE(BITOP3, 0) SIMPLE(LSHL_OR, 0) SIMPLE(LSHR_B64, 0) SIMPLE(CMP_EQ_E32, 0) SIMPLE(MAX_U32, 0)
   }
   const unsigned long long t1 = __builtin_readcyclecounter(), r1 = wall_clock64();
   out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7 ^ c ^ s0 ^ (unsigned)w0 ^ (unsigned)w1 ^ (unsigned)w2 ^ (unsigned)w3 ^ (unsigned)msk;
