@@ -55,6 +55,7 @@ def parse_args():
                     help="aligner mode of the TIMED workload: none = exact (the contract), wfadaptive = WFA2-lib's adaptive reduction (10, 50, 1)")
     ap.add_argument("--leg-steps", type=int, default=3)
     ap.add_argument("--e2e-regions", type=int, default=10000, help="regions of the file-to-text leg (BED + BAM -> SAM text through otg_assemble_files); 0: skip")
+    ap.add_argument("--vcf-regions", type=int, default=5000, help="regions of the file-to-VCF leg (50-sample allele BAM + BED + FASTA -> VCF through otg_genotype_files; configs[3]'s size); 0: skip")
     return ap.parse_args()
 
 
@@ -159,6 +160,46 @@ def cpu_baseline(batch, params, seconds, n_threads, runs=3, with_reference_conse
 FIXTURE_CODE = ("import sys, json, time; sys.path.insert(0, %r); from otter_amd import bamwrite; t0 = time.time(); "
                 "fx = bamwrite.make_tr_fixture(sys.argv[1], int(sys.argv[2]), depth=30, len_range=(1000, 5000), seed=7); "
                 "json.dump({'bam': fx['bam'], 'bed': fx['bed'], 'build_s': time.time() - t0}, open(sys.argv[1] + '/fixture.json', 'w'))")
+
+
+GT_FIXTURE_CODE = ("import sys, json, time; sys.path.insert(0, %r); from otter_amd import bamwrite; t0 = time.time(); "
+                   "fx = bamwrite.make_genotype_fixture(sys.argv[1], int(sys.argv[2]), n_samples=50, len_range=(1000, 5000), seed=11); "
+                   "json.dump({'bam': fx['bam'], 'bed': fx['bed'], 'fasta': fx['fasta'], 'records': fx['n_records'], 'build_s': time.time() - t0}, open(sys.argv[1] + '/fixture.json', 'w'))")
+
+
+def start_gt_fixture(n_regions):
+    """the 50-sample allele BAM of the file-to-VCF leg, written by a child process started before this process touches the GPU"""
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="otg_vcf_")
+    p = subprocess.Popen([sys.executable, "-c", GT_FIXTURE_CODE % ROOT, tmp, str(n_regions)], stdin=subprocess.DEVNULL)
+    return tmp, p
+
+
+def vcf_leg(tmp, proc, n_regions, threads):
+    """BASELINE configs[3] from files: `otter genotype -b regions.bed -r ref.fa alleles.bam` as ONE library call (otg_genotype_files: allele ingest on
+    host threads -> anallele_cluster on the GPU -> VCF text; src/genotype.cpp:69-171), on a generated 50-sample x n_regions allele BAM.  The
+    reference's own judgement of this configuration is that it is BAM-I/O-bound (SURVEY finding 9): the stage times say where the wall goes."""
+    import shutil
+    import otter_amd
+    try:
+        if proc.wait(timeout=1200) != 0:
+            raise RuntimeError("fixture writer failed")
+        fx = json.load(open(os.path.join(tmp, "fixture.json")))
+        best = None
+        for _ in range(2):
+            t1 = time.perf_counter()
+            text, st = otter_amd.genotype_files(fx["bam"], fx["bed"], fasta=fx["fasta"], threads=threads)
+            dt = time.perf_counter() - t1
+            if best is None or dt < best[0]:
+                best = (dt, st, len(text), text.count(b"\n"))
+        dt, st, nbytes, nlines = best
+        return {"workload": "BASELINE configs[3] from files: %d regions x 50 samples x 2 alleles of 1-5 kb (+ the reference allele), one merged allele BAM" % n_regions,
+                "regions_per_s": round(n_regions / dt, 1), "regions": n_regions, "allele_records": int(fx["records"]), "alleles_clustered": int(st["n_alleles"]),
+                "vcf_bytes": nbytes, "vcf_lines": nlines, "bam_bytes": os.path.getsize(fx["bam"]), "host_threads": threads, "wall_ms": round(dt * 1000.0, 1),
+                "stage_busy_ms": {"ingest": round(st["ms_ingest"], 1), "cluster": round(st["ms_hot_path"], 1), "emit": round(st["ms_emit"], 1)},
+                "what": "allele BAM/BAI + BED + FASTA -> otg_genotype_files -> VCF text, best of 2", "fixture_build_s": round(fx["build_s"], 1)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def start_fixture(n_regions):
@@ -331,8 +372,14 @@ def run_rank(args):
         legs_in[2] = synth.config_batch(2, workers=workers)
         legs_in[4] = synth.config_batch(4, synth.CONFIGS[4]["n_regions"] // 8, workers=workers)
         legs_in[3] = synth.config_batch(3, workers=workers)
+    # N > 1: north_star's own shape rides along — configs[4], the 100 000-region job of 1-10 kb loci, 12 500 regions per GPU (rank r's contiguous shard)
+    want_leg4_multi = world > 1 and not args.no_legs and args.config is None and args.regions is None
+    if want_leg4_multi:
+        n4 = synth.CONFIGS[4]["n_regions"] // 8
+        legs_in[4] = synth.config_batch(4, n4, first_chunk=rank * (n4 // synth.CHUNK), workers=workers)
     gen_s = time.perf_counter() - t_gen
     fixture = start_fixture(args.e2e_regions) if (args.e2e_regions > 0 and world == 1) else None
+    gt_fixture = start_gt_fixture(args.vcf_regions) if (args.vcf_regions > 0 and want_legs) else None
 
     import torch
     dist = None
@@ -455,6 +502,19 @@ def run_rank(args):
         world_seen = dist.get_world_size()
     else:
         total_regions = float(regions_ok)
+    leg4_multi = None
+    if want_leg4_multi:
+        lr = assemble_run(4, legs_in[4], args.leg_steps, 1, 0)
+        ls = lr["kstats"][-1]
+        t4 = torch.tensor([lr["dt"], float(int(ls["n_regions_ok"]))], dtype=torch.float64, device="cuda")
+        t4max = t4.clone(); dist.all_reduce(t4max, op=dist.ReduceOp.MAX)
+        t4sum = t4.clone(); dist.all_reduce(t4sum, op=dist.ReduceOp.SUM)
+        dt4 = float(t4max[0])
+        leg4_multi = {"workload": synth.config_workload(4, len(legs_in[4]["regions"]), world), "value": round(float(t4sum[1]) * args.leg_steps / dt4, 2), "unit": "regions/s",
+                      "n_gpus": world, "ms_per_step": round(dt4 * 1000.0 / args.leg_steps, 2), "steps": args.leg_steps, "scaling": "weak",
+                      "timed_region": "otg_assemble_run + RCCL gather to rank 0 + one D2H; barrier on both sides, max over ranks", "stage_ms_rank0": stage_ms(ls),
+                      "allele_records": lr["info"].get("records"), "gather_bytes": lr["info"].get("gather_bytes")}
+        legs_in[4] = None
     if rank != 0:
         if dist is not None:
             dist.barrier()
@@ -481,6 +541,8 @@ def run_rank(args):
                                     "what": "SURVEY 8(d): otg_assemble_submit (H2D) + run + collect (D2H), mean of %d passes" % min(3, max(1, args.steps))}},
         "roofline": roofline(r["kstats"], cfg, n_regions),
     }
+    if leg4_multi is not None:
+        out["config"]["legs"] = {"configs[4]": leg4_multi}
     if world > 1:
         out["config"]["gather"] = {"path": "device buffers -> RCCL gather -> one D2H on rank 0", "bytes": info.get("gather_bytes"), "ms_last_step": round(info.get("gather_ms", 0.0), 2)}
     else:
@@ -537,6 +599,12 @@ def run_rank(args):
             out["config"]["e2e"] = e2e_leg(fixture[0], fixture[1], args.e2e_regions, max(1, min(16, os.cpu_count() or 1)))
         except Exception as e:
             out["config"]["e2e"] = {"error": repr(e)}
+    if gt_fixture is not None:
+        try:
+            ctx.close()
+            out["config"]["legs"]["configs[3]_files_to_vcf"] = vcf_leg(gt_fixture[0], gt_fixture[1], args.vcf_regions, max(1, min(16, os.cpu_count() or 1)))
+        except Exception as e:
+            out["config"]["legs"]["configs[3]_files_to_vcf"] = {"error": repr(e)}
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

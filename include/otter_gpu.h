@@ -43,6 +43,9 @@ extern "C" {
 #define OTG_REGION_NO_SPANNING   2   /* "[WARNING] No spanning reads"                                         */
 #define OTG_REGION_EMPTY         3   /* no reads at all                                                       */
 #define OTG_REGION_HAP_CONFLICT  4   /* "ERROR: conflicting haplotag information" (reference exit(1)s)       */
+#define OTG_REGION_ALIGN_CAPACITY 5  /* a gap-affine alignment of this region outgrew the device workspaces: no records for THIS region, the rest of
+                                        the batch is unaffected (the reference has no length cap, src/assemble.cpp:51-154; here the last-resort tier
+                                        holds one provenance byte per wavefront cell and its slab is a share of the device's memory)             */
 
 typedef struct otg_ctx otg_ctx;
 

@@ -14,6 +14,7 @@ OTG_REGION_SKIP_MAXCOV = 1
 OTG_REGION_NO_SPANNING = 2
 OTG_REGION_EMPTY = 3
 OTG_REGION_HAP_CONFLICT = 4
+OTG_REGION_ALIGN_CAPACITY = 5
 
 
 class otg_params(C.Structure):

@@ -77,11 +77,11 @@ def _parse_cigar(cigar):
     return ops
 
 
-def write_bam(path, targets, records, level=1):
+def write_bam(path, targets, records, level=1, extra_header=""):
     """targets: [(name, length)]; records: iterable of (tid, pos0, name, flag, mapq, cigar (str, [(len, opchar)] or (lengths, BAM op codes) as arrays), seq (bytes or uint8 array), tags bytes)
     sorted by (tid, pos0).  Writes `path` and `path + '.bai'`.  Returns the number of records."""
     bg = _Bgzf(path, level)
-    text = "@HD\tVN:1.4\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % (n, l) for n, l in targets)
+    text = "@HD\tVN:1.4\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % (n, l) for n, l in targets) + extra_header
     hdr = b"BAM\x01" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(targets))
     for n, l in targets:
         nb = n.encode() + b"\x00"
@@ -229,3 +229,50 @@ def make_tr_fixture(dirname, n_regions, depth=30, len_range=(1000, 5000), seed=7
         for i in range(0, len(rb), 60):
             f.write(rb[i:i + 60] + "\n")
     return {"bam": bam, "bed": bed, "fasta": fa, "regions": regions, "n_records": len(recs)}
+
+
+def make_genotype_fixture(dirname, n_regions, n_samples=50, len_range=(1000, 5000), seed=11, flank=300):
+    """The input of `otter genotype` at BASELINE configs[3]'s shape: ONE merged allele BAM as `otter assemble` writes it per sample (a read group per
+    sample, `@PG ID:otter OF:l,r`, records = allele sequences with the tags RG / ta / tc / ac / sc / ic / se; src/anseqs.cpp:42-63) holding
+    2 x n_samples allele records per tandem-repeat locus (otter_amd.synth.make_genotype_batch: population alleles + consensus-level errors), a BED
+    file and a reference FASTA whose sequence under each region is the locus's reference allele.  Writes alleles.bam (+ .bai), regions.bed, ref.fa."""
+    import os
+    import struct as st
+    from . import synth
+    gb = synth.make_genotype_batch(n_regions, n_samples=n_samples, len_range=len_range, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+    arena, off, ln, first, smp = gb["arena"], gb["seq_off"], gb["seq_len"], gb["first_allele"], gb["sample"]
+    ref_parts, regions, recs = [], [], []
+    pos = 0
+    names = ["smp%02d" % i for i in range(n_samples)]
+    for r in range(n_regions):
+        a0, a1 = int(first[r]), int(first[r + 1])
+        refal = arena[int(off[a1 - 1]):int(off[a1 - 1]) + int(ln[a1 - 1])]        # the last allele of a region is the reference allele
+        start = pos + flank
+        end = start + int(refal.size)
+        ref_parts += [ACGT[rng.integers(0, 4, flank)], refal, ACGT[rng.integers(0, 4, flank)]]
+        regions.append(("chrG", start, end))
+        ta = ("chrG:%d-%d" % (start, end)).encode()
+        seen = {}
+        for a in range(a0, a1 - 1):
+            sm = int(smp[a]); k = seen.get(sm, 0); seen[sm] = k + 1
+            seq = arena[int(off[a]):int(off[a]) + int(ln[a])]
+            cov = int(rng.integers(8, 20))
+            tags = (b"RGZ" + names[sm].encode() + b"\0" + b"taZ" + ta + b"\0" + b"tcC" + bytes([cov * 2]) + b"acC" + bytes([cov]) + b"scC" + bytes([max(1, cov - 2)]) +
+                    b"icC" + bytes([2]) + b"sef" + st.pack("<f", float(rng.integers(0, 50)) / 1000.0))
+            recs.append((0, start - 1, "chrG:%d-%d_%d" % (start, end, k), 0, 0, [(int(seq.size), "M")], seq, tags))
+        pos = end + flank
+    ref = np.concatenate(ref_parts)
+    bam, bed, fa = os.path.join(dirname, "alleles.bam"), os.path.join(dirname, "regions.bed"), os.path.join(dirname, "ref.fa")
+    extra = "".join("@RG\tID:%s\n" % n for n in names) + "@PG\tID:otter\tOF:1,0\n"
+    write_bam(bam, [("chrG", int(ref.size))], recs, extra_header=extra)             # generated in coordinate order already
+    with open(bed, "w") as f:
+        for c, s_, e in regions:
+            f.write("%s\t%d\t%d\n" % (c, s_, e))
+    with open(fa, "w") as f:
+        f.write(">chrG\n")
+        rb = ref.tobytes().decode()
+        for i in range(0, len(rb), 60):
+            f.write(rb[i:i + 60] + "\n")
+    return {"bam": bam, "bed": bed, "fasta": fa, "regions": regions, "n_records": len(recs), "n_samples": n_samples}

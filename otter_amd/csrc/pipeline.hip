@@ -293,6 +293,18 @@ __global__ void K_stats(const uint32_t* __restrict__ todo, const uint32_t* __res
   if (threadIdx.x == 0) { atomicAdd(&acc[0], sc[0]); atomicAdd(&acc[1], sb[0]); if (blockIdx.x == 0) atomicAdd(&acc[2], (unsigned long long)n); }
 }
 
+// A gap-affine alignment the device could not hold (score < 0: the last-resort tier ran out of provenance storage) takes its REGION out of
+// the results — status OTG_REGION_ALIGN_CAPACITY, no records — and nothing else: task slot = read index, so the region follows from the read.
+__global__ void K_mark_failed_affine(const uint32_t* __restrict__ todo, const uint32_t* __restrict__ n_todo, const int32_t* __restrict__ scores,
+                                     const uint32_t* __restrict__ read_region, int32_t* __restrict__ status)
+{
+  const uint32_t n = *n_todo;
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+    const uint32_t slot = todo[t];
+    if (scores[slot] < 0) { const uint32_t r = read_region[slot]; if (r != 0xffffffffu) status[r] = OTG_REGION_ALIGN_CAPACITY; }
+  }
+}
+
 __global__ void K_scatter_labels(const uint32_t* __restrict__ read_region, const otg_region* __restrict__ regions,
                                  const int32_t* __restrict__ vpos, const int32_t* __restrict__ cl_labels, uint32_t n_reads,
                                  int32_t* __restrict__ labels)
@@ -806,7 +818,7 @@ static int assemble_run_body(otg_ctx* ctx, bool realign_only)
       rc = otg_launch_affine_todo(ctx, d_arena, d_tasks, d_todo, d_cnt + 16, NR, P.mismatch, P.gap_open, P.gap_ext, d_scores, d_cig_off, d_cig_len, d_cig, d_cells, &kms, &kl);
       if (rc) return rc;
       pl->stats.ms_affine_kernel += kms; pl->stats.affine_kernel_launches += kl; }
-    hipLaunchKernelGGL(K_stats, dim3(64), dim3(256), 0, st, d_todo, d_cnt + 16, d_tasks, d_cells, d_stats + 4, d_scores, d_cnt + 41);
+    hipLaunchKernelGGL(K_stats, dim3(64), dim3(256), 0, st, d_todo, d_cnt + 16, d_tasks, d_cells, d_stats + 4, d_scores, d_cnt + 42);
     hipLaunchKernelGGL(K_realign_apply, dim3(gr_reads), dim3(TB), 0, st, d_reads, NR, (const uint8_t*)B(B_RKIND), d_cig, d_cig_off, d_cig_len, P.flank, P.min_sim);
     pl->stats.ms_realign = t.ms();
   }
@@ -815,7 +827,7 @@ static int assemble_run_body(otg_ctx* ctx, bool realign_only)
     HIP_TRY(ctx, hipStreamSynchronize(st));
     pl->stats.ms_total = total.ms();
     uint32_t hf = 0;
-    HIP_TRY(ctx, hipMemcpy(&hf, d_cnt + 41, sizeof(hf), hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(&hf, d_cnt + 42, sizeof(hf), hipMemcpyDeviceToHost));
     if (hf) return otg_fail(ctx, OTG_ERR_CAPACITY, "a gap-affine alignment exhausted its backtrace storage on the device");
     return OTG_OK;             // pl->ran stays false: there are no allele results to collect
   }
@@ -883,6 +895,7 @@ static int assemble_run_body(otg_ctx* ctx, bool realign_only)
       if (rc) return rc;
       pl->stats.ms_affine_kernel += kms; pl->stats.affine_kernel_launches += kl; }
     hipLaunchKernelGGL(K_stats, dim3(64), dim3(256), 0, st, d_todo, d_cnt + 28, d_tasks, d_cells, d_stats + 4, d_scores, d_cnt + 41);
+    hipLaunchKernelGGL(K_mark_failed_affine, dim3(64), dim3(256), 0, st, d_todo, d_cnt + 28, d_scores, d_rr, d_status);      // such a region drops out; the batch goes on
     hipLaunchKernelGGL(K_member_cigars, dim3(gr_reads), dim3(TB), 0, st, (otg_poa_member*)B(B_MEMBERS), (const otg_poa_graph*)B(B_GRAPHS), NR, d_cig_len);
     pl->stats.ms_affine = t.ms();
     dbg(ctx, "affine done");
@@ -925,10 +938,11 @@ static int assemble_run_body(otg_ctx* ctx, bool realign_only)
   HIP_TRY(ctx, hipGetLastError());
   pl->stats.ms_total = total.ms();
   {
-    uint32_t hf[2];
+    uint32_t hf[3];
     HIP_TRY(ctx, hipMemcpy(hf, d_cnt + 40, sizeof(hf), hipMemcpyDeviceToHost));
     if (hf[0]) return otg_fail(ctx, OTG_ERR_FATAL, "an edit-distance alignment did not complete on the device");
-    if (hf[1]) return otg_fail(ctx, OTG_ERR_CAPACITY, "a gap-affine alignment exhausted its backtrace storage on the device");
+    // hf[1]: a consensus alignment outgrew the last-resort tier's workspace: its region carries OTG_REGION_ALIGN_CAPACITY, everything else is delivered
+    if (hf[2]) return otg_fail(ctx, OTG_ERR_CAPACITY, "a flank re-alignment exhausted its backtrace storage on the device");
   }
   // statistics
   unsigned long long hs[8];

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(WPB * 64) void wfa_affine_kernel(
   constexpr int QCAP = 2048;
   __shared__ int s_lo[WPB][3][64];
   __shared__ int s_hi[WPB][3][64];
-  __shared__ uint16_t s_queue[WPB][QCAP];
+  __shared__ uint32_t s_queue[WPB][QCAP];        // 32-bit entries: wavefronts wider than 65 535 diagonals (pairs beyond 32 kb) end up here
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
   uint8_t* my = ws.base + (size_t)(blockIdx.x * WPB + wib) * ws.stride;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(WPB * 64) void wfa_affine_kernel(
   int* mlo = s_lo[wib][0]; int* mhi = s_hi[wib][0];
   int* ilo = s_lo[wib][1]; int* ihi = s_hi[wib][1];
   int* dlo = s_lo[wib][2]; int* dhi = s_hi[wib][2];
-  volatile lds_u16* queue = (volatile lds_u16*)&s_queue[wib][0];
+  volatile lds_u32* queue = (volatile lds_u32*)&s_queue[wib][0];
   const uint32_t n_todo = n_todo_ptr ? *n_todo_ptr : n_todo_imm;
 
   for (;;) {
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(WPB * 64) void wfa_affine_kernel(
     const int pef = t.pattern_end_free, tef = t.text_end_free;
     const int kb = pl + 1; // ring index of diagonal k is k + kb
     const int kend = tl - pl;
-    bool fail = (pl + tl + 3 > ws.capa) || (pl + tl + 3 > 65535);   // queue entries are 16-bit diagonal indices
+    bool fail = pl + tl + 3 > ws.capa;
     size_t slab_top = 0;
     uint64_t W = 0;
     int s_end = -1, k_end = 0;
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(WPB * 64) void wfa_affine_kernel(
             const unsigned long long mm = __ballot(more);
             if (more) {
               const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
-              queue[wq + rank] = (uint16_t)(kk - lo);
+              queue[wq + rank] = (uint32_t)(kk - lo);
             }
             wq += __builtin_popcountll(mm);
           }
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(WPB * 64) void wfa_affine_kernel(
         const unsigned long long mq = __ballot(more);
         if (more) {
           const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mq, 0u));
-          queue[qn + rank] = (uint16_t)(k - lo);
+          queue[qn + rank] = (uint32_t)(k - lo);
         }
         qn += __builtin_popcountll(mq);
         if (qn + 64 > QCAP) drain();
@@ -925,6 +925,8 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
     wsB.slab_bytes = slabB & ~(size_t)255; wsB.stride = wsB.off_slab + wsB.slab_bytes;
     // tier C: generic kernel (global int32 rings), a few waves with the largest useful slabs
     size_t slabC = std::min<size_t>((size_t)2 * maxlen * (size_t)(ws.nrows), budget / (gridC * WPB));
+    static const size_t slab_cap_env = getenv("OTG_AFFINE_LAST_SLAB_MB") ? (size_t)atoi(getenv("OTG_AFFINE_LAST_SLAB_MB")) << 20 : 0;      // test switch: a last-resort tier that runs out
+    if (slab_cap_env) slabC = std::min(slabC, slab_cap_env);
     if (slabC > ws.off_slab + 256) slabC -= ws.off_slab + 256;
     wsC.slab_bytes = slabC & ~(size_t)255; wsC.stride = wsC.off_slab + wsC.slab_bytes;
     const size_t need = std::max(std::max(wsA.stride * wavesA, wsB.stride * wavesB), wsC.stride * (size_t)gridC * WPB);
@@ -1021,13 +1023,49 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
         }
         HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, main_stream));
       }
-      for (int t = OTG_REG_TIERS - 1; t >= 0; --t) {      // widest windows first: their alignments are the longest
-        if (!blocks[t]) continue;
-        if (concurrent) { ctx->stream = ctx->tier_stream[t]; HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_fork, 0)); }
+      // Which stream a tier runs on when they run side by side.  HIP gives a process 4 hardware queues; with one stream per tier two pairs of tiers
+      // shared a queue and ran one after the other (r03's timeline of a 1 000-region step: <1,12> started when <2,8> ended, <1,8> when <4,8>
+      // ended), and a tier whose list is EMPTY still lasts as long as the persistent blocks of the others keep its own blocks from being
+      // dispatched (<8,8>: 36 ms on a batch that gave it nothing) and holds up whatever shares its stream.  So on small batches the host reads the
+      // seven segment bounds back (one small copy behind the bound pass and the sort, which it would otherwise only queue behind), launches the
+      // tiers that have work, and deals them to THREE streams — main + two side streams — longest expected run first.
+      int side_of[OTG_REG_TIERS] = {-2, -2, -2, -2, -2};         // -2: not launched, -1: the main stream, 0 / 1: a side stream
+      int order[OTG_REG_TIERS] = {4, 3, 2, 1, 0};
+      if (concurrent) {
+        uint32_t hseg[OTG_REG_TIERS + 2];
+        HIP_TRY(ctx, hipMemcpyAsync(hseg, seg, sizeof(hseg), hipMemcpyDeviceToHost, main_stream));
+        HIP_TRY(ctx, hipStreamSynchronize(main_stream));
+        static const double weight[OTG_REG_TIERS] = {1.0, 2.2, 4.0, 16.0, 64.0};      // per alignment, ~ window^2
+        double cost[OTG_REG_TIERS], load[3] = {0.0, 0.0, 0.0};
+        for (int t = 0; t < OTG_REG_TIERS; ++t) cost[t] = blocks[t] ? weight[t] * (double)(hseg[t + 1] - hseg[t]) : 0.0;
+        std::sort(order, order + OTG_REG_TIERS, [&](int a, int b) { return cost[a] > cost[b]; });
+        for (int q = 0; q < OTG_REG_TIERS; ++q) {
+          const int t = order[q];
+          if (cost[t] <= 0.0) continue;
+          int best = 0;
+          for (int j = 1; j < 3; ++j) if (load[j] < load[best]) best = j;
+          load[best] += cost[t];
+          side_of[t] = best - 1;
+        }
+      } else {
+        for (int t = 0; t < OTG_REG_TIERS; ++t) side_of[t] = blocks[t] ? -1 : -2;
+      }
+      bool side_used[2] = {false, false};
+      for (int q = 0; q < OTG_REG_TIERS; ++q) {
+        const int t = order[q];
+        if (side_of[t] == -2) continue;
+        if (side_of[t] >= 0) {
+          ctx->stream = ctx->tier_stream[side_of[t]];
+          if (!side_used[side_of[t]]) { HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_fork, 0)); side_used[side_of[t]] = true; }
+        }
         const int rc = otg_launch_affine_reg_tier(ctx, t, shape[t], blocks[t], d_arena, d_tasks, sorted, seg + t, g, d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells,
                                                   cnt + 72 + t, n_ovf, ovf_r, wr[t], d_bound, ctx->affine_visited);
-        if (concurrent) { const hipStream_t ts = ctx->stream; ctx->stream = main_stream; if (!rc) { HIP_TRY(ctx, hipEventRecord(ctx->ev_join[t], ts)); HIP_TRY(ctx, hipStreamWaitEvent(main_stream, ctx->ev_join[t], 0)); } }
+        ctx->stream = main_stream;
         if (rc) return rc;
+      }
+      for (int sd = 0; sd < 2; ++sd) if (side_used[sd]) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_join[sd], ctx->tier_stream[sd]));
+        HIP_TRY(ctx, hipStreamWaitEvent(main_stream, ctx->ev_join[sd], 0));
       }
       inA = ovf_r; inA_n = n_ovf; inA_imm = 0;
     }

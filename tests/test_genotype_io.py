@@ -277,3 +277,45 @@ def test_genotype_chain_bam_to_vcf_gpu_vs_oracle(gpu, oracle, tmp_path):
     blk0 = bam.ingest_alleles((beds, carena), reference=None, threads=2)
     table, _ = otter_amd.genotype_files(bam_path, bed_path, fasta=None, threads=2, batch_regions=9)
     assert table == otter_amd.emit_genotype_lengths(bam, beds, carena, blk0, len(samples)) and table.count(b"\n") > 10
+
+
+@needs_ref
+def test_bench_genotype_fixture_reads_alike(tmp_path):
+    """the allele BAM bench.py's file-to-VCF leg runs on (otter_amd.bamwrite.make_genotype_fixture): the reference's own SampleIndex / parse_analleles and
+    the product's ingest return the same samples, offsets and alleles for it"""
+    from otter_amd import bamwrite
+    fx = bamwrite.make_genotype_fixture(str(tmp_path), 12, n_samples=5, len_range=(150, 700))
+    bam = otter_amd.Bam(fx["bam"])
+    samples, ol, orr = bam.sample_index()
+    rs, rol, ror = _ref_sample_index(fx["bam"])
+    assert (samples, ol, orr) == (rs, rol, ror) and len(samples) == 5 and (ol, orr) == (1, 0)
+    beds, carena = abi.make_beds(fx["regions"])
+    for fasta in (None, fx["fasta"]):
+        blk = bam.ingest_alleles((beds, carena), reference=otter_amd.Fasta(fasta) if fasta else None, threads=2)
+        ref_blk = _ref_ingest_alleles(fx["bam"], fasta, fx["regions"])
+        assert np.array_equal(blk["first_allele"], ref_blk["first_allele"])
+        assert np.array_equal(np.diff(blk["first_allele"].astype(np.int64)), np.full(12, 11 if fasta else 10))
+        for f in ("seq_len", "scov", "acov", "tcov", "ic", "ps", "hp", "region", "label"):
+            assert np.array_equal(blk["alleles"][f], ref_blk["alleles"][f]), f
+        assert np.array_equal(blk["alleles"]["se"], ref_blk["alleles"]["se"])
+        n = int(blk["alleles"]["seq_len"].astype(np.int64).sum())
+        assert blk["arena"][:n].tobytes() == ref_blk["arena"][:n].tobytes()
+
+
+@pytest.mark.gpu
+def test_genotype_files_on_the_bench_fixture(gpu, oracle, tmp_path):
+    """otg_genotype_files on the bench fixture's shape (small): the VCF text of the one-call path == product ingest -> ORACLE anallele_cluster -> oracle text"""
+    from otter_amd import bamwrite
+    fx = bamwrite.make_genotype_fixture(str(tmp_path), 30, n_samples=6, len_range=(200, 900))
+    bam = otter_amd.Bam(fx["bam"])
+    samples, ol, orr = bam.sample_index()
+    beds, carena = abi.make_beds(fx["regions"])
+    blk = bam.ingest_alleles((beds, carena), reference=otter_amd.Fasta(fx["fasta"]), threads=2)
+    so, sl, fa_, na_ = otter_amd.genotype_blocks(blk)
+    assert (na_ == 13).all()
+    P = abi.default_params()
+    ogt, ogl, ogk, ohsd, ongt, oreps = oracle.genotype_cluster_batch(P, blk["arena"], so, sl, fa_, na_)
+    exp = oracle.emit_vcf_header(bam.targets(), samples) + oracle.emit_vcf_lines(beds, carena, blk, len(samples), ogt, ohsd, ongt, oreps, ol, orr)
+    text, st = otter_amd.genotype_files(fx["bam"], fx["bed"], fasta=fx["fasta"], threads=3)
+    assert text == exp and st["n_regions"] == 30 and st["n_alleles"] == 30 * 13
+    assert (ongt > 1).sum() > 10                  # the loci are polymorphic: the clustering has something to do
