@@ -609,6 +609,9 @@ void otg_affine_reg_geometry(int tier, int shape, int* aln_per_block, int* block
     case 30: a = 1; b = 4; break;       // <4,8>   16
     case 31: a = 1; b = 3; break;       // <8,4>   24
     case 40: a = 1; b = 2; break;       // <8,8>   16
+    // (r04, measured and not kept: <2,16> for the 4096 window — half the exchange, an even split of ~10 live slots — at 2 waves per SIMD without spills
+    //  or 3 with: affine stage of a 2 500-region slice of the 1-10 kb shard 364 ms with <4,8>, 436 / 392 ms with <2,16>: occupancy weighs more)
+
     default: break;
   }
   *aln_per_block = a; *blocks_per_cu = b;
@@ -636,6 +639,7 @@ int otg_launch_affine_reg_tier(otg_ctx* ctx, int tier, int shape, uint32_t block
     case 22: OTG_REG_LAUNCH(1, 16, 6144, 2); break;
     case 31: OTG_REG_LAUNCH(8, 4, 8192, 6, 256); break;
     case 40: OTG_REG_LAUNCH(8, 8, 12288, 4); break;
+
 #endif
     default: return otg_fail(ctx, OTG_ERR_ARG, "no register tier %d shape %d", tier, shape);
   }

@@ -27,6 +27,15 @@ CASES = [
     ("OTG_POA_NO_LDS", ["tests/test_gpu_poa.py"]),                                       # second-generation POA on every graph (the op-string fuzz and the insertion stretches in global memory)
     ("OTG_POA_PIECE_MB=1", ["tests/test_gpu_poa.py", "tests/test_gpu_pipeline.py::test_ont_kb"]),         # graph images in many small pieces that reuse the work arrays
     ("OTG_NO_REASSIGN_REV", ["tests/test_gpu_pipeline.py::test_haps_mode", "tests/test_gpu_pipeline.py::test_ont_kb"]),
+    ("OTG_REG_SHAPE=11210", AFFINE_CORE),                                                # the other instantiation of every register window: <2,4>, <1,12> at 4 waves, <1,16>, <8,4>
+    ("OTG_REG_SHAPE=2200", AFFINE_CORE),                                                 # <2,6> for the 1536 window, <1,16> without spills for the 2048 one
+    ("OTG_AFFINE_CONCURRENT=1", AFFINE_CORE),                                            # register tiers side by side on three streams whatever the batch size
+    ("OTG_AFFINE_CONCURRENT=0", ["tests/test_gpu_affine.py::test_affine_small_mixed", "tests/test_gpu_pipeline.py::test_ont_kb"]),   # ... and one after the other on a small batch
+    # the adaptive mode's tier chains (wfa_adaptive.hip): byte-probe tiers only; the wide packed tier first; the 1024-diagonal LDS tier / the int32 tier alone for the gap-affine aligner
+    ("OTG_ADAPTIVE_EDIT_TIERS=12", ["tests/test_gpu_adaptive.py::test_adaptive_edit_small", "tests/test_gpu_adaptive.py::test_adaptive_edit_long", "tests/test_gpu_adaptive.py::test_adaptive_edit_wide_and_huge"]),
+    ("OTG_ADAPTIVE_EDIT_TIERS=2", ["tests/test_gpu_adaptive.py::test_adaptive_edit_small", "tests/test_gpu_adaptive.py::test_adaptive_edit_long"]),
+    ("OTG_ADAPTIVE_AFFINE_TIERS=2", ["tests/test_gpu_adaptive.py::test_adaptive_affine_small", "tests/test_gpu_adaptive.py::test_adaptive_affine_long", "tests/test_gpu_adaptive.py::test_adaptive_pipeline"]),
+    ("OTG_ADAPTIVE_AFFINE_TIERS=0", ["tests/test_gpu_adaptive.py::test_adaptive_affine_small", "tests/test_gpu_adaptive.py::test_adaptive_affine_other_penalties_and_wide"]),
 ]
 
 
