@@ -338,6 +338,13 @@ struct PackedPair {
 // The fast edit tier: window of CAP diagonals (signed 16-bit offsets, null = -32768) + the packed pair in LDS.  Invariant that removes every
 // range test from the sweep: a slot of the window is non-null only while its diagonal is inside the live range — the window is null-filled per
 // pair, and the diagonals a cut drops are nulled right there — so the recurrence reads its neighbours unconditionally.
+//
+// The sweep is written BRANCH-FREE (r04, second version): on gfx950 a wave64 vector instruction costs 2.2 or 4.2 SIMD cycles by class and the one
+// scalar unit of a CU serves four SIMDs (profiles/r04_valu_peak.json), and the first version spent as many scalar as vector instructions on
+// execution-mask bookkeeping around its `if`s.  Now every lane of a chunk computes, probes and stores unconditionally — an invalid or out-of-range
+// lane probes wherever its offset points (LDS reads outside the allocation return zero, inside it harmless words) and stores NULL, which is what a
+// slot outside the live range holds anyway — and the only branches left are wave-uniform: "did any lane's run outlive its probe" and the loop.
+// Score 0 runs through the same sweep: the start diagonals are seeded with their offset MINUS ONE, as if by a score -1.
 template <int CAP, int QCAP, int WPB>
 __global__ __launch_bounds__(WPB * 64) void wfa_edit_adaptive_lds_kernel(
     const uint8_t* __restrict__ arena, const otg_align_task* __restrict__ tasks,
@@ -371,15 +378,20 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_adaptive_lds_kernel(
     int lo = ef ? -t.pattern_begin_free : 0, hi = ef ? t.text_begin_free : 0;
     if (lo < -pl) lo = -pl;
     if (hi > tl) hi = tl;
-    bool overflow = pl > 32766 || tl > 32766 || hi - lo + 3 > CAP;
+    // (the last chunk of a sweep stores 64 lanes whatever the range: the slots behind hi must not alias the live range)
+    bool overflow = pl > 32766 || tl > 32766 || hi - lo + 68 > CAP;
     PackedPair pk{(volatile lds_u32*)(s_dyn + (size_t)wib * seqw), 0, false};
     if (!overflow) { pk.init(P, pl, T, tl, lane, seqw); overflow = !pk.ok; }
     int s = 0, steps_wait = 0;
     uint64_t W = 0;
     bool done = false;
-    if (!overflow) for (int q = lane; q < CAP / 2; q += 64) wf32[q] = 0x80008000u;
+    if (!overflow) {
+      for (int q = lane; q < CAP / 2; q += 64) wf32[q] = 0x80008000u;
+      for (int c = lo; c <= hi; c += 64) { const int k = c + lane; if (k <= hi) wf[k & MASK] = (int16_t)((k > 0 ? k : 0) - 1); }      // "score -1"
+    }
+    const int offT4 = pk.offT * 4;
     while (!overflow) {
-      if (hi - lo + 3 > CAP) { overflow = true; break; }          // (the sweep also reads the slot above hi: it must not alias lo)
+      if (hi - lo + 68 > CAP) { overflow = true; break; }
       W += (uint64_t)(hi - lo + 1);
       int carry = NUL;
       int dmin = BIG;
@@ -429,39 +441,57 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_adaptive_lds_kernel(
           qn = wq; ++pass;
         }
       };
-      // ---- sweep
+      // ---- sweep (branch-free per lane)
+      const volatile lds_u32* SQ = pk.SQ;
       for (int c = lo; c <= hi; c += 64) {
         const int k = c + lane;
-        const bool in = k <= hi;
-        int mx;
-        if (s == 0) {
-          mx = k > 0 ? k : 0;
-        } else {
-          const int o = wf[k & MASK], r = wf[(k + 1) & MASK];          // null outside the live range: no range tests
-          int l = dpp_shr1(o);
-          if (lane == 0) l = carry;
-          carry = __builtin_amdgcn_readlane(o, 63);
-          mx = imax(imax(l + 1, o + 1), r);
+        const int o = wf[k & MASK], r = wf[(k + 1) & MASK];            // null outside the live range: no range tests
+        const int l = __builtin_amdgcn_update_dpp(carry, o, 0x138, 0xf, 0xf, false);      // lane i <- lane i-1, lane 0 <- the previous chunk's lane 63
+        carry = __builtin_amdgcn_readlane(o, 63);
+        const int mx = imax(imax(l + 1, o + 1), r);
+        const int v = mx - k;
+        const int t1 = tl - mx, t2 = pl - v;                              // what is left of the text / the pattern
+        const bool valid = (uint32_t)mx <= (uint32_t)tl && (uint32_t)v <= (uint32_t)pl && k <= hi;
+        // the probe, wherever the offsets point
+        int pm;
+        {
+          const int wp = (v >> 2) & ~3, wt = offT4 + ((mx >> 2) & ~3);     // byte addresses of the first word of each 32-base window
+          const uint32_t sp = (uint32_t)(v & 15) * 2u, st = (uint32_t)(mx & 15) * 2u;
+          const volatile lds_u32* pp = (const volatile lds_u32*)((const volatile __attribute__((address_space(3))) char*)SQ + wp);
+          const volatile lds_u32* pt = (const volatile lds_u32*)((const volatile __attribute__((address_space(3))) char*)SQ + wt);
+          const uint32_t p0 = pp[0], p1 = pp[1], p2 = pp[2], q0 = pt[0], q1 = pt[1], q2 = pt[2];
+          const uint32_t xl = __builtin_amdgcn_alignbit(p1, p0, sp) ^ __builtin_amdgcn_alignbit(q1, q0, st);
+          const uint32_t xh = __builtin_amdgcn_alignbit(p2, p1, sp) ^ __builtin_amdgcn_alignbit(q2, q1, st);
+          uint32_t flo, fhi;      // v_ffbl_b32: index of the lowest set bit, 0xffffffff for zero — which is what the min below wants
+          asm("v_ffbl_b32 %0, %1" : "=v"(flo) : "v"(xl));
+          asm("v_ffbl_b32 %0, %1" : "=v"(fhi) : "v"(xh));
+          const uint32_t a = flo < (fhi | 32u) ? flo : (fhi | 32u);
+          pm = (int)((a < 64u ? a : 64u) >> 1);
         }
-        int h = mx, v = mx - k;
-        const bool valid = in && mx >= 0 && h <= tl && v <= pl;
-        bool more = false;
-        if (valid && v < pl && h < tl) {
-          const int m = pk.match32(v, h, imin(pl - v, tl - h));
-          v += m; h += m;
-          more = (m == 32) && v < pl && h < tl;
+        const int m = imin(imin(pm, t1), t2);                            // the run, limited by the sequence ends
+        const bool more = valid && imin(imin(pm, t1 - 1), t2 - 1) == 32;  // a full probe with more than 32 bases left of both sequences
+        const int h2 = mx + m;
+        wf[k & MASK] = (int16_t)(valid ? h2 : NUL);                      // every lane stores (see the head of the kernel)
+        const bool here = valid && !more;
+        const int lh = t1 - m, lv = t2 - m;
+        int d;
+        if (!ef) d = imax(lh, lv);
+        else {
+          d = imin(imax(lh, lv - pef), imax(lv, lh - tef));
+          fin_l = fin_l || (here && ((lh <= 0 && lv <= pef) || (lv <= 0 && lh <= tef)));
         }
-        if (in) wf[k & MASK] = (int16_t)(valid ? h : NUL);
-        if (valid && !more) finished(h, k);
+        dmin = imin(dmin, here ? d : BIG);
         const unsigned long long mm = __ballot(more);
-        if (more) {
-          const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
-          queue[qn + rank] = (uint16_t)(k - lo);
+        if (mm) {
+          if (more) {
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+            queue[qn + rank] = (uint16_t)(k - lo);
+          }
+          qn += __builtin_popcountll(mm);
+          if (qn + 64 > QCAP) drain();
         }
-        qn += __builtin_popcountll(mm);
-        if (qn + 64 > QCAP) drain();
       }
-      drain();
+      if (qn) drain();
       // ---- end test on the fully extended wavefront
       bool any_done;
       if (ef) any_done = __ballot(fin_l) != 0ull;

@@ -68,6 +68,8 @@ __device__ __forceinline__ void opaque_v(int& x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ unsigned long long mk_eq(int a, int b) { return __builtin_amdgcn_sicmp(a, b, 32); }
 __device__ __forceinline__ unsigned long long mk_gt(int a, int b) { return __builtin_amdgcn_sicmp(a, b, 38); }
 __device__ __forceinline__ unsigned long long mk_ule(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 37); }
+// (r04, measured and not kept: the selects on vcc — "s_mov_b64 vcc, mask; v_cndmask_b32_e32", a 2.2-cycle vector instruction + a scalar move instead of the
+//  4.2-cycle e64 form on an SGPR pair: affine stage of a 2 500-region slice of configs[1] 105.2 -> 107.1 ms; the scalar unit is the scarcer resource here)
 __device__ __forceinline__ int sel(unsigned long long m, int a, int b) { int r; asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m)); return r; }     // lane in m ? a : b
 __device__ __forceinline__ int sel0(unsigned long long m, int a) { int r; asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(a), "s"(m)); return r; }                   // lane in m ? a : 0
 __device__ __forceinline__ bool lane_in(unsigned long long m, int lane) { return ((m >> lane) & 1ull) != 0ull; }
