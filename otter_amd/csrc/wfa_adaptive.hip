@@ -86,6 +86,50 @@ __device__ __forceinline__ void wfadaptive_cut(const Heur& H, int& steps_wait, i
   steps_wait = H.steps;
 }
 
+// The same cut with both ends looked at in ONE step (the fast tiers): lanes 0-31 hold the 32 lowest diagonals of the range, lanes 32-63 the 32
+// highest; one offset read, one distance, one ballot.  A scan that would have to look further than 32 diagonals from an end — nothing in range
+// among them and the limit not reached — falls back to the general form above (same result by construction: both implement "first diagonal
+// from the end within the threshold, but not past the limit").
+template <class Off>
+__device__ __forceinline__ void wfadaptive_cut32(const Heur& H, int& steps_wait, int mind, int pl, int tl, bool ef, int pef, int tef,
+                                                 int& lo, int& hi, int lane, Off off)
+{
+  if (steps_wait - 1 > 0 || hi - lo + 1 < H.min_wf_len) { wfadaptive_cut(H, steps_wait, mind, pl, tl, ef, pef, tef, lo, hi, lane, off); return; }
+  const int kend = tl - pl;
+  const int min_k = ef ? kend - tef : kend, max_k = ef ? kend + pef : kend;
+  const int top_limit = imin(min_k - 1, hi);
+  const bool low = lane < 32;
+  const int k = low ? lo + lane : hi - 63 + lane;
+  bool ok = false;
+  if (k >= lo && k <= hi) ok = left_to_align(off(k), k, pl, tl, ef, pef, tef) - mind <= H.max_dist;
+  const unsigned long long b = __ballot(ok);
+  // low end: the first diagonal in [lo, top_limit) within the threshold, else top_limit
+  int nlo = lo;
+  bool fallback = false;
+  if (top_limit > lo) {
+    const int n = top_limit - lo;                                  // candidates lo .. top_limit - 1
+    const uint32_t cand = (uint32_t)b & (n >= 32 ? 0xffffffffu : ((1u << n) - 1u));
+    if (cand) nlo = lo + (int)__builtin_ctz(cand);
+    else if (n <= 32) nlo = top_limit;
+    else fallback = true;
+  }
+  int nhi = hi;
+  if (!fallback) {
+    const int bottom_limit = imax(max_k + 1, nlo);
+    if (hi > bottom_limit) {
+      const int n = hi - bottom_limit;                             // candidates bottom_limit + 1 .. hi = the top n bits
+      const uint32_t hb = (uint32_t)(b >> 32);
+      const uint32_t cand = hb & (n >= 32 ? 0xffffffffu : ~((1u << (32 - n)) - 1u));
+      if (cand) nhi = hi - (int)__builtin_clz(cand);
+      else if (n <= 32) nhi = bottom_limit;
+      else fallback = true;
+    }
+  }
+  if (fallback) { wfadaptive_cut(H, steps_wait, mind, pl, tl, ef, pef, tef, lo, hi, lane, off); return; }
+  lo = nlo; hi = nhi;
+  steps_wait = H.steps;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Edit distance, score only.  Replaces WFAlignerEdit(Score, MemoryMed)::alignEnd2End / alignEndsFree + getAlignmentScore() under the
 // heuristic.  The wavefront is updated IN PLACE (ascending sweep: the left neighbour of lane 0 is carried in a scalar, the right
@@ -400,6 +444,7 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_adaptive_lds_kernel(
       auto finished = [&](int h, int k) {
         dmin = imin(dmin, left_to_align(h, k, pl, tl, ef, pef, tef));
         if (ef) { const int v = h - k; fin_l = fin_l || (h >= tl && pl - v <= pef) || (v >= pl && tl - h <= tef); }
+        else fin_l = fin_l || (k == kend && h >= tl);
       };
       auto drain = [&]() {
         int pass = 0;
@@ -475,7 +520,7 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_adaptive_lds_kernel(
         const bool here = valid && !more;
         const int lh = t1 - m, lv = t2 - m;
         int d;
-        if (!ef) d = imax(lh, lv);
+        if (!ef) { d = imax(lh, lv); fin_l = fin_l || (here && k == kend && lh <= 0); }      // the end diagonal has reached the end of the text
         else {
           d = imin(imax(lh, lv - pef), imax(lv, lh - tef));
           fin_l = fin_l || (here && ((lh <= 0 && lv <= pef) || (lv <= 0 && lh <= tef)));
@@ -493,17 +538,11 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_adaptive_lds_kernel(
       }
       if (qn) drain();
       // ---- end test on the fully extended wavefront
-      bool any_done;
-      if (ef) any_done = __ballot(fin_l) != 0ull;
-      else {
-        any_done = false;
-        if (kend >= lo && kend <= hi) { const int x = __builtin_amdgcn_readfirstlane((int)wf[kend & MASK]); any_done = x >= tl; }
-      }
-      if (any_done) { done = true; break; }
+      if (__ballot(fin_l) != 0ull) { done = true; break; }
       // ---- the cut; what it drops is nulled (the invariant above)
       const int olo = lo, ohi = hi;
       const int mind = wave_min_i32(dmin);
-      wfadaptive_cut(H, steps_wait, mind, pl, tl, ef, pef, tef, lo, hi, lane, [&](int k) { const int x = wf[k & MASK]; return x < 0 ? OTG_NULL_OFF : x; });
+      wfadaptive_cut32(H, steps_wait, mind, pl, tl, ef, pef, tef, lo, hi, lane, [&](int k) { const int x = wf[k & MASK]; return x < 0 ? OTG_NULL_OFF : x; });
       for (int c = olo; c < lo; c += 64) if (c + lane < lo) wf[(c + lane) & MASK] = (int16_t)NUL;
       for (int c = hi + 1; c <= ohi; c += 64) if (c + lane <= ohi) wf[(c + lane) & MASK] = (int16_t)NUL;
       lo = lo - 1 < -pl ? -pl : lo - 1;
@@ -807,6 +846,249 @@ __global__ __launch_bounds__(WPB * 64) void wfa_affine_adaptive_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The fast gap-affine tier (penalties (4,6,2) -> (2,4,1), pairs with pl + tl < 32766 that pack): the same recurrence and provenance as the kernel
+// above, its sweep written BRANCH-FREE like the fast edit tier's.  Eleven rows of CAP signed 16-bit offsets per wave in a modular window: the M
+// ring (5), the I and D rings (2 each), a row that is always null (what a score reads in place of wavefronts that do not exist yet) and a seed
+// row (the start diagonals' offsets minus one, read as "M[s-2]" by score 0, so that score 0 is a sweep like any other).  The null discipline of the
+// edit tier holds PER ROW — a slot is non-null only while its diagonal lies in the range its row currently stands for — so the five operands of a
+// cell are read unconditionally: when a ring row is taken over by a new score, what its previous score left outside the new range is nulled, and
+// so is what a cut drops.  Every lane of a chunk computes, probes and stores (NULL where the lane lies behind the range); a provenance row is
+// padded to whole chunks for the same reason.
+template <int CAP, int QCAP, int WPB>
+__global__ __launch_bounds__(WPB * 64) void wfa_affine_adaptive_lds_kernel(
+    const uint8_t* __restrict__ arena, const otg_align_task* __restrict__ tasks,
+    const uint32_t* __restrict__ todo, const uint32_t* __restrict__ n_todo_ptr, uint32_t n_todo_imm, int g,
+    int32_t* __restrict__ scores, const uint64_t* __restrict__ cig_off, uint32_t* __restrict__ cig_len,
+    uint8_t* __restrict__ cig_arena, uint64_t* __restrict__ cells,
+    uint32_t* __restrict__ ticket, uint32_t* __restrict__ n_overflow, uint32_t* __restrict__ overflow_list,
+    AffWs ws, Heur H, int seqw)
+{
+  constexpr int xs = 2, oes = 4, es = 1, RM = 5, RI = 2;
+  constexpr int ROW_I = RM, ROW_D = RM + RI, ROW_NULL = RM + 2 * RI, ROW_SEED = ROW_NULL + 1, NROWS = ROW_SEED + 1;
+  constexpr int MASK = CAP - 1, NUL = -32768;
+  static_assert(NROWS * CAP * 2 >= 2048, "the backtrace stages its 2 KB window in the rows (free once the forward pass is over)");
+  __shared__ __attribute__((aligned(16))) int16_t s_rows[WPB][NROWS][CAP];
+  __shared__ __attribute__((aligned(16))) uint32_t s_q[WPB][QCAP];
+  extern __shared__ uint32_t s_dyn[];                         // [WPB][seqw]: the packed pairs
+  using lds_char = __attribute__((address_space(3))) char;
+  const int lane = threadIdx.x & 63;
+  const int wib = threadIdx.x >> 6;
+  uint8_t* my = ws.base + (size_t)(blockIdx.x * WPB + wib) * ws.stride;
+  int64_t* rowtab = (int64_t*)(my + ws.off_rowtab);
+  uint8_t* rev = my + ws.off_rev;
+  uint8_t* slab = my + ws.off_slab;
+  volatile lds_char* ROWS = (volatile lds_char*)&s_rows[wib][0][0];
+  volatile lds_u32* ROWS32 = (volatile lds_u32*)&s_rows[wib][0][0];
+  auto U = [](int x) { return __builtin_amdgcn_readfirstlane(x); };
+  volatile lds_u32* queue = (volatile lds_u32*)&s_q[wib][0];
+  const uint32_t n_todo = n_todo_ptr ? *n_todo_ptr : n_todo_imm;
+  auto rd = [&](int row, int k) -> int { return *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + row * (CAP * 2) + ((k & MASK) << 1)); };
+  auto wr = [&](int row, int k, int v) { *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + row * (CAP * 2) + ((k & MASK) << 1)) = (int16_t)v; };
+  // nulls the diagonals [a, b] of a row (a no-op for an empty interval)
+  auto null_range = [&](int row, int a, int b) { for (int c = a; c <= b; c += 64) if (c + lane <= b) wr(row, c + lane, NUL); };
+
+  for (;;) {
+    const uint32_t tk = otg_wave_atomic_add(ticket, 1u);
+    if (tk >= n_todo) break;
+    const uint32_t ti = todo ? todo[tk] : tk;
+    const otg_align_task t = tasks[ti];
+    const uint8_t* P = arena + t.pattern_off;
+    const uint8_t* T = arena + t.text_off;
+    const int pl = (int)t.pattern_len, tl = (int)t.text_len;
+    const bool ef = t.endsfree != 0;
+    const int pef = ef ? t.pattern_end_free : 0, tef = ef ? t.text_end_free : 0;
+    const int kend = tl - pl;
+    int s_end = -1, k_end = 0;
+    uint64_t W = 0;
+    bool fail = pl + tl >= 32766;
+    PackedPair pk{(volatile lds_u32*)(s_dyn + (size_t)wib * seqw), 0, false};
+    if (!fail) { pk.init(P, pl, T, tl, lane, seqw); fail = !pk.ok; }
+    const int offT4 = pk.offT * 4;
+    const volatile lds_char* SQB = (const volatile lds_char*)pk.SQ;
+    size_t slab_top = 0;
+    int steps_wait = 0;
+    if (!fail) {
+      for (int q = lane; q < NROWS * CAP / 2; q += 64) ROWS32[q] = 0x80008000u;
+      const int lo0 = ef ? imax(-t.pattern_begin_free, -pl) : 0, hi0 = ef ? imin(t.text_begin_free, tl) : 0;
+      if (hi0 - lo0 + 68 > CAP) fail = true;
+      else for (int c = lo0; c <= hi0; c += 64) { const int k = c + lane; if (k <= hi0) wr(ROW_SEED, k, (k > 0 ? k : 0) - 1); }
+    }
+    // the ranges the ring rows stand for, in scalar registers: M[s-1] .. M[s-5] (the last one = what this score's own row still holds) and the
+    // I / D wavefronts of s-1 and s-2; (1, 0) = null
+    int r1lo = 1, r1hi = 0, r2lo = 1, r2hi = 0, r3lo = 1, r3hi = 0, r4lo = 1, r4hi = 0, r5lo = 1, r5hi = 0, i1lo = 1, i1hi = 0, i2lo = 1, i2hi = 0;
+    int sm = RM - 1, si = 1;
+    for (int s = 0; !fail; ++s) {
+      if (s >= ws.nrows) { fail = true; break; }
+      sm = sm + 1 == RM ? 0 : sm + 1; si ^= 1;                   // s % 5, s & 1
+      // the rows this score reads (the null row where the wavefront does not exist) and the range it covers
+      int lo, hi;
+      int qx = ROW_NULL, qo = ROW_NULL, qi = ROW_NULL, qd = ROW_NULL;
+      if (s == 0) {
+        lo = ef ? imax(-t.pattern_begin_free, -pl) : 0;
+        hi = ef ? imin(t.text_begin_free, tl) : 0;
+        qx = ROW_SEED;
+      } else {
+        lo = 1 << 30; hi = -(1 << 30);
+        if (r2hi >= r2lo) { lo = imin(lo, r2lo); hi = imax(hi, r2hi); qx = sm >= xs ? sm - xs : sm - xs + RM; }
+        if (r4hi >= r4lo) { lo = imin(lo, r4lo - 1); hi = imax(hi, r4hi + 1); qo = sm >= oes ? sm - oes : sm - oes + RM; }
+        if (i1hi >= i1lo) { lo = imin(lo, i1lo - 1); hi = imax(hi, i1hi + 1); qi = ROW_I + (si ^ 1); qd = ROW_D + (si ^ 1); }      // (the I and D wavefronts of a score share their range)
+        if (lo < -pl) lo = -pl;
+        if (hi > tl) hi = tl;
+      }
+      // the ring rows of this score are taken over: what their previous scores left is nulled (outside the new range; everything when the score is unreachable)
+      const int omlo = r5lo, omhi = r5hi, oilo = i2lo, oihi = i2hi;
+      r5lo = r4lo; r5hi = r4hi; r4lo = r3lo; r4hi = r3hi; r3lo = r2lo; r3hi = r2hi; r2lo = r1lo; r2hi = r1hi; i2lo = i1lo; i2hi = i1hi;
+      if (hi < lo) {       // null wavefront: this score is not reachable (the reference skips the heuristic too)
+        null_range(sm, omlo, omhi); null_range(ROW_I + si, oilo, oihi); null_range(ROW_D + si, oilo, oihi);
+        r1lo = 1; r1hi = 0; i1lo = 1; i1hi = 0;
+        rowtab[s] = -1;
+        if (s > 2 * (oes + es * (pl + tl)) + 8) fail = true;
+        continue;
+      }
+      const int width = hi - lo + 1, padded = ((width + 63) >> 6) << 6;
+      if (width + 68 > CAP || slab_top + (size_t)padded > ws.slab_bytes) { fail = true; break; }
+      null_range(sm, omlo, imin(omhi, lo - 1)); null_range(sm, imax(omlo, hi + 1), omhi);
+      null_range(ROW_I + si, oilo, imin(oihi, lo - 1)); null_range(ROW_I + si, imax(oilo, hi + 1), oihi);
+      null_range(ROW_D + si, oilo, imin(oihi, lo - 1)); null_range(ROW_D + si, imax(oilo, hi + 1), oihi);
+      uint8_t* btrow = slab + slab_top - lo;     // btrow[k]; the row is padded to whole chunks
+      rowtab[s] = (int64_t)slab_top - lo;        // wave-uniform store
+      slab_top += (size_t)padded;
+      W += 3ull * (uint64_t)width;
+      int dmin = BIG, kfin = BIG;
+      int qn = 0;
+      auto finished = [&](int h, int k) {
+        dmin = imin(dmin, left_to_align(h, k, pl, tl, ef, pef, tef));
+        if (ef) { const int v = h - k; if ((h >= tl && pl - v <= pef) || (v >= pl && tl - h <= tef)) kfin = imin(kfin, k); }
+        else if (k == kend && h >= tl) kfin = k;
+      };
+      auto drain = [&]() {
+        int pass = 0;
+        while (qn > 0) {
+          if (qn <= 4 && pass > 0) {
+            for (int e = 0; e < qn; ++e) {
+              const int kk = lo + U((int)queue[e]);
+              int h = U(rd(sm, kk));
+              const int v = h - kk;
+              h += otg_wave_match(P, T, v, h, imin(pl - v, tl - h), lane);
+              wr(sm, kk, h);                         // the same value from every lane
+              finished(h, kk);
+            }
+            qn = 0;
+            break;
+          }
+          int wq = 0;
+          for (int q0 = 0; q0 < qn; q0 += 64) {
+            const bool act = q0 + lane < qn;
+            int kk = 0, h = 0, v = 0;
+            bool more = false;
+            if (act) {
+              kk = lo + (int)queue[q0 + lane];
+              h = rd(sm, kk);
+              v = h - kk;
+              const int m = pk.match32(v, h, imin(pl - v, tl - h));
+              v += m; h += m;
+              more = (m == 32) && v < pl && h < tl;
+              wr(sm, kk, h);
+              if (!more) finished(h, kk);
+            }
+            const unsigned long long mm = __ballot(more);
+            if (more) {
+              const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+              queue[wq + rank] = (uint32_t)(kk - lo);
+            }
+            wq += __builtin_popcountll(mm);
+          }
+          qn = wq; ++pass;
+        }
+      };
+      // ---- sweep (branch-free per lane)
+      const int bx = qx * (CAP * 2), bo = qo * (CAP * 2), bi = qi * (CAP * 2), bd = qd * (CAP * 2);
+      const int bm = sm * (CAP * 2), bI = (ROW_I + si) * (CAP * 2), bD = (ROW_D + si) * (CAP * 2);
+      for (int c = lo; c <= hi; c += 64) {
+        const int k = c + lane;
+        const int a0 = (k & MASK) << 1, am = ((k - 1) & MASK) << 1, ap = ((k + 1) & MASK) << 1;
+        const int io = *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + bo + am), dop = *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + bo + ap);
+        const int ix = *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + bi + am), dx = *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + bd + ap);
+        const int mm = *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + bx + a0);
+        const bool ext_i = ix >= io, ext_d = dx >= dop;
+        const int insv = imax(ix, io) + 1, delv = imax(dx, dop), mis = mm + 1;
+        const int mx = imax(imax(delv, mis), insv);
+        const uint32_t org = mx == mis ? 0u : (mx == delv ? 1u : 2u);      // mismatch wins ties over deletion over insertion
+        const uint32_t bits = org | (ext_i ? 4u : 0u) | (ext_d ? 8u : 0u);
+        const bool inr = k <= hi;
+        const int v = mx - k;
+        const int t1 = tl - mx, t2 = pl - v;
+        const bool valid = inr && (uint32_t)mx <= (uint32_t)tl && (uint32_t)v <= (uint32_t)pl;
+        int pm;
+        {
+          const int wp = (v >> 2) & ~3, wt = offT4 + ((mx >> 2) & ~3);
+          const uint32_t sp = (uint32_t)(v & 15) * 2u, st = (uint32_t)(mx & 15) * 2u;
+          const volatile lds_u32* pp = (const volatile lds_u32*)(SQB + wp);
+          const volatile lds_u32* pt = (const volatile lds_u32*)(SQB + wt);
+          const uint32_t p0 = pp[0], p1 = pp[1], p2 = pp[2], q0 = pt[0], q1 = pt[1], q2 = pt[2];
+          const uint32_t xl = __builtin_amdgcn_alignbit(p1, p0, sp) ^ __builtin_amdgcn_alignbit(q1, q0, st);
+          const uint32_t xh = __builtin_amdgcn_alignbit(p2, p1, sp) ^ __builtin_amdgcn_alignbit(q2, q1, st);
+          uint32_t flo, fhi;
+          asm("v_ffbl_b32 %0, %1" : "=v"(flo) : "v"(xl));
+          asm("v_ffbl_b32 %0, %1" : "=v"(fhi) : "v"(xh));
+          const uint32_t a = flo < (fhi | 32u) ? flo : (fhi | 32u);
+          pm = (int)((a < 64u ? a : 64u) >> 1);
+        }
+        const int m = imin(imin(pm, t1), t2);
+        const bool more = valid && imin(imin(pm, t1 - 1), t2 - 1) == 32;
+        const int h2 = mx + m;
+        *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + bm + a0) = (int16_t)(valid ? h2 : NUL);
+        *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + bI + a0) = (int16_t)((inr && insv >= 0) ? insv : NUL);
+        *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + bD + a0) = (int16_t)((inr && delv >= 0) ? delv : NUL);
+        btrow[k] = (uint8_t)bits;                                        // every lane stores: the row is padded
+        const bool here = valid && !more;
+        const int lh = t1 - m, lv = t2 - m;
+        int d;
+        bool fin;
+        if (!ef) { d = imax(lh, lv); fin = here && k == kend && lh <= 0; }
+        else { d = imin(imax(lh, lv - pef), imax(lv, lh - tef)); fin = here && ((lh <= 0 && lv <= pef) || (lv <= 0 && lh <= tef)); }
+        kfin = imin(kfin, fin ? k : BIG);
+        dmin = imin(dmin, here ? d : BIG);
+        const unsigned long long mq = __ballot(more);
+        if (mq) {
+          if (more) {
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mq, 0u));
+            queue[qn + rank] = (uint32_t)(k - lo);
+          }
+          qn += __builtin_popcountll(mq);
+          if (qn + 64 > QCAP) drain();
+        }
+      }
+      if (qn) drain();
+      // termination on the fully extended wavefront: end-to-end the end diagonal; ends-free the lowest diagonal that qualifies
+      if (__ballot(kfin != BIG) != 0ull) { k_end = wave_min_i32(kfin); s_end = s; break; }
+      // the cut: M[s], and the score's I / D wavefronts to the same range; what it drops is nulled
+      int clo = lo, chi = hi;
+      const int mind = wave_min_i32(dmin);
+      wfadaptive_cut32(H, steps_wait, mind, pl, tl, ef, pef, tef, clo, chi, lane, [&](int k) { const int x = rd(sm, k); return x < 0 ? OTG_NULL_OFF : x; });
+      if (clo > lo || chi < hi) {
+        null_range(sm, lo, clo - 1); null_range(sm, chi + 1, hi);
+        null_range(ROW_I + si, lo, clo - 1); null_range(ROW_I + si, chi + 1, hi);
+        null_range(ROW_D + si, lo, clo - 1); null_range(ROW_D + si, chi + 1, hi);
+      }
+      r1lo = clo; r1hi = chi;
+      if (s == 0) { i1lo = 1; i1hi = 0; }       // no I / D wavefront at score 0 (its sweep stored nulls: both came from the null row)
+      else { i1lo = clo; i1hi = chi; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");        // row table and provenance rows are read back by all lanes
+
+    if (fail || s_end < 0) {
+      if (overflow_list) { const uint32_t q = otg_wave_atomic_add(n_overflow, 1u); overflow_list[q] = ti; }
+      else { scores[ti] = -1; cig_len[ti] = 0; }
+      continue;
+    }
+    if (!backtrace_unpack<false>(P, pl, T, tl, s_end, k_end, xs, oes, es, rowtab, slab, rev, ws.rev_cap, cig_arena + cig_off[ti], lane, &scores[ti], &cig_len[ti], g,
+                                 (volatile lds_u32*)&s_rows[wib][0][0], EqBytes{P, T})) continue;
+    if (cells) cells[ti] = W;
+  }
+}
+
 int gcd3(int a, int b, int c)
 {
   auto g2 = [](int x, int y) { while (y) { int t = x % y; x = y; y = t; } return x; };
@@ -917,7 +1199,7 @@ int otg_launch_affine_adaptive_todo(otg_ctx* ctx, const uint8_t* d_arena, const 
   const Heur H{ctx->heur_min_wf_len, ctx->heur_max_dist, ctx->heur_steps < 1 ? 1 : ctx->heur_steps};
   const uint32_t ncu = (uint32_t)ctx->n_cu;
   const size_t maxlen = ((size_t)ctx->max_seq_len + 4095) & ~(size_t)4095;
-  static const int only = getenv("OTG_ADAPTIVE_AFFINE_TIERS") ? atoi(getenv("OTG_ADAPTIVE_AFFINE_TIERS")) : 7;
+  static const int only = getenv("OTG_ADAPTIVE_AFFINE_TIERS") ? atoi(getenv("OTG_ADAPTIVE_AFFINE_TIERS")) : 7;      // bit t = tier t runs (packed 256, packed 1024, bytes 1024); the int32 tier always does
 
   AffWs ws;
   ws.capa = (int)(2 * maxlen + 16) & ~1;
@@ -943,8 +1225,8 @@ int otg_launch_affine_adaptive_todo(otg_ctx* ctx, const uint8_t* d_arena, const 
   AffWs w0 = lds_ws(std::max<size_t>((size_t)160 * maxlen, (size_t)1 << 19));
   AffWs w1 = lds_ws(std::max<size_t>((size_t)2560 * maxlen, (size_t)1 << 23));
   // blocks per CU by LDS: rows 9 x CAP x 2 B + queue + range tables + the packed pair
-  const uint32_t pc0 = std::max<uint32_t>(1, std::min<uint32_t>(6, (uint32_t)((160 * 1024) / (WPB0 * (9 * 256 * 2 + 2048 + 256 + (size_t)seqw * 4)))));
-  const uint32_t pc1 = std::max<uint32_t>(1, std::min<uint32_t>(8, (uint32_t)((160 * 1024) / (WPB1 * (9 * 1024 * 2 + 4096 + 256 + (size_t)seqw * 4)))));
+  const uint32_t pc0 = std::max<uint32_t>(1, std::min<uint32_t>(6, (uint32_t)((160 * 1024) / (WPB0 * (11 * 256 * 2 + 1024 + 64 + (size_t)seqw * 4)))));
+  const uint32_t pc1 = std::max<uint32_t>(1, std::min<uint32_t>(8, (uint32_t)((160 * 1024) / (WPB1 * (11 * 1024 * 2 + 4096 + 64 + (size_t)seqw * 4)))));
   uint32_t grid0 = std::min<uint32_t>(ncu * pc0, (n_tasks + WPB0 - 1) / WPB0), grid1 = std::min<uint32_t>(ncu * pc1, n_tasks), grid2 = 8;
   AffWs w2 = ws;
   {
@@ -972,15 +1254,21 @@ int otg_launch_affine_adaptive_todo(otg_ctx* ctx, const uint8_t* d_arena, const 
   if (kernel_ms) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   const uint32_t* in = d_todo; const uint32_t* in_n = d_n_todo; uint32_t in_imm = n_tasks;
   uint32_t* l0 = lists; uint32_t* l1 = lists + n_tasks;
-  if (only & 1) {
-    hipLaunchKernelGGL((wfa_affine_adaptive_kernel<256, 512, WPB0, 8>), dim3(grid0), dim3(WPB0 * 64), (size_t)WPB0 * seqw * 4, ctx->stream, d_arena, d_tasks, in, in_n, in_imm,
-                       xs, oes, es, g, d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, c + 0, c + 3, l0, w0, H, seqw);
+  const bool std_pen = xs == 2 && oes == 4 && es == 1;
+  if ((only & 1) && std_pen) {      // fast tier, 256 diagonals
+    hipLaunchKernelGGL((wfa_affine_adaptive_lds_kernel<256, 256, WPB0>), dim3(grid0), dim3(WPB0 * 64), (size_t)WPB0 * seqw * 4, ctx->stream, d_arena, d_tasks, in, in_n, in_imm,
+                       g, d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, c + 0, c + 3, l0, w0, H, seqw);
     in = l0; in_n = c + 3; in_imm = 0;
   }
-  if (only & 2) {
-    hipLaunchKernelGGL((wfa_affine_adaptive_kernel<1024, 1024, WPB1, 8>), dim3(grid1), dim3(WPB1 * 64), (size_t)WPB1 * seqw * 4, ctx->stream, d_arena, d_tasks, in, in_n, in_imm,
-                       xs, oes, es, g, d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, c + 1, c + 4, l1, w1, H, seqw);
+  if ((only & 2) && std_pen) {      // fast tier, 1024 diagonals
+    hipLaunchKernelGGL((wfa_affine_adaptive_lds_kernel<1024, 1024, WPB1>), dim3(grid1), dim3(WPB1 * 64), (size_t)WPB1 * seqw * 4, ctx->stream, d_arena, d_tasks, in, in_n, in_imm,
+                       g, d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, c + 1, c + 4, l1, w1, H, seqw);
     in = l1; in_n = c + 4; in_imm = 0;
+  }
+  if ((only & 4) && std_pen) {      // byte probes, 1024 diagonals: pairs with bytes outside ACGT or too long to pack
+    hipLaunchKernelGGL((wfa_affine_adaptive_kernel<1024, 1024, WPB1, 8>), dim3(grid1), dim3(WPB1 * 64), 0, ctx->stream, d_arena, d_tasks, in, in_n, in_imm,
+                       xs, oes, es, g, d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, c + 6, c + 7, l0, w1, H, 0);
+    in = l0; in_n = c + 7; in_imm = 0;
   }
   hipLaunchKernelGGL((wfa_affine_adaptive_kernel<0, 2048, WPB2, 64>), dim3(grid2), dim3(WPB2 * 64), 0, ctx->stream, d_arena, d_tasks, in, in_n, in_imm,
                      xs, oes, es, g, d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, c + 2, c + 5, (uint32_t*)nullptr, w2, H, 0);
