@@ -29,8 +29,22 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps if os.path.isfile(d))
 
 
+TOOL_SRC = os.path.join(HERE, "..", "tools", "otter_assemble.cpp")
+TOOL = os.path.join(HERE, "..", "tools", "otter_assemble")
+
+
+def build_tool(force=False):
+    """the command-line host of the dispatcher (plain C++ over the C-ABI); rebuilt when its source or the library is newer"""
+    if not os.path.exists(TOOL_SRC) or not os.path.exists(LIB):
+        return
+    if not force and os.path.exists(TOOL) and os.path.getmtime(TOOL) > max(os.path.getmtime(TOOL_SRC), os.path.getmtime(LIB), os.path.getmtime(os.path.join(HERE, "..", "include", "otter_gpu.h"))):
+        return
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", TOOL, TOOL_SRC, "-L" + HERE, "-lotter_gpu", "-Wl,-rpath," + HERE, "-Wl,-rpath,/opt/rocm/lib"])
+
+
 def build(force=False, verbose=False, jobs=4):
     if not force and not needs_build():
+        build_tool()
         return LIB
     cc = hipcc()
     objs = []
@@ -52,11 +66,7 @@ def build(force=False, verbose=False, jobs=4):
     _drain(procs)
     cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lz", "-pthread", "-ldl"]      # zlib: BGZF blocks of the BAM ingest; threads: its region slices
     subprocess.check_call(cmd)
-    # the command-line host of the dispatcher (plain C++ over the C-ABI)
-    tool_src = os.path.join(HERE, "..", "tools", "otter_assemble.cpp")
-    if os.path.exists(tool_src):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", os.path.join(HERE, "..", "tools", "otter_assemble"), tool_src,
-                               "-L" + HERE, "-lotter_gpu", "-Wl,-rpath," + HERE, "-Wl,-rpath,/opt/rocm/lib"])
+    build_tool(force=True)
     return LIB
 
 

@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <mutex>
+#include <vector>
 
 using namespace otg_affine;
 
@@ -1090,6 +1091,31 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
     fprintf(stderr, "[otg] affine: register tiers take %u / %u / %u / %u / %u alignments, %u go to the HBM-row tiers (of which given up by a register tier: %u); tier A gives up %u, tier B %u\n",
             h5[1] - h5[0], h5[2] - h5[1], h5[3] - h5[2], h5[4] - h5[3], h5[5] - h5[4], h5[7], h5[7] - (h5[6] - h5[5]), h[9], h[11]);
     const int32_t* dbg_bound = (const int32_t*)ctx->pool[SLOT_BT_POOL].p;
+    if (dbg_bound && bounded) {
+      // How loose is the bound?  The exact tiers visit the diamond of the bound U (~U^2 / 2 cells); the diamond of the final score s would do.
+      // Histogram of U / s and the share of diamond cells that lie outside the exact score's diamond (sum U^2 against sum s^2).
+      std::vector<int32_t> hb(n_tasks), hs(n_tasks);
+      HIP_TRY(ctx, hipMemcpy(hb.data(), dbg_bound, (size_t)n_tasks * 4, hipMemcpyDeviceToHost));
+      HIP_TRY(ctx, hipMemcpy(hs.data(), d_scores, (size_t)n_tasks * 4, hipMemcpyDeviceToHost));
+      uint32_t n_live = 0;
+      std::vector<uint32_t> ids;
+      if (d_todo) {
+        if (d_n_todo) HIP_TRY(ctx, hipMemcpy(&n_live, d_n_todo, 4, hipMemcpyDeviceToHost)); else n_live = n_tasks;
+        ids.resize(n_live);
+        if (n_live) HIP_TRY(ctx, hipMemcpy(ids.data(), d_todo, (size_t)n_live * 4, hipMemcpyDeviceToHost));
+      } else { n_live = n_tasks; ids.resize(n_live); for (uint32_t i = 0; i < n_live; ++i) ids[i] = i; }
+      double su2 = 0, ss2 = 0; uint64_t hist[6] = {0, 0, 0, 0, 0, 0}, n_ok = 0;
+      for (uint32_t q = 0; q < n_live; ++q) {
+        const int32_t U = hb[ids[q]], sc = hs[ids[q]];
+        if (U < 0 || U >= 0x40000000 || sc <= 0) continue;
+        const double u = (double)U * g, r = u / (double)sc;       // the bound is in units of g, the score in penalty units
+        su2 += u * u; ss2 += (double)sc * sc; ++n_ok;
+        ++hist[r <= 1.0 ? 0 : r <= 1.02 ? 1 : r <= 1.05 ? 2 : r <= 1.1 ? 3 : r <= 1.2 ? 4 : 5];
+      }
+      if (n_ok) fprintf(stderr, "[otg] affine: bound / final score over %llu alignments: == 1: %.1f %%, <= 1.02: %.1f %%, <= 1.05: %.1f %%, <= 1.1: %.1f %%, <= 1.2: %.1f %%, above: %.1f %%; diamond cells outside the exact score's diamond: %.1f %%\n",
+                        (unsigned long long)n_ok, 100.0 * hist[0] / n_ok, 100.0 * hist[1] / n_ok, 100.0 * hist[2] / n_ok, 100.0 * hist[3] / n_ok, 100.0 * hist[4] / n_ok, 100.0 * hist[5] / n_ok,
+                        100.0 * (su2 - ss2) / su2);
+    }
     if (h5[7] && dbg_bound && bounded && reg_mask) {        // who left a register tier (the first few): lengths, free ends, bound
       const uint32_t nshow = std::min<uint32_t>(h5[7], 24u);
       std::vector<uint32_t> ids(nshow);

@@ -251,3 +251,34 @@ def test_dispatcher_batch_plan_of_the_library(gpu, tmp_path):
     two, st2 = otter_amd.assemble_files(fx["bam"], fx["bed"], batch_regions=0, devices=[0, 0], **kw)
     assert two == whole and st2["n_devices"] == 2
     otter_amd.assemble_files_release()
+
+
+@pytest.mark.gpu
+def test_dispatcher_adaptive_heuristic(gpu, oracle, tmp_path):
+    """The aligner mode travels through the one-call path: otg_assemble_job.params.heuristic = wfadaptive(10,50,1) (and the command line's
+    --wfa-heuristic) gives the text of library ingest -> ORACLE in adaptive mode -> oracle emit; the default job stays exact, and the two differ."""
+    import os
+    import subprocess
+    from otter_amd import bamwrite
+    fx = bamwrite.make_tr_fixture(str(tmp_path), 12, depth=16, len_range=(500, 1600), seed=9)
+    b = otter_amd.Bam(fx["bam"])
+    batch = b.ingest(fx["regions"], offset_l=1, offset_r=1, mapq=10)
+    hdr = otter_amd.emit_sam_header(b.targets(), "s1", 1, 1)
+    b.close()
+    beds, carena = abi.make_beds(fx["regions"])
+    texts = {}
+    gpu.trim()
+    for name, heur in (("exact", abi.OTG_HEURISTIC_NONE), ("adaptive", abi.OTG_HEURISTIC_WFADAPTIVE)):
+        P = abi.default_params(heuristic=heur)
+        expect = hdr + oracle.emit_alleles(beds, carena, oracle.assemble_batch(P, batch), "s1", False)
+        text, st = otter_amd.assemble_files(fx["bam"], fx["bed"], read_group="s1", params=P, batch_regions=5, offset_l=1, offset_r=1, mapq=10, threads=2)
+        assert text == expect, name
+        texts[name] = text
+    assert texts["exact"] != texts["adaptive"]          # ONT reads of 0.5-1.6 kb: the adaptive cut moves some consensus bases
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "otter_assemble")
+    if os.path.exists(tool):
+        otter_amd.assemble_files_release()
+        for flag, want in ((["--wfa-heuristic", "wfadaptive"], "adaptive"), (["--wfa-heuristic", "wfadaptive:10,50,1"], "adaptive"), (["--wfa-heuristic", "none"], "exact"), ([], "exact")):
+            p = subprocess.run([tool, "-b", fx["bed"], "-R", "s1", "-o", "1,1", "-m", "10", "-t", "2"] + flag + [fx["bam"]], capture_output=True, timeout=300)
+            assert p.returncode == 0, p.stderr.decode()[-500:]
+            assert p.stdout == texts[want], flag

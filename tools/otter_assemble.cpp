@@ -2,7 +2,10 @@
 // (src/command_assemble.cpp:20-45) over otg_assemble_files, the dispatcher of libotter_gpu.so.  Host C++ only: BED / BAM / FASTA in,
 // SAM or FASTA records on stdout, in BED order.
 //   otter_assemble -b regions.bed -R sample [-r ref.fa] [--fasta] [--reads-only] [--haps] [-p] [-l] [-o L[,R]] [-a N] [-m Q] [-q RQ] [-c COV]
-//                  [-F f] [-A len,f] [-e err] [-h bw[,len,bw]] [-f flank] [-s sim] [-t threads] [--batch N] [--gpus 0,1,..] <BAM>
+//                  [-F f] [-A len,f] [-e err] [-h bw[,len,bw]] [-f flank] [-s sim] [-t threads] [--batch N] [--gpus 0,1,..]
+//                  [--wfa-heuristic none|wfadaptive[:min_wavefront_length,max_distance_threshold,steps]] <BAM>
+// The last option has no counterpart in the reference: its aligners run whatever WFA2-lib's default heuristic is (src/assemble.cpp:49-50 never
+// calls setHeuristic*); here the default is exact alignment and `wfadaptive` (= 10,50,1) reproduces a WFA2-lib whose default is the adaptive one.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -53,6 +56,15 @@ int main(int argc, char** argv)
     else if (a == "-t" || a == "--threads") job.ingest.threads = atoi(val().c_str());
     else if (a == "--batch") job.batch_regions = (uint32_t)atoi(val().c_str());
     else if (a == "--gpus") { for (auto& d : split(val(), ',')) devs.push_back(atoi(d.c_str())); }
+    else if (a == "--wfa-heuristic") {
+      const std::string h = val();
+      if (h == "none") job.params.heuristic = OTG_HEURISTIC_NONE;
+      else if (h.rfind("wfadaptive", 0) == 0) {
+        job.params.heuristic = OTG_HEURISTIC_WFADAPTIVE;
+        if (h.size() > 10 && h[10] == ':') { auto v = split(h.substr(11), ','); if (v.size() != 3) { fprintf(stderr, "[ERROR] --wfa-heuristic wfadaptive:<min_wavefront_length>,<max_distance_threshold>,<steps>\n"); return 1; }
+          job.params.heur_min_wavefront_length = atoi(v[0].c_str()); job.params.heur_max_distance_threshold = atoi(v[1].c_str()); job.params.heur_steps_between_cutoffs = atoi(v[2].c_str()); }
+      } else { fprintf(stderr, "[ERROR] --wfa-heuristic none | wfadaptive[:a,b,c]\n"); return 1; }
+    }
     else if (a.size() && a[0] == '-') { fprintf(stderr, "[ERROR] unknown option %s\n", a.c_str()); return 1; }
     else bam = a;
   }
