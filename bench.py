@@ -354,10 +354,17 @@ def run_rank(args):
         return 2
     import numpy as np
     from otter_amd import abi, synth          # numpy only: nothing here touches the GPU
+    # Rehearsal of the N > 1 code path on a box with ONE GPU (OTG_BENCH_REHEARSAL=1, optionally OTG_BENCH_REHEARSAL_REGIONS=<multiple of 250>): every
+    # rank opens its context on device 0, the process group is gloo, the records are gathered from host memory.  Not a measurement — it exists so
+    # that the control flow of the multi-rank run (shards, legs, collectives, who prints) has been executed before a real 8-GPU node runs it.
+    rehearse = os.environ.get("OTG_BENCH_REHEARSAL") == "1" and world > 1
+    reh_regions = int(os.environ.get("OTG_BENCH_REHEARSAL_REGIONS", "0")) if rehearse else 0
 
     # ---- every synthetic input first, by worker processes, before torch / HIP are initialised in this process
     cfg = args.config if args.config is not None else 1
     n_regions = args.regions if args.regions is not None else (synth.CONFIGS[cfg]["n_regions"] // 8 if cfg == 4 else synth.CONFIGS[cfg]["n_regions"])
+    if reh_regions and args.regions is None:
+        n_regions = reh_regions
     if n_regions % synth.CHUNK and world > 1:
         sys.stderr.write("bench.py: --regions must be a multiple of %d for N>1\n" % synth.CHUNK)
         return 2
@@ -375,7 +382,7 @@ def run_rank(args):
     # N > 1: north_star's own shape rides along — configs[4], the 100 000-region job of 1-10 kb loci, 12 500 regions per GPU (rank r's contiguous shard)
     want_leg4_multi = world > 1 and not args.no_legs and args.config is None and args.regions is None
     if want_leg4_multi:
-        n4 = synth.CONFIGS[4]["n_regions"] // 8
+        n4 = reh_regions if reh_regions else synth.CONFIGS[4]["n_regions"] // 8
         legs_in[4] = synth.config_batch(4, n4, first_chunk=rank * (n4 // synth.CHUNK), workers=workers)
     gen_s = time.perf_counter() - t_gen
     fixture = start_fixture(args.e2e_regions) if (args.e2e_regions > 0 and world == 1) else None
@@ -386,11 +393,16 @@ def run_rank(args):
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            local_rank = 0
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     import otter_amd
     from otter_amd import parallel
     ctx = otter_amd.Context(local_rank)
+    tdev = torch.device("cpu") if rehearse else torch.device("cuda", local_rank)      # where the timing tensors and the gathered records live
     nth = max(1, min(32, os.cpu_count() or 1))       # the reference caps -t at 32 (src/otter_opts.cpp:93)
 
     def sync():
@@ -458,8 +470,8 @@ def run_rank(args):
                 # end-of-run gather of the per-region allele records to rank 0 (RCCL over xGMI), straight from the library's
                 # device-resident result buffers: GPU -> GPU, one device-to-host copy on rank 0
                 t0 = time.perf_counter()
-                res = ctx.assemble_device_results()
-                g = parallel.gather_records(res, dist, rank, world, torch.device("cuda", local_rank))
+                res = ctx.assemble_collect() if rehearse else ctx.assemble_device_results()
+                g = parallel.gather_records(res, dist, rank, world, tdev)
                 info["gather_ms"] = (time.perf_counter() - t0) * 1000.0
                 if rank == 0:
                     info["records"] = len(g["alleles"])
@@ -493,7 +505,7 @@ def run_rank(args):
     st = r["kstats"][-1]
     regions_ok = int(st["n_regions_ok"])
     dt = r["dt"]
-    tt = torch.tensor([dt, float(regions_ok)], dtype=torch.float64, device="cuda")
+    tt = torch.tensor([dt, float(regions_ok)], dtype=torch.float64, device=tdev)
     world_seen = 1
     if dist is not None:
         tmax = tt.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -506,7 +518,7 @@ def run_rank(args):
     if want_leg4_multi:
         lr = assemble_run(4, legs_in[4], args.leg_steps, 1, 0)
         ls = lr["kstats"][-1]
-        t4 = torch.tensor([lr["dt"], float(int(ls["n_regions_ok"]))], dtype=torch.float64, device="cuda")
+        t4 = torch.tensor([lr["dt"], float(int(ls["n_regions_ok"]))], dtype=torch.float64, device=tdev)
         t4max = t4.clone(); dist.all_reduce(t4max, op=dist.ReduceOp.MAX)
         t4sum = t4.clone(); dist.all_reduce(t4sum, op=dist.ReduceOp.SUM)
         dt4 = float(t4max[0])
@@ -529,6 +541,7 @@ def run_rank(args):
         "config": {"workload": synth.config_workload(cfg, n_regions, world), "baseline_config": cfg,
                    "regions_per_gpu": n_regions, "reads_per_region": synth.CONFIGS[cfg]["n_reads"],
                    "parallelism": "static BED shard x%d + RCCL gather" % world, "world_size_rccl": world_seen,
+                   **({"rehearsal": "OTG_BENCH_REHEARSAL=1: all ranks on device 0, gloo, host gather — control-flow check, NOT a measurement"} if rehearse else {}),
                    "aligner_heuristic": "none (exact)" if args.heuristic == "none" else "wfadaptive(10,50,1)",
                    "timed_region": "otg_assemble_run + " + ("RCCL gather to rank 0 + one D2H" if world > 1 else "otg_assemble_collect (D2H of the records)") + "; inputs resident in HBM",
                    "stage_ms": stage_ms(st),

@@ -100,3 +100,28 @@ def test_library_gather_two_ranks(tmp_path):
         whole = ctx.assemble(abi.default_params(), b)
     assert g["counts"][:, 0].tolist() == [20, 20]
     assert _records(g) == _records(whole)
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_control_flow_rehearsal(gpu):
+    """bench.py's N > 1 path executed on the one-GPU box (OTG_BENCH_REHEARSAL=1: two ranks, both contexts on device 0, gloo, records gathered from host
+    memory): static BED shards per rank, the timed steps with their gather, the configs[4] leg that rides along at N > 1, the max / sum over ranks, rank 0
+    printing ONE line.  A control-flow check, not a measurement (the line says so)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gpu.trim()
+    env = dict(os.environ, OTG_BENCH_REHEARSAL="1", OTG_BENCH_REHEARSAL_REGIONS="250")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--leg-steps", "1"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "rehearsal" in d["config"]
+    assert d["config"]["regions_per_gpu"] == 250 and "static BED shard of 500" in d["config"]["workload"]
+    leg = d["config"]["legs"]["configs[4]"]
+    assert leg["n_gpus"] == 2 and leg["value"] > 0 and leg["allele_records"] >= 500 and "1000-10000 bp" in leg["workload"]
+    assert d["config"]["gather"]["bytes"] > 0
