@@ -508,28 +508,48 @@ int otg_genotype_files(const otg_genotype_job* job, otg_write_fn write, void* us
   }
   const uint32_t per = job->batch_regions ? job->batch_regions : 1024u;
   const int threads = job->threads > 0 ? job->threads : 1;
-  std::vector<uint8_t> arena; std::vector<otg_allele> alleles; std::vector<uint32_t> first;
+  // Two batches in flight: while one is clustered on the GPU and formatted, the next is ingested (the reference does all three one region at a
+  // time, src/genotype.cpp:80-157; SURVEY finding 9: this command is BAM-I/O-bound, so ingest is what must never wait).  The VCF text of a batch is
+  // formatted by `threads` host threads, each a contiguous slice of its regions, concatenated in order.
+  struct GtBatch {
+    std::vector<uint8_t> arena; std::vector<otg_allele> alleles; std::vector<uint32_t> first;
+    uint32_t f = 0, n = 0, na = 0; uint64_t used = 0; int rc = OTG_OK; double ms = 0; std::string err;
+  };
+  GtBatch bufs[2];
+  auto ingest_into = [&](GtBatch& B, uint32_t f) {
+    B.f = f; B.n = std::min<uint32_t>(per, (uint32_t)beds.size() - f);
+    B.first.assign((size_t)B.n + 1, 0);
+    size_t cap_al = std::max<size_t>(B.alleles.size(), (size_t)B.n * 128 + 64), cap_ar = std::max<size_t>(B.arena.size(), (size_t)B.n * 128 * 4096 + 4096);
+    const auto t0 = Clock::now();
+    for (int attempt = 0; attempt < 4; ++attempt) {
+      B.alleles.resize(cap_al); B.arena.resize(cap_ar);
+      B.na = 0; B.used = 0;
+      B.rc = otg_ingest_alleles(bam, beds.data() + f, chr_arena.data(), B.n, threads, fasta, B.arena.data(), B.arena.size(), &B.used, B.alleles.data(), (uint32_t)B.alleles.size(), &B.na, B.first.data());
+      if (B.rc != OTG_ERR_CAPACITY) break;
+      cap_al = (size_t)B.na + 64; cap_ar = (size_t)B.used + 4096;
+    }
+    if (B.rc != OTG_OK) B.err = last_err();
+    B.ms = ms_since(t0);
+  };
   std::vector<uint64_t> seq_off; std::vector<uint32_t> seq_len, n_al;
   std::vector<int32_t> gt, gtl, gtk, ngt, reps; std::vector<double> hsd;
   std::string text;
-  for (uint32_t f = 0; f < (uint32_t)beds.size(); f += per) {
-    const uint32_t n = std::min<uint32_t>(per, (uint32_t)beds.size() - f);
-    first.assign((size_t)n + 1, 0);
-    size_t cap_al = std::max<size_t>(alleles.size(), (size_t)n * 128 + 64), cap_ar = std::max<size_t>(arena.size(), (size_t)n * 128 * 4096 + 4096);
-    uint32_t na = 0; uint64_t used = 0;
-    auto t0 = Clock::now();
-    for (int attempt = 0; attempt < 4; ++attempt) {
-      alleles.resize(cap_al); arena.resize(cap_ar);
-      na = 0; used = 0;
-      rc = otg_ingest_alleles(bam, beds.data() + f, chr_arena.data(), n, threads, fasta, arena.data(), arena.size(), &used, alleles.data(), (uint32_t)alleles.size(), &na, first.data());
-      if (rc != OTG_ERR_CAPACITY) break;
-      cap_al = (size_t)na + 64; cap_ar = (size_t)used + 4096;
-    }
-    if (rc != OTG_OK) { cleanup(); return rc; }
-    st.ms_ingest += ms_since(t0); st.n_reads += na; st.input_bytes += used;
+  std::vector<std::string> parts;
+  const uint32_t n_beds = (uint32_t)beds.size();
+  if (n_beds) ingest_into(bufs[0], 0);
+  for (uint32_t f = 0, idx = 0; f < n_beds; f += per, ++idx) {
+    GtBatch& B = bufs[idx & 1];
+    if (B.rc != OTG_OK) { rc = B.rc; const std::string e = B.err; cleanup(); return otg_fail(nullptr, rc, "otg_genotype_files: %s", e.c_str()); }
+    std::thread next;
+    const bool overlap = with_ref && f + per < n_beds;            // (the two-length table without -r reads the BAM handle's sample list while it formats: kept in sequence)
+    if (overlap) next = std::thread([&, f, idx] { ingest_into(bufs[(idx + 1) & 1], f + per); });
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{next};
+    const uint32_t n = B.n, na = B.na; const uint64_t used = B.used;
+    std::vector<uint32_t>& first = B.first; std::vector<otg_allele>& alleles = B.alleles; std::vector<uint8_t>& arena = B.arena;
+    st.ms_ingest += B.ms; st.n_reads += na; st.input_bytes += used;
     uint64_t need = 0;
+    auto t0 = Clock::now();
     if (with_ref) {
-      t0 = Clock::now();
       seq_off.resize(na); seq_len.resize(na); n_al.resize(n);
       for (uint32_t i = 0; i < na; ++i) { seq_off[i] = alleles[i].seq_off; seq_len[i] = alleles[i].seq_len; }
       for (uint32_t r = 0; r < n; ++r) n_al[r] = first[r + 1] - first[r];
@@ -538,28 +558,60 @@ int otg_genotype_files(const otg_genotype_job* job, otg_write_fn write, void* us
       if (na) {
         rc = otg_genotype_cluster_batch(ctx, &job->params, arena.data(), used + 64, seq_off.data(), seq_len.data(), first.data(), n_al.data(), n,
                                         gt.data(), gtl.data(), gtk.data(), hsd.data(), ngt.data(), reps.data());      // anallele_cluster (src/genotype.cpp:138)
-        if (rc != OTG_OK) { const std::string e = otg_last_error(ctx) ? otg_last_error(ctx) : ""; cleanup(); return otg_fail(nullptr, rc, "otg_genotype_files: %s", e.c_str()); }
+        if (rc != OTG_OK) { const std::string e = otg_last_error(ctx) ? otg_last_error(ctx) : ""; joiner.~Joiner(); cleanup(); return otg_fail(nullptr, rc, "otg_genotype_files: %s", e.c_str()); }
       } else std::fill(ngt.begin(), ngt.end(), 0);
       st.ms_hot_path += ms_since(t0);
       t0 = Clock::now();
-      rc = otg_emit_vcf_lines(beds.data() + f, chr_arena.data(), n, first.data(), alleles.data(), arena.data(), n_samples, gt.data(), hsd.data(), ngt.data(), reps.data(), ol, orr, nullptr, 0, &need);
-      if (rc != OTG_OK && rc != OTG_ERR_CAPACITY) { cleanup(); return rc; }
-      text.resize(need);
-      rc = otg_emit_vcf_lines(beds.data() + f, chr_arena.data(), n, first.data(), alleles.data(), arena.data(), n_samples, gt.data(), hsd.data(), ngt.data(), reps.data(), ol, orr,
-                              need ? &text[0] : nullptr, need, &need);
+      // VCF lines: slices of the batch's regions on host threads (output_vcf_line, src/genotype.cpp:43-78, is a pure function of its region)
+      const uint32_t nslice = (uint32_t)std::max(1, std::min<int>(threads, (int)((n + 31) / 32)));
+      parts.assign(nslice, std::string());
+      std::vector<int> prc(nslice, OTG_OK);
+      std::vector<std::string> perr(nslice);
+      auto emit_slice = [&](uint32_t sidx) {
+        const uint32_t a = (uint32_t)((uint64_t)n * sidx / nslice), e = (uint32_t)((uint64_t)n * (sidx + 1) / nslice);
+        std::string& out = parts[sidx];
+        uint64_t bytes = 0;
+        for (uint32_t r = a; r < e; ++r) bytes += 512 + 80ull * (n_samples + 1);
+        for (uint32_t i = first[a]; i < first[e]; ++i) bytes += alleles[i].seq_len + 8;          // every allele sequence could be an ALT
+        out.resize(bytes);
+        uint64_t len = 0;
+        int r2 = otg_emit_vcf_lines(beds.data() + f + a, chr_arena.data(), e - a, first.data() + a, alleles.data(), arena.data(), n_samples, gt.data(), hsd.data(), ngt.data() + a,
+                                    reps.data(), ol, orr, bytes ? &out[0] : nullptr, bytes, &len);
+        if (r2 == OTG_ERR_CAPACITY) {         // (the estimate above is an upper bound; kept as a safety net)
+          out.resize(len);
+          r2 = otg_emit_vcf_lines(beds.data() + f + a, chr_arena.data(), e - a, first.data() + a, alleles.data(), arena.data(), n_samples, gt.data(), hsd.data(), ngt.data() + a,
+                                  reps.data(), ol, orr, len ? &out[0] : nullptr, len, &len);
+        }
+        if (r2 != OTG_OK) perr[sidx] = last_err();
+        prc[sidx] = r2;
+        out.resize(r2 == OTG_OK ? len : 0);
+      };
+      if (nslice == 1) emit_slice(0);
+      else {
+        std::vector<std::thread> th;
+        for (uint32_t sidx = 0; sidx < nslice; ++sidx) th.emplace_back(emit_slice, sidx);
+        for (auto& t : th) t.join();
+      }
+      text.clear();
+      for (uint32_t sidx = 0; sidx < nslice; ++sidx) {
+        if (prc[sidx] != OTG_OK) { rc = prc[sidx]; const std::string e = perr[sidx]; joiner.~Joiner(); cleanup(); return otg_fail(nullptr, rc, "otg_genotype_files: %s", e.c_str()); }
+        text += parts[sidx];
+      }
+      rc = OTG_OK;
     } else {
-      t0 = Clock::now();
       rc = otg_emit_genotype_lengths(bam, beds.data() + f, chr_arena.data(), n, first.data(), alleles.data(), n_samples, nullptr, 0, &need);   // src/genotype.cpp:112-121
       if (rc != OTG_OK && rc != OTG_ERR_CAPACITY) { cleanup(); return rc; }
       text.resize(need);
       rc = otg_emit_genotype_lengths(bam, beds.data() + f, chr_arena.data(), n, first.data(), alleles.data(), n_samples, need ? &text[0] : nullptr, need, &need);
     }
-    if (rc != OTG_OK) { cleanup(); return rc; }
+    if (rc != OTG_OK) { joiner.~Joiner(); cleanup(); return rc; }
     st.ms_emit += ms_since(t0);
     for (uint32_t r = 0; r < n; ++r) { if (first[r + 1] > first[r]) ++st.n_regions_ok; }
     st.n_alleles += na;
-    if (!text.empty() && write(user, text.data(), text.size()) != 0) { cleanup(); return otg_fail(nullptr, OTG_ERR_ARG, "otg_genotype_files: the writer failed"); }
+    if (!text.empty() && write(user, text.data(), text.size()) != 0) { joiner.~Joiner(); cleanup(); return otg_fail(nullptr, OTG_ERR_ARG, "otg_genotype_files: the writer failed"); }
     st.output_bytes += text.size();
+    if (next.joinable()) next.join();
+    if (!overlap && f + per < n_beds) ingest_into(bufs[(idx + 1) & 1], f + per);
   }
   cleanup();
   st.ms_total = ms_since(t_all); st.n_devices = 1;
