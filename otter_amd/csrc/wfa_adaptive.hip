@@ -855,7 +855,7 @@ __global__ __launch_bounds__(WPB * 64) void wfa_affine_adaptive_kernel(
 // cell are read unconditionally: when a ring row is taken over by a new score, what its previous score left outside the new range is nulled, and
 // so is what a cut drops.  Every lane of a chunk computes, probes and stores (NULL where the lane lies behind the range); a provenance row is
 // padded to whole chunks for the same reason.
-template <int CAP, int QCAP, int WPB>
+template <int CAP, int QCAP, int WPB, bool MASKED>
 __global__ __launch_bounds__(WPB * 64) void wfa_affine_adaptive_lds_kernel(
     const uint8_t* __restrict__ arena, const otg_align_task* __restrict__ tasks,
     const uint32_t* __restrict__ todo, const uint32_t* __restrict__ n_todo_ptr, uint32_t n_todo_imm, int g,
@@ -867,6 +867,7 @@ __global__ __launch_bounds__(WPB * 64) void wfa_affine_adaptive_lds_kernel(
   constexpr int xs = 2, oes = 4, es = 1, RM = 5, RI = 2;
   constexpr int ROW_I = RM, ROW_D = RM + RI, ROW_NULL = RM + 2 * RI, ROW_SEED = ROW_NULL + 1, NROWS = ROW_SEED + 1;
   constexpr int MASK = CAP - 1, NUL = -32768;
+  constexpr int PAD = MASKED ? 4 : 68;        // diagonals of the window a range must leave free (unmasked: the last chunk's 64 lanes all store)
   static_assert(NROWS * CAP * 2 >= 2048, "the backtrace stages its 2 KB window in the rows (free once the forward pass is over)");
   __shared__ __attribute__((aligned(16))) int16_t s_rows[WPB][NROWS][CAP];
   __shared__ __attribute__((aligned(16))) uint32_t s_q[WPB][QCAP];
@@ -911,7 +912,7 @@ __global__ __launch_bounds__(WPB * 64) void wfa_affine_adaptive_lds_kernel(
     if (!fail) {
       for (int q = lane; q < NROWS * CAP / 2; q += 64) ROWS32[q] = 0x80008000u;
       const int lo0 = ef ? imax(-t.pattern_begin_free, -pl) : 0, hi0 = ef ? imin(t.text_begin_free, tl) : 0;
-      if (hi0 - lo0 + 68 > CAP) fail = true;
+      if (hi0 - lo0 + PAD > CAP) fail = true;
       else for (int c = lo0; c <= hi0; c += 64) { const int k = c + lane; if (k <= hi0) wr(ROW_SEED, k, (k > 0 ? k : 0) - 1); }
     }
     // the ranges the ring rows stand for, in scalar registers: M[s-1] .. M[s-5] (the last one = what this score's own row still holds) and the
@@ -947,7 +948,7 @@ __global__ __launch_bounds__(WPB * 64) void wfa_affine_adaptive_lds_kernel(
         continue;
       }
       const int width = hi - lo + 1, padded = ((width + 63) >> 6) << 6;
-      if (width + 68 > CAP || slab_top + (size_t)padded > ws.slab_bytes) { fail = true; break; }
+      if (width + PAD > CAP || slab_top + (size_t)padded > ws.slab_bytes) { fail = true; break; }
       null_range(sm, omlo, imin(omhi, lo - 1)); null_range(sm, imax(omlo, hi + 1), omhi);
       null_range(ROW_I + si, oilo, imin(oihi, lo - 1)); null_range(ROW_I + si, imax(oilo, hi + 1), oihi);
       null_range(ROW_D + si, oilo, imin(oihi, lo - 1)); null_range(ROW_D + si, imax(oilo, hi + 1), oihi);
@@ -1038,9 +1039,11 @@ __global__ __launch_bounds__(WPB * 64) void wfa_affine_adaptive_lds_kernel(
         const int m = imin(imin(pm, t1), t2);
         const bool more = valid && imin(imin(pm, t1 - 1), t2 - 1) == 32;
         const int h2 = mx + m;
-        *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + bm + a0) = (int16_t)(valid ? h2 : NUL);
-        *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + bI + a0) = (int16_t)((inr && insv >= 0) ? insv : NUL);
-        *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + bD + a0) = (int16_t)((inr && delv >= 0) ? delv : NUL);
+        if (!MASKED || inr) {       // MASKED: lanes behind the range do not store, the window is usable up to CAP - 4 diagonals (one execution-mask region per chunk)
+          *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + bm + a0) = (int16_t)(valid ? h2 : NUL);
+          *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + bI + a0) = (int16_t)((inr && insv >= 0) ? insv : NUL);
+          *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + bD + a0) = (int16_t)((inr && delv >= 0) ? delv : NUL);
+        }
         btrow[k] = (uint8_t)bits;                                        // every lane stores: the row is padded
         const bool here = valid && !more;
         const int lh = t1 - m, lv = t2 - m;
@@ -1256,12 +1259,12 @@ int otg_launch_affine_adaptive_todo(otg_ctx* ctx, const uint8_t* d_arena, const 
   uint32_t* l0 = lists; uint32_t* l1 = lists + n_tasks;
   const bool std_pen = xs == 2 && oes == 4 && es == 1;
   if ((only & 1) && std_pen) {      // fast tier, 256 diagonals
-    hipLaunchKernelGGL((wfa_affine_adaptive_lds_kernel<256, 256, WPB0>), dim3(grid0), dim3(WPB0 * 64), (size_t)WPB0 * seqw * 4, ctx->stream, d_arena, d_tasks, in, in_n, in_imm,
+    hipLaunchKernelGGL((wfa_affine_adaptive_lds_kernel<256, 256, WPB0, true>), dim3(grid0), dim3(WPB0 * 64), (size_t)WPB0 * seqw * 4, ctx->stream, d_arena, d_tasks, in, in_n, in_imm,
                        g, d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, c + 0, c + 3, l0, w0, H, seqw);
     in = l0; in_n = c + 3; in_imm = 0;
   }
   if ((only & 2) && std_pen) {      // fast tier, 1024 diagonals
-    hipLaunchKernelGGL((wfa_affine_adaptive_lds_kernel<1024, 1024, WPB1>), dim3(grid1), dim3(WPB1 * 64), (size_t)WPB1 * seqw * 4, ctx->stream, d_arena, d_tasks, in, in_n, in_imm,
+    hipLaunchKernelGGL((wfa_affine_adaptive_lds_kernel<1024, 1024, WPB1, false>), dim3(grid1), dim3(WPB1 * 64), (size_t)WPB1 * seqw * 4, ctx->stream, d_arena, d_tasks, in, in_n, in_imm,
                        g, d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, c + 1, c + 4, l1, w1, H, seqw);
     in = l1; in_n = c + 4; in_imm = 0;
   }
