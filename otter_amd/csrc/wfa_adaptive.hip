@@ -1087,7 +1087,295 @@ __global__ __launch_bounds__(WPB * 64) void wfa_affine_adaptive_lds_kernel(
       continue;
     }
     if (!backtrace_unpack<false>(P, pl, T, tl, s_end, k_end, xs, oes, es, rowtab, slab, rev, ws.rev_cap, cig_arena + cig_off[ti], lane, &scores[ti], &cig_len[ti], g,
-                                 (volatile lds_u32*)&s_rows[wib][0][0], EqBytes{P, T})) continue;
+                                 (volatile lds_u32*)&s_rows[wib][0][0], EqPacked{pk.SQ, pk.offT})) continue;
+    if (cells) cells[ti] = W;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The wide gap-affine tiers: NW waves on ONE alignment.  What reaches them are the alignments whose wavefront outgrows the 256-diagonal window —
+// 5-15 chunks of 64 diagonals per score — and a wave on its own spends a score waiting for LDS, chunk after chunk, with less than one wave per
+// SIMD resident (the provenance slab of an alignment, not LDS, bounds how many are in flight).  Here the chunks of a score are dealt to the waves
+// of the block (chunk j to wave j mod NW); everything else of a score is REPLICATED: every wave keeps the ranges, the row indices, the slab
+// cursor and the cut's step counter in its own scalar registers and computes the same values from the same inputs, so a score needs one barrier:
+//
+//   take-over nulling (block-wide, disjoint from what the sweep stores)  ->  sweep of the own chunks, own queue, own drain  ->  own minimum of
+//   "left to align" and own end candidate to LDS  ->  BARRIER  ->  every wave reduces the NW pairs, every wave computes the cut from the M row
+//   and nulls what it drops.
+//
+// The cut is safe to compute while another wave already nulls: a wave nulls only diagonals the cut dropped, i.e. diagonals that were NOT within
+// the threshold, and a null offset reads as "not within the threshold" — a late wave finds the same first diagonal from either end.  The rows a
+// wave that runs ahead writes in the next score (M[s+1], the I / D rows of the other parity) are not the rows a late wave still reads (M[s]).
+// The exchange words alternate with the parity of the score.  The backtrace is wave 0's; the others wait at the next ticket.
+template <int CAP, int QCAP, int NW>
+__global__ __launch_bounds__(NW * 64) void wfa_affine_adaptive_mw_kernel(
+    const uint8_t* __restrict__ arena, const otg_align_task* __restrict__ tasks,
+    const uint32_t* __restrict__ todo, const uint32_t* __restrict__ n_todo_ptr, uint32_t n_todo_imm, int g,
+    int32_t* __restrict__ scores, const uint64_t* __restrict__ cig_off, uint32_t* __restrict__ cig_len,
+    uint8_t* __restrict__ cig_arena, uint64_t* __restrict__ cells,
+    uint32_t* __restrict__ ticket, uint32_t* __restrict__ n_overflow, uint32_t* __restrict__ overflow_list,
+    AffWs ws, Heur H, int seqw)
+{
+  constexpr int xs = 2, oes = 4, es = 1, RM = 5, RI = 2;
+  constexpr int ROW_I = RM, ROW_D = RM + RI, ROW_NULL = RM + 2 * RI, ROW_SEED = ROW_NULL + 1, NROWS = ROW_SEED + 1;
+  constexpr int MASK = CAP - 1, NUL = -32768, PAD = 4, NT = NW * 64;
+  __shared__ __attribute__((aligned(16))) int16_t s_rows[NROWS][CAP];
+  __shared__ __attribute__((aligned(16))) uint32_t s_q[NW][QCAP];
+  __shared__ int s_x[2][NW][2];
+  __shared__ uint32_t s_tk;
+  __shared__ int s_bad;
+  extern __shared__ uint32_t s_dyn[];                         // [seqw]: the packed pair of the block's alignment
+  using lds_char = __attribute__((address_space(3))) char;
+  const int tid = threadIdx.x, lane = tid & 63;
+  auto U = [](int x) { return __builtin_amdgcn_readfirstlane(x); };
+  const int ww = U(tid >> 6);
+  uint8_t* my = ws.base + (size_t)blockIdx.x * ws.stride;
+  int64_t* rowtab = (int64_t*)(my + ws.off_rowtab);
+  uint8_t* rev = my + ws.off_rev;
+  uint8_t* slab = my + ws.off_slab;
+  volatile lds_char* ROWS = (volatile lds_char*)&s_rows[0][0];
+  volatile lds_u32* ROWS32 = (volatile lds_u32*)&s_rows[0][0];
+  volatile lds_u32* queue = (volatile lds_u32*)&s_q[ww][0];
+  volatile lds_u32* SQ = (volatile lds_u32*)s_dyn;
+  const uint32_t n_todo = n_todo_ptr ? *n_todo_ptr : n_todo_imm;
+  auto rd = [&](int row, int k) -> int { return *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + row * (CAP * 2) + ((k & MASK) << 1)); };
+  auto wr = [&](int row, int k, int v) { *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + row * (CAP * 2) + ((k & MASK) << 1)) = (int16_t)v; };
+  auto null_block = [&](int row, int a, int b) { for (int c = a + tid; c <= b; c += NT) wr(row, c, NUL); };          // all waves share the interval
+  auto null_wave = [&](int row, int a, int b) { for (int c = a + lane; c <= b; c += 64) wr(row, c, NUL); };          // every wave nulls all of it
+
+  for (;;) {
+    __syncthreads();                      // the previous alignment is over for every wave (wave 0 staged its backtrace in the rows)
+    if (tid == 0) { s_tk = atomicAdd(ticket, 1u); s_bad = 0; }
+    __syncthreads();
+    const uint32_t tk = (uint32_t)U((int)s_tk);
+    if (tk >= n_todo) break;
+    const uint32_t ti = todo ? todo[tk] : tk;
+    const otg_align_task t = tasks[ti];
+    const uint8_t* P = arena + t.pattern_off;
+    const uint8_t* T = arena + t.text_off;
+    const int pl = (int)t.pattern_len, tl = (int)t.text_len;
+    const bool ef = t.endsfree != 0;
+    const int pef = ef ? t.pattern_end_free : 0, tef = ef ? t.text_end_free : 0;
+    const int kend = tl - pl;
+    int s_end = -1, k_end = 0;
+    uint64_t W = 0;
+    const int offT = (pl + 15) / 16 + 3;
+    bool fail = pl + tl >= 32766 || offT + (tl + 15) / 16 + 3 > seqw;
+    const int lo0 = ef ? imax(-t.pattern_begin_free, -pl) : 0, hi0 = ef ? imin(t.text_begin_free, tl) : 0;
+    if (hi0 - lo0 + PAD > CAP) fail = true;
+    if (!fail) {
+      // the pair, packed by the whole block (PackedPair::init, one word per thread and round)
+      bool bad = false;
+      auto pack = [&](const uint8_t* S, int len, int woff) {
+        for (int q = tid; q < (len + 15) / 16 + 3; q += NT) {
+          uint32_t w = 0;
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int b0 = 16 * q + 8 * j;
+            const uint64_t x = b0 < len ? otg_load8(S + b0) : 0ull;
+#pragma unroll
+            for (int t2 = 0; t2 < 8; ++t2) {
+              const uint32_t c = (uint32_t)(x >> (8 * t2)) & 0xffu;
+              const uint32_t code = (c >> 1) & 3u;
+              if (b0 + t2 < len && c != ((0x47544341u >> (8 * code)) & 0xffu)) bad = true;
+              w |= code << (2 * (8 * j + t2));
+            }
+          }
+          SQ[woff + q] = w;
+        }
+      };
+      pack(P, pl, 0);
+      pack(T, tl, offT);
+      if (__ballot(bad) != 0ull && lane == 0) s_bad = 1;
+      for (int q = tid; q < NROWS * CAP / 2; q += NT) ROWS32[q] = 0x80008000u;
+    }
+    __syncthreads();
+    if (!fail) {
+      fail = U(s_bad) != 0;
+      if (!fail) for (int k = lo0 + tid; k <= hi0; k += NT) wr(ROW_SEED, k, (k > 0 ? k : 0) - 1);
+    }
+    __syncthreads();
+    const PackedPair pk{SQ, offT, true};
+    const int offT4 = offT * 4;
+    const volatile lds_char* SQB = (const volatile lds_char*)SQ;
+    size_t slab_top = 0;
+    int steps_wait = 0;
+    int r1lo = 1, r1hi = 0, r2lo = 1, r2hi = 0, r3lo = 1, r3hi = 0, r4lo = 1, r4hi = 0, r5lo = 1, r5hi = 0, i1lo = 1, i1hi = 0, i2lo = 1, i2hi = 0;
+    int sm = RM - 1, si = 1;
+    for (int s = 0; !fail; ++s) {
+      if (s >= ws.nrows) { fail = true; break; }
+      sm = sm + 1 == RM ? 0 : sm + 1; si ^= 1;
+      int lo, hi;
+      int qx = ROW_NULL, qo = ROW_NULL, qi = ROW_NULL, qd = ROW_NULL;
+      if (s == 0) { lo = lo0; hi = hi0; qx = ROW_SEED; }
+      else {
+        lo = 1 << 30; hi = -(1 << 30);
+        if (r2hi >= r2lo) { lo = imin(lo, r2lo); hi = imax(hi, r2hi); qx = sm >= xs ? sm - xs : sm - xs + RM; }
+        if (r4hi >= r4lo) { lo = imin(lo, r4lo - 1); hi = imax(hi, r4hi + 1); qo = sm >= oes ? sm - oes : sm - oes + RM; }
+        if (i1hi >= i1lo) { lo = imin(lo, i1lo - 1); hi = imax(hi, i1hi + 1); qi = ROW_I + (si ^ 1); qd = ROW_D + (si ^ 1); }
+        if (lo < -pl) lo = -pl;
+        if (hi > tl) hi = tl;
+      }
+      lo = U(lo); hi = U(hi);
+      const int omlo = r5lo, omhi = r5hi, oilo = i2lo, oihi = i2hi;
+      r5lo = r4lo; r5hi = r4hi; r4lo = r3lo; r4hi = r3hi; r3lo = r2lo; r3hi = r2hi; r2lo = r1lo; r2hi = r1hi; i2lo = i1lo; i2hi = i1hi;
+      if (hi < lo) {       // unreachable score
+        null_block(sm, omlo, omhi); null_block(ROW_I + si, oilo, oihi); null_block(ROW_D + si, oilo, oihi);
+        r1lo = 1; r1hi = 0; i1lo = 1; i1hi = 0;
+        if (tid == 0) rowtab[s] = -1;
+        if (s > 2 * (oes + es * (pl + tl)) + 8) fail = true;
+        __syncthreads();
+        continue;
+      }
+      const int width = hi - lo + 1, padded = ((width + 63) >> 6) << 6;
+      if (width + PAD > CAP || slab_top + (size_t)padded > ws.slab_bytes) { fail = true; break; }
+      null_block(sm, omlo, imin(omhi, lo - 1)); null_block(sm, imax(omlo, hi + 1), omhi);
+      null_block(ROW_I + si, oilo, imin(oihi, lo - 1)); null_block(ROW_I + si, imax(oilo, hi + 1), oihi);
+      null_block(ROW_D + si, oilo, imin(oihi, lo - 1)); null_block(ROW_D + si, imax(oilo, hi + 1), oihi);
+      uint8_t* btrow = slab + slab_top - lo;
+      if (tid == 0) rowtab[s] = (int64_t)slab_top - lo;
+      slab_top += (size_t)padded;
+      W += 3ull * (uint64_t)width;
+      int dmin = BIG, kfin = BIG;
+      int qn = 0;
+      auto finished = [&](int h, int k) {
+        dmin = imin(dmin, left_to_align(h, k, pl, tl, ef, pef, tef));
+        if (ef) { const int v = h - k; if ((h >= tl && pl - v <= pef) || (v >= pl && tl - h <= tef)) kfin = imin(kfin, k); }
+        else if (k == kend && h >= tl) kfin = k;
+      };
+      auto drain = [&]() {
+        int pass = 0;
+        while (qn > 0) {
+          if (qn <= 4 && pass > 0) {
+            for (int e = 0; e < qn; ++e) {
+              const int kk = lo + U((int)queue[e]);
+              int h = U(rd(sm, kk));
+              const int v = h - kk;
+              h += otg_wave_match(P, T, v, h, imin(pl - v, tl - h), lane);
+              wr(sm, kk, h);
+              finished(h, kk);
+            }
+            qn = 0;
+            break;
+          }
+          int wq = 0;
+          for (int q0 = 0; q0 < qn; q0 += 64) {
+            const bool act = q0 + lane < qn;
+            int kk = 0, h = 0, v = 0;
+            bool more = false;
+            if (act) {
+              kk = lo + (int)queue[q0 + lane];
+              h = rd(sm, kk);
+              v = h - kk;
+              const int m = pk.match32(v, h, imin(pl - v, tl - h));
+              v += m; h += m;
+              more = (m == 32) && v < pl && h < tl;
+              wr(sm, kk, h);
+              if (!more) finished(h, kk);
+            }
+            const unsigned long long mm = __ballot(more);
+            if (more) {
+              const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+              queue[wq + rank] = (uint32_t)(kk - lo);
+            }
+            wq += __builtin_popcountll(mm);
+          }
+          qn = wq; ++pass;
+        }
+      };
+      // ---- sweep of this wave's chunks (branch-free per lane, as in the one-wave tier)
+      const int bx = qx * (CAP * 2), bo = qo * (CAP * 2), bi = qi * (CAP * 2), bd = qd * (CAP * 2);
+      const int bm = sm * (CAP * 2), bI = (ROW_I + si) * (CAP * 2), bD = (ROW_D + si) * (CAP * 2);
+      for (int c = lo + 64 * ww; c <= hi; c += 64 * NW) {
+        const int k = c + lane;
+        const int a0 = (k & MASK) << 1, am = ((k - 1) & MASK) << 1, ap = ((k + 1) & MASK) << 1;
+        const int io = *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + bo + am), dop = *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + bo + ap);
+        const int ix = *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + bi + am), dx = *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + bd + ap);
+        const int mm = *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + bx + a0);
+        const bool ext_i = ix >= io, ext_d = dx >= dop;
+        const int insv = imax(ix, io) + 1, delv = imax(dx, dop), mis = mm + 1;
+        const int mx = imax(imax(delv, mis), insv);
+        const uint32_t org = mx == mis ? 0u : (mx == delv ? 1u : 2u);      // mismatch wins ties over deletion over insertion
+        const uint32_t bits = org | (ext_i ? 4u : 0u) | (ext_d ? 8u : 0u);
+        const bool inr = k <= hi;
+        const int v = mx - k;
+        const int t1 = tl - mx, t2 = pl - v;
+        const bool valid = inr && (uint32_t)mx <= (uint32_t)tl && (uint32_t)v <= (uint32_t)pl;
+        int pm;
+        {
+          const int wp = (v >> 2) & ~3, wt = offT4 + ((mx >> 2) & ~3);
+          const uint32_t sp = (uint32_t)(v & 15) * 2u, st = (uint32_t)(mx & 15) * 2u;
+          const volatile lds_u32* pp = (const volatile lds_u32*)(SQB + wp);
+          const volatile lds_u32* pt = (const volatile lds_u32*)(SQB + wt);
+          const uint32_t p0 = pp[0], p1 = pp[1], p2 = pp[2], q0 = pt[0], q1 = pt[1], q2 = pt[2];
+          const uint32_t xl = __builtin_amdgcn_alignbit(p1, p0, sp) ^ __builtin_amdgcn_alignbit(q1, q0, st);
+          const uint32_t xh = __builtin_amdgcn_alignbit(p2, p1, sp) ^ __builtin_amdgcn_alignbit(q2, q1, st);
+          uint32_t flo, fhi;
+          asm("v_ffbl_b32 %0, %1" : "=v"(flo) : "v"(xl));
+          asm("v_ffbl_b32 %0, %1" : "=v"(fhi) : "v"(xh));
+          const uint32_t a = flo < (fhi | 32u) ? flo : (fhi | 32u);
+          pm = (int)((a < 64u ? a : 64u) >> 1);
+        }
+        const int m = imin(imin(pm, t1), t2);
+        const bool more = valid && imin(imin(pm, t1 - 1), t2 - 1) == 32;
+        const int h2 = mx + m;
+        if (inr) {            // lanes behind the range do not store: the window is usable up to CAP - 4 diagonals
+          *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + bm + a0) = (int16_t)(valid ? h2 : NUL);
+          *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + bI + a0) = (int16_t)(insv >= 0 ? insv : NUL);
+          *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + bD + a0) = (int16_t)(delv >= 0 ? delv : NUL);
+        }
+        btrow[k] = (uint8_t)bits;                                        // every lane stores: the row is padded to whole chunks
+        const bool here = valid && !more;
+        const int lh = t1 - m, lv = t2 - m;
+        int d;
+        bool fin;
+        if (!ef) { d = imax(lh, lv); fin = here && k == kend && lh <= 0; }
+        else { d = imin(imax(lh, lv - pef), imax(lv, lh - tef)); fin = here && ((lh <= 0 && lv <= pef) || (lv <= 0 && lh <= tef)); }
+        kfin = imin(kfin, fin ? k : BIG);
+        dmin = imin(dmin, here ? d : BIG);
+        const unsigned long long mq = __ballot(more);
+        if (mq) {
+          if (more) {
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mq, 0u));
+            queue[qn + rank] = (uint32_t)(k - lo);
+          }
+          qn += __builtin_popcountll(mq);
+          if (qn + 64 > QCAP) drain();
+        }
+      }
+      if (qn) drain();
+      // ---- the one barrier of the score: every wave's chunks are final, the block's minimum and end candidate follow from the NW pairs
+      {
+        const int wd = wave_min_i32(dmin), wk = wave_min_i32(kfin);
+        if (lane == 0) { s_x[s & 1][ww][0] = wd; s_x[s & 1][ww][1] = wk; }
+      }
+      __syncthreads();
+      int mind = BIG, kf = BIG;
+#pragma unroll
+      for (int w2 = 0; w2 < NW; ++w2) { mind = imin(mind, U(s_x[s & 1][w2][0])); kf = imin(kf, U(s_x[s & 1][w2][1])); }
+      if (kf != BIG) { k_end = kf; s_end = s; break; }
+      // the cut: computed by every wave (same inputs, same result), what it drops nulled by every wave
+      int clo = lo, chi = hi;
+      wfadaptive_cut32(H, steps_wait, mind, pl, tl, ef, pef, tef, clo, chi, lane, [&](int k) { const int x = rd(sm, k); return x < 0 ? OTG_NULL_OFF : x; });
+      clo = U(clo); chi = U(chi);
+      if (clo > lo || chi < hi) {
+        null_wave(sm, lo, clo - 1); null_wave(sm, chi + 1, hi);
+        null_wave(ROW_I + si, lo, clo - 1); null_wave(ROW_I + si, chi + 1, hi);
+        null_wave(ROW_D + si, lo, clo - 1); null_wave(ROW_D + si, chi + 1, hi);
+      }
+      r1lo = clo; r1hi = chi;
+      if (s == 0) { i1lo = 1; i1hi = 0; }
+      else { i1lo = clo; i1hi = chi; }
+    }
+    __syncthreads();                      // provenance rows and the row table: written by all waves / thread 0, read back by wave 0
+    if (ww != 0) continue;
+    if (fail || s_end < 0) {
+      if (overflow_list) { const uint32_t q = otg_wave_atomic_add(n_overflow, 1u); overflow_list[q] = ti; }
+      else { scores[ti] = -1; cig_len[ti] = 0; }
+      continue;
+    }
+    if (!backtrace_unpack<false>(P, pl, T, tl, s_end, k_end, xs, oes, es, rowtab, slab, rev, ws.rev_cap, cig_arena + cig_off[ti], lane, &scores[ti], &cig_len[ti], g,
+                                 (volatile lds_u32*)&s_rows[0][0], EqPacked{SQ, offT})) continue;
     if (cells) cells[ti] = W;
   }
 }
@@ -1197,12 +1485,14 @@ int otg_launch_affine_adaptive_todo(otg_ctx* ctx, const uint8_t* d_arena, const 
   uint32_t* cnt = (uint32_t*)otg_slot(ctx, SLOT_COUNTERS, 128 * sizeof(uint32_t));
   uint32_t* lists = (uint32_t*)otg_slot(ctx, SLOT_TODO, 2 * (size_t)n_tasks * sizeof(uint32_t));
   if (!cnt || !lists) return OTG_ERR_HIP;
-  uint32_t* c = cnt + 120;                    // c[0..2] tickets, c[3..4] lengths of the overflow lists
-  HIP_TRY(ctx, hipMemsetAsync(c, 0, 8 * sizeof(uint32_t), ctx->stream));
+  uint32_t* c = cnt + 120;                    // c[0..2] tickets, c[3..4] lengths of the overflow lists, c[6..7] the byte tier's pair, c[-2..-1] the 4096 window's
+  HIP_TRY(ctx, hipMemsetAsync(c - 2, 0, 10 * sizeof(uint32_t), ctx->stream));
   const Heur H{ctx->heur_min_wf_len, ctx->heur_max_dist, ctx->heur_steps < 1 ? 1 : ctx->heur_steps};
   const uint32_t ncu = (uint32_t)ctx->n_cu;
   const size_t maxlen = ((size_t)ctx->max_seq_len + 4095) & ~(size_t)4095;
-  static const int only = getenv("OTG_ADAPTIVE_AFFINE_TIERS") ? atoi(getenv("OTG_ADAPTIVE_AFFINE_TIERS")) : 7;      // bit t = tier t runs (packed 256, packed 1024, bytes 1024); the int32 tier always does
+  // bit t = tier t runs: 1 packed 256, 2 packed 1024, 4 bytes 1024, 8 packed 4096; 16 = the 1024 window as ONE wave per alignment (the tier as first
+  // built) instead of four; the int32 tier always runs
+  static const int only = getenv("OTG_ADAPTIVE_AFFINE_TIERS") ? atoi(getenv("OTG_ADAPTIVE_AFFINE_TIERS")) : 15;
 
   AffWs ws;
   ws.capa = (int)(2 * maxlen + 16) & ~1;
@@ -1227,10 +1517,13 @@ int otg_launch_affine_adaptive_todo(otg_ctx* ctx, const uint8_t* d_arena, const 
   // (gcd units): 40 x maxlen bytes hold the typical alignment of the first tier four times over; the second tier gets 16 x that.
   AffWs w0 = lds_ws(std::max<size_t>((size_t)160 * maxlen, (size_t)1 << 19));
   AffWs w1 = lds_ws(std::max<size_t>((size_t)2560 * maxlen, (size_t)1 << 23));
+  AffWs w3 = lds_ws(std::max<size_t>((size_t)8192 * maxlen, (size_t)1 << 25));       // the 4096-diagonal window: a block per CU (90 KB of rows)
   // blocks per CU by LDS: rows 9 x CAP x 2 B + queue + range tables + the packed pair
   const uint32_t pc0 = std::max<uint32_t>(1, std::min<uint32_t>(6, (uint32_t)((160 * 1024) / (WPB0 * (11 * 256 * 2 + 1024 + 64 + (size_t)seqw * 4)))));
   const uint32_t pc1 = std::max<uint32_t>(1, std::min<uint32_t>(8, (uint32_t)((160 * 1024) / (WPB1 * (11 * 1024 * 2 + 4096 + 64 + (size_t)seqw * 4)))));
+  constexpr int NW1 = 4, NW3 = 8, QMW = 256;
   uint32_t grid0 = std::min<uint32_t>(ncu * pc0, (n_tasks + WPB0 - 1) / WPB0), grid1 = std::min<uint32_t>(ncu * pc1, n_tasks), grid2 = 8;
+  uint32_t grid3 = std::min<uint32_t>(ncu, n_tasks);
   AffWs w2 = ws;
   {
     const size_t ring_bytes = (size_t)(ws.rm + 2 * ws.ri) * ws.capa * sizeof(int32_t);
@@ -1245,14 +1538,15 @@ int otg_launch_affine_adaptive_todo(otg_ctx* ctx, const uint8_t* d_arena, const 
     const size_t budget = std::min<size_t>((size_t)(total_b * 0.15), (size_t)((free_b + ctx->pool[SLOT_WF_WS].cap) * 0.8));
     while (grid1 > 8 && w1.stride * grid1 * WPB1 > budget / 2) grid1 /= 2;
     while (grid0 > 8 && w0.stride * grid0 * WPB0 > budget / 2) grid0 /= 2;
+    while (grid3 > 8 && w3.stride * grid3 > budget / 2) grid3 /= 2;
     // the generic tier: the worst case of the longest pair of the batch (every diagonal at every score), as far as the budget goes
     size_t slab2 = std::min<size_t>((size_t)2 * maxlen * (size_t)ws.nrows, budget / (grid2 * WPB2));
     if (slab2 > w2.off_slab + 256) slab2 -= w2.off_slab + 256;
     w2.slab_bytes = slab2 & ~(size_t)255; w2.stride = w2.off_slab + w2.slab_bytes;
-    const size_t need = std::max(std::max(w0.stride * grid0 * WPB0, w1.stride * grid1 * WPB1), w2.stride * (size_t)grid2 * WPB2);
+    const size_t need = std::max(std::max(std::max(w0.stride * grid0 * WPB0, w1.stride * grid1 * WPB1), w2.stride * (size_t)grid2 * WPB2), w3.stride * grid3);
     uint8_t* wsp = (uint8_t*)otg_slot(ctx, SLOT_WF_WS, need);
     if (!wsp) return OTG_ERR_HIP;
-    w0.base = w1.base = w2.base = wsp;
+    w0.base = w1.base = w2.base = w3.base = wsp;
   }
   if (kernel_ms) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   const uint32_t* in = d_todo; const uint32_t* in_n = d_n_todo; uint32_t in_imm = n_tasks;
@@ -1263,15 +1557,25 @@ int otg_launch_affine_adaptive_todo(otg_ctx* ctx, const uint8_t* d_arena, const 
                        g, d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, c + 0, c + 3, l0, w0, H, seqw);
     in = l0; in_n = c + 3; in_imm = 0;
   }
-  if ((only & 2) && std_pen) {      // fast tier, 1024 diagonals
-    hipLaunchKernelGGL((wfa_affine_adaptive_lds_kernel<1024, 1024, WPB1, false>), dim3(grid1), dim3(WPB1 * 64), (size_t)WPB1 * seqw * 4, ctx->stream, d_arena, d_tasks, in, in_n, in_imm,
-                       g, d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, c + 1, c + 4, l1, w1, H, seqw);
+  if ((only & 2) && std_pen) {      // 1024 diagonals, four waves per alignment (bit 16: one)
+    if (only & 16)
+      hipLaunchKernelGGL((wfa_affine_adaptive_lds_kernel<1024, 1024, WPB1, false>), dim3(grid1), dim3(WPB1 * 64), (size_t)WPB1 * seqw * 4, ctx->stream, d_arena, d_tasks, in, in_n, in_imm,
+                         g, d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, c + 1, c + 4, l1, w1, H, seqw);
+    else
+      hipLaunchKernelGGL((wfa_affine_adaptive_mw_kernel<1024, QMW, NW1>), dim3(grid1), dim3(NW1 * 64), (size_t)seqw * 4, ctx->stream, d_arena, d_tasks, in, in_n, in_imm,
+                         g, d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, c + 1, c + 4, l1, w1, H, seqw);
     in = l1; in_n = c + 4; in_imm = 0;
+  }
+  if ((only & 8) && std_pen) {      // 4096 diagonals, eight waves per alignment, one block per CU
+    uint32_t* lout = in == l0 ? l1 : l0;
+    hipLaunchKernelGGL((wfa_affine_adaptive_mw_kernel<4096, QMW, NW3>), dim3(grid3), dim3(NW3 * 64), (size_t)seqw * 4, ctx->stream, d_arena, d_tasks, in, in_n, in_imm,
+                       g, d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, c - 2, c - 1, lout, w3, H, seqw);
+    in = lout; in_n = c - 1; in_imm = 0;
   }
   if ((only & 4) && std_pen) {      // byte probes, 1024 diagonals: pairs with bytes outside ACGT or too long to pack
     hipLaunchKernelGGL((wfa_affine_adaptive_kernel<1024, 1024, WPB1, 8>), dim3(grid1), dim3(WPB1 * 64), 0, ctx->stream, d_arena, d_tasks, in, in_n, in_imm,
-                       xs, oes, es, g, d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, c + 6, c + 7, l0, w1, H, 0);
-    in = l0; in_n = c + 7; in_imm = 0;
+                       xs, oes, es, g, d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, c + 6, c + 7, in == l0 ? l1 : l0, w1, H, 0);
+    in = in == l0 ? l1 : l0; in_n = c + 7; in_imm = 0;
   }
   hipLaunchKernelGGL((wfa_affine_adaptive_kernel<0, 2048, WPB2, 64>), dim3(grid2), dim3(WPB2 * 64), 0, ctx->stream, d_arena, d_tasks, in, in_n, in_imm,
                      xs, oes, es, g, d_scores, d_cig_off, d_cig_len, d_cig_arena, d_cells, c + 2, c + 5, (uint32_t*)nullptr, w2, H, 0);
@@ -1279,10 +1583,10 @@ int otg_launch_affine_adaptive_todo(otg_ctx* ctx, const uint8_t* d_arena, const 
   HIP_TRY(ctx, hipGetLastError());
   if (getenv("OTG_DEBUG")) {
     hipError_t er = hipStreamSynchronize(ctx->stream);
-    uint32_t h[8];
-    (void)hipMemcpy(h, c, sizeof(h), hipMemcpyDeviceToHost);
-    fprintf(stderr, "[otg] affine, wfadaptive(%d,%d,%d): %s; the 256-diagonal window passes on %u alignments, the 1024 one %u; %u / %u alignments in flight, %.2f / %.2f MB each\n",
-            H.min_wf_len, H.max_dist, H.steps, hipGetErrorString(er), h[3], h[4], grid0 * WPB0, grid1 * WPB1, (double)w0.stride / 1e6, (double)w1.stride / 1e6);
+    uint32_t h[10];
+    (void)hipMemcpy(h, c - 2, sizeof(h), hipMemcpyDeviceToHost);
+    fprintf(stderr, "[otg] affine, wfadaptive(%d,%d,%d): %s; the 256-diagonal window passes on %u alignments, the 1024 one %u, the 4096 one %u, the byte probes %u; %u / %u / %u alignments in flight, %.2f / %.2f / %.2f MB each\n",
+            H.min_wf_len, H.max_dist, H.steps, hipGetErrorString(er), h[5], h[6], h[1], h[9], grid0 * WPB0, grid1 * WPB1, grid3, (double)w0.stride / 1e6, (double)w1.stride / 1e6, (double)w3.stride / 1e6);
   }
   if (kernel_ms) {
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));

@@ -1,5 +1,6 @@
 """One-off differential check at config-1 shapes: the HIP pipeline vs the CPU oracle (multi-threaded over regions) on
-N regions per case; prints one line per case.  Heavier than the -m gpu tests (the oracle runs ~0.3 regions/s/thread)."""
+N regions per case; prints one line per case.  Heavier than the -m gpu tests (the oracle runs ~0.3 regions/s/thread).
+usage: python scripts/diff_check.py [regions per case] [seed offset] [none | wfadaptive[:min_wf_len,max_dist,steps]]"""
 import os, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -13,15 +14,22 @@ oracle_lib.lib()
 ctx = otter_amd.Context(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 96
 seed_off = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+heur = sys.argv[3] if len(sys.argv) > 3 else "none"
+hkw = {}
+if heur.startswith("wfadaptive"):
+    a, b, c = (int(x) for x in heur.split(":")[1].split(",")) if ":" in heur else (10, 50, 1)
+    hkw = dict(heuristic=abi.OTG_HEURISTIC_WFADAPTIVE, heur_min_wavefront_length=a, heur_max_distance_threshold=b, heur_steps_between_cutoffs=c)
 cases = [dict(len_range=(1000, 5000), n_reads=30, err="ont", seed=101),
          dict(len_range=(1000, 5000), n_reads=30, err="ont", seed=102, realign=True),
          dict(len_range=(3000, 9000), n_reads=16, err="ont", seed=103),
-         dict(len_range=(300, 1500), n_reads=40, err="hifi", seed=104)]
+         dict(len_range=(300, 1500), n_reads=40, err="hifi", seed=104),
+         dict(len_range=(1000, 10000), n_reads=30, err="ont", seed=105),
+         dict(len_range=(100, 800), n_reads=60, err="ont", seed=106, realign=True)]
 nth = min(16, os.cpu_count() or 1)
 for c in cases:
     kw = dict(c); realign = kw.pop("realign", False); kw["seed"] += seed_off
     batch = synth.make_batch(n, realign=realign, **kw)
-    P = abi.default_params(realign=1 if realign else 0)
+    P = abi.default_params(realign=1 if realign else 0, **hkw)
     t0 = time.time()
     res = ctx.assemble(P, batch)
     tg = time.time() - t0
