@@ -888,6 +888,44 @@ __global__ __launch_bounds__(WPB * 64) void wfa_affine_adaptive_lds_kernel(
   auto wr = [&](int row, int k, int v) { *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + row * (CAP * 2) + ((k & MASK) << 1)) = (int16_t)v; };
   // nulls the diagonals [a, b] of a row (a no-op for an empty interval)
   auto null_range = [&](int row, int a, int b) { for (int c = a; c <= b; c += 64) if (c + lane <= b) wr(row, c + lane, NUL); };
+  // The nulling of a score in ONE pass each.  Ranges move by a few diagonals per score, so what a take-over or a cut has to null is four (two)
+  // intervals a few diagonals wide; as six loops per event they were half of the kernel's scalar instructions (and the scalar unit, shared by the
+  // four SIMDs of a CU, was its busiest resource).  null_quarters: lanes 16 q .. 16 q + 15 take interval q — intervals 0 and 1 of row rA, 2 and 3
+  // of rows rB AND rC; null_halves: lanes 0-31 / 32-63 take the two intervals of three rows.  Wider intervals fall back to the loops.
+  const int lq = lane >> 4, lj = lane & 15;
+  auto null_quarters = [&](int rA, int a0, int b0, int a1, int b1, int rB, int rC, int a2, int b2, int a3, int b3) {
+    const int n0 = b0 - a0 + 1, n1 = b1 - a1 + 1, n2 = b2 - a2 + 1, n3 = b3 - a3 + 1;
+    const int nmax = imax(imax(n0, n1), imax(n2, n3));
+    if (nmax <= 0) return;
+    if (nmax > 16) {
+      null_range(rA, a0, b0); null_range(rA, a1, b1);
+      null_range(rB, a2, b2); null_range(rB, a3, b3); null_range(rC, a2, b2); null_range(rC, a3, b3);
+      return;
+    }
+    const int a = lq < 2 ? (lq == 0 ? a0 : a1) : (lq == 2 ? a2 : a3);
+    const int n = lq < 2 ? (lq == 0 ? n0 : n1) : (lq == 2 ? n2 : n3);
+    if (lj < n) {
+      const int ad = ((a + lj) & MASK) << 1;
+      *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + (lq < 2 ? rA : rB) * (CAP * 2) + ad) = (int16_t)NUL;
+      if (lq >= 2) *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + rC * (CAP * 2) + ad) = (int16_t)NUL;
+    }
+  };
+  auto null_halves = [&](int r0, int r1, int r2, int a0, int b0, int a1, int b1) {
+    const int n0 = b0 - a0 + 1, n1 = b1 - a1 + 1;
+    if (imax(n0, n1) <= 0) return;
+    if (imax(n0, n1) > 32) {
+      null_range(r0, a0, b0); null_range(r0, a1, b1); null_range(r1, a0, b0); null_range(r1, a1, b1); null_range(r2, a0, b0); null_range(r2, a1, b1);
+      return;
+    }
+    const bool low = lane < 32;
+    const int a = low ? a0 : a1, n = low ? n0 : n1, jj = lane & 31;
+    if (jj < n) {
+      const int ad = ((a + jj) & MASK) << 1;
+      *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + r0 * (CAP * 2) + ad) = (int16_t)NUL;
+      *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + r1 * (CAP * 2) + ad) = (int16_t)NUL;
+      *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + r2 * (CAP * 2) + ad) = (int16_t)NUL;
+    }
+  };
 
   for (;;) {
     const uint32_t tk = otg_wave_atomic_add(ticket, 1u);
@@ -941,7 +979,7 @@ __global__ __launch_bounds__(WPB * 64) void wfa_affine_adaptive_lds_kernel(
       const int omlo = r5lo, omhi = r5hi, oilo = i2lo, oihi = i2hi;
       r5lo = r4lo; r5hi = r4hi; r4lo = r3lo; r4hi = r3hi; r3lo = r2lo; r3hi = r2hi; r2lo = r1lo; r2hi = r1hi; i2lo = i1lo; i2hi = i1hi;
       if (hi < lo) {       // null wavefront: this score is not reachable (the reference skips the heuristic too)
-        null_range(sm, omlo, omhi); null_range(ROW_I + si, oilo, oihi); null_range(ROW_D + si, oilo, oihi);
+        null_quarters(sm, omlo, omhi, 1, 0, ROW_I + si, ROW_D + si, oilo, oihi, 1, 0);
         r1lo = 1; r1hi = 0; i1lo = 1; i1hi = 0;
         rowtab[s] = -1;
         if (s > 2 * (oes + es * (pl + tl)) + 8) fail = true;
@@ -949,9 +987,7 @@ __global__ __launch_bounds__(WPB * 64) void wfa_affine_adaptive_lds_kernel(
       }
       const int width = hi - lo + 1, padded = ((width + 63) >> 6) << 6;
       if (width + PAD > CAP || slab_top + (size_t)padded > ws.slab_bytes) { fail = true; break; }
-      null_range(sm, omlo, imin(omhi, lo - 1)); null_range(sm, imax(omlo, hi + 1), omhi);
-      null_range(ROW_I + si, oilo, imin(oihi, lo - 1)); null_range(ROW_I + si, imax(oilo, hi + 1), oihi);
-      null_range(ROW_D + si, oilo, imin(oihi, lo - 1)); null_range(ROW_D + si, imax(oilo, hi + 1), oihi);
+      null_quarters(sm, omlo, imin(omhi, lo - 1), imax(omlo, hi + 1), omhi, ROW_I + si, ROW_D + si, oilo, imin(oihi, lo - 1), imax(oilo, hi + 1), oihi);
       uint8_t* btrow = slab + slab_top - lo;     // btrow[k]; the row is padded to whole chunks
       rowtab[s] = (int64_t)slab_top - lo;        // wave-uniform store
       slab_top += (size_t)padded;
@@ -1070,11 +1106,7 @@ __global__ __launch_bounds__(WPB * 64) void wfa_affine_adaptive_lds_kernel(
       int clo = lo, chi = hi;
       const int mind = wave_min_i32(dmin);
       wfadaptive_cut32(H, steps_wait, mind, pl, tl, ef, pef, tef, clo, chi, lane, [&](int k) { const int x = rd(sm, k); return x < 0 ? OTG_NULL_OFF : x; });
-      if (clo > lo || chi < hi) {
-        null_range(sm, lo, clo - 1); null_range(sm, chi + 1, hi);
-        null_range(ROW_I + si, lo, clo - 1); null_range(ROW_I + si, chi + 1, hi);
-        null_range(ROW_D + si, lo, clo - 1); null_range(ROW_D + si, chi + 1, hi);
-      }
+      null_halves(sm, ROW_I + si, ROW_D + si, lo, clo - 1, chi + 1, hi);
       r1lo = clo; r1hi = chi;
       if (s == 0) { i1lo = 1; i1hi = 0; }       // no I / D wavefront at score 0 (its sweep stored nulls: both came from the null row)
       else { i1lo = clo; i1hi = chi; }
@@ -1099,7 +1131,7 @@ __global__ __launch_bounds__(WPB * 64) void wfa_affine_adaptive_lds_kernel(
 // of the block (chunk j to wave j mod NW); everything else of a score is REPLICATED: every wave keeps the ranges, the row indices, the slab
 // cursor and the cut's step counter in its own scalar registers and computes the same values from the same inputs, so a score needs one barrier:
 //
-//   take-over nulling (block-wide, disjoint from what the sweep stores)  ->  sweep of the own chunks, own queue, own drain  ->  own minimum of
+//   take-over nulling (wave 0; disjoint from what the sweep stores)  ->  sweep of the own chunks, own queue, own drain  ->  own minimum of
 //   "left to align" and own end candidate to LDS  ->  BARRIER  ->  every wave reduces the NW pairs, every wave computes the cut from the M row
 //   and nulls what it drops.
 //
@@ -1140,8 +1172,46 @@ __global__ __launch_bounds__(NW * 64) void wfa_affine_adaptive_mw_kernel(
   const uint32_t n_todo = n_todo_ptr ? *n_todo_ptr : n_todo_imm;
   auto rd = [&](int row, int k) -> int { return *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + row * (CAP * 2) + ((k & MASK) << 1)); };
   auto wr = [&](int row, int k, int v) { *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + row * (CAP * 2) + ((k & MASK) << 1)) = (int16_t)v; };
-  auto null_block = [&](int row, int a, int b) { for (int c = a + tid; c <= b; c += NT) wr(row, c, NUL); };          // all waves share the interval
-  auto null_wave = [&](int row, int a, int b) { for (int c = a + lane; c <= b; c += 64) wr(row, c, NUL); };          // every wave nulls all of it
+  // the barrier of a score orders LDS only: the provenance bytes and the row table (global memory) are read back after the forward pass, behind
+  // a full __syncthreads(); waiting for their acknowledgement at every score costs more than the score's sweep
+  auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  auto null_wave = [&](int row, int a, int b) { for (int c = a + lane; c <= b; c += 64) wr(row, c, NUL); };          // (this wave nulls all of it)
+  // one-pass nulling as in the one-wave tier: quarters of a wave for the four intervals of a take-over (wave 0's job: the rows taken over are next
+  // read behind this score's barrier), halves for the two intervals of a cut (every wave's job, see above)
+  const int lq = lane >> 4, lj = lane & 15;
+  auto null_quarters = [&](int rA, int a0, int b0, int a1, int b1, int rB, int rC, int a2, int b2, int a3, int b3) {
+    const int n0 = b0 - a0 + 1, n1 = b1 - a1 + 1, n2 = b2 - a2 + 1, n3 = b3 - a3 + 1;
+    const int nmax = imax(imax(n0, n1), imax(n2, n3));
+    if (nmax <= 0) return;
+    if (nmax > 16) {
+      null_wave(rA, a0, b0); null_wave(rA, a1, b1);
+      null_wave(rB, a2, b2); null_wave(rB, a3, b3); null_wave(rC, a2, b2); null_wave(rC, a3, b3);
+      return;
+    }
+    const int a = lq < 2 ? (lq == 0 ? a0 : a1) : (lq == 2 ? a2 : a3);
+    const int n = lq < 2 ? (lq == 0 ? n0 : n1) : (lq == 2 ? n2 : n3);
+    if (lj < n) {
+      const int ad = ((a + lj) & MASK) << 1;
+      *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + (lq < 2 ? rA : rB) * (CAP * 2) + ad) = (int16_t)NUL;
+      if (lq >= 2) *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + rC * (CAP * 2) + ad) = (int16_t)NUL;
+    }
+  };
+  auto null_halves = [&](int r0, int r1, int r2, int a0, int b0, int a1, int b1) {
+    const int n0 = b0 - a0 + 1, n1 = b1 - a1 + 1;
+    if (imax(n0, n1) <= 0) return;
+    if (imax(n0, n1) > 32) {
+      null_wave(r0, a0, b0); null_wave(r0, a1, b1); null_wave(r1, a0, b0); null_wave(r1, a1, b1); null_wave(r2, a0, b0); null_wave(r2, a1, b1);
+      return;
+    }
+    const bool low = lane < 32;
+    const int a = low ? a0 : a1, n = low ? n0 : n1, jj = lane & 31;
+    if (jj < n) {
+      const int ad = ((a + jj) & MASK) << 1;
+      *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + r0 * (CAP * 2) + ad) = (int16_t)NUL;
+      *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + r1 * (CAP * 2) + ad) = (int16_t)NUL;
+      *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + r2 * (CAP * 2) + ad) = (int16_t)NUL;
+    }
+  };
 
   for (;;) {
     __syncthreads();                      // the previous alignment is over for every wave (wave 0 staged its backtrace in the rows)
@@ -1220,18 +1290,16 @@ __global__ __launch_bounds__(NW * 64) void wfa_affine_adaptive_mw_kernel(
       const int omlo = r5lo, omhi = r5hi, oilo = i2lo, oihi = i2hi;
       r5lo = r4lo; r5hi = r4hi; r4lo = r3lo; r4hi = r3hi; r3lo = r2lo; r3hi = r2hi; r2lo = r1lo; r2hi = r1hi; i2lo = i1lo; i2hi = i1hi;
       if (hi < lo) {       // unreachable score
-        null_block(sm, omlo, omhi); null_block(ROW_I + si, oilo, oihi); null_block(ROW_D + si, oilo, oihi);
+        if (ww == 0) null_quarters(sm, omlo, omhi, 1, 0, ROW_I + si, ROW_D + si, oilo, oihi, 1, 0);
         r1lo = 1; r1hi = 0; i1lo = 1; i1hi = 0;
         if (tid == 0) rowtab[s] = -1;
         if (s > 2 * (oes + es * (pl + tl)) + 8) fail = true;
-        __syncthreads();
+        lds_barrier();
         continue;
       }
       const int width = hi - lo + 1, padded = ((width + 63) >> 6) << 6;
       if (width + PAD > CAP || slab_top + (size_t)padded > ws.slab_bytes) { fail = true; break; }
-      null_block(sm, omlo, imin(omhi, lo - 1)); null_block(sm, imax(omlo, hi + 1), omhi);
-      null_block(ROW_I + si, oilo, imin(oihi, lo - 1)); null_block(ROW_I + si, imax(oilo, hi + 1), oihi);
-      null_block(ROW_D + si, oilo, imin(oihi, lo - 1)); null_block(ROW_D + si, imax(oilo, hi + 1), oihi);
+      if (ww == 0) null_quarters(sm, omlo, imin(omhi, lo - 1), imax(omlo, hi + 1), omhi, ROW_I + si, ROW_D + si, oilo, imin(oihi, lo - 1), imax(oilo, hi + 1), oihi);
       uint8_t* btrow = slab + slab_top - lo;
       if (tid == 0) rowtab[s] = (int64_t)slab_top - lo;
       slab_top += (size_t)padded;
@@ -1349,7 +1417,7 @@ __global__ __launch_bounds__(NW * 64) void wfa_affine_adaptive_mw_kernel(
         const int wd = wave_min_i32(dmin), wk = wave_min_i32(kfin);
         if (lane == 0) { s_x[s & 1][ww][0] = wd; s_x[s & 1][ww][1] = wk; }
       }
-      __syncthreads();
+      lds_barrier();
       int mind = BIG, kf = BIG;
 #pragma unroll
       for (int w2 = 0; w2 < NW; ++w2) { mind = imin(mind, U(s_x[s & 1][w2][0])); kf = imin(kf, U(s_x[s & 1][w2][1])); }
@@ -1358,11 +1426,7 @@ __global__ __launch_bounds__(NW * 64) void wfa_affine_adaptive_mw_kernel(
       int clo = lo, chi = hi;
       wfadaptive_cut32(H, steps_wait, mind, pl, tl, ef, pef, tef, clo, chi, lane, [&](int k) { const int x = rd(sm, k); return x < 0 ? OTG_NULL_OFF : x; });
       clo = U(clo); chi = U(chi);
-      if (clo > lo || chi < hi) {
-        null_wave(sm, lo, clo - 1); null_wave(sm, chi + 1, hi);
-        null_wave(ROW_I + si, lo, clo - 1); null_wave(ROW_I + si, chi + 1, hi);
-        null_wave(ROW_D + si, lo, clo - 1); null_wave(ROW_D + si, chi + 1, hi);
-      }
+      null_halves(sm, ROW_I + si, ROW_D + si, lo, clo - 1, chi + 1, hi);
       r1lo = clo; r1hi = chi;
       if (s == 0) { i1lo = 1; i1hi = 0; }
       else { i1lo = clo; i1hi = chi; }
@@ -1514,13 +1578,15 @@ int otg_launch_affine_adaptive_todo(otg_ctx* ctx, const uint8_t* d_arena, const 
   constexpr int WPB0 = 4, WPB1 = 1, WPB2 = 4;
   const int seqw = (int)std::min<size_t>(2 * (((size_t)ctx->max_seq_len + 15) / 16 + 3) + 2, 8192);      // LDS words per wave for the packed pair
   // provenance: a row per score, as wide as the wavefront.  Mean width under the cut ~100 diagonals, scores ~0.4 per base
-  // (gcd units): 40 x maxlen bytes hold the typical alignment of the first tier four times over; the second tier gets 16 x that.
+  // (gcd units): 40 x maxlen bytes hold the typical alignment of the first tier four times over.
   AffWs w0 = lds_ws(std::max<size_t>((size_t)160 * maxlen, (size_t)1 << 19));
-  AffWs w1 = lds_ws(std::max<size_t>((size_t)2560 * maxlen, (size_t)1 << 23));
+  // (1024 window: 640 x maxlen = 5 MB for 5 kb reads — a wavefront of 400 diagonals over 2 000 scores takes 0.8 MB — so that LDS, not the budget, bounds the
+  // alignments in flight: 1 280 instead of 640 with the 2 560 x maxlen of the one-wave tier, gap-affine stage 211 -> 186 ms; what outgrows it has the 4096 tier behind it)
+  AffWs w1 = lds_ws(std::max<size_t>((size_t)640 * maxlen, (size_t)1 << 21));
   AffWs w3 = lds_ws(std::max<size_t>((size_t)8192 * maxlen, (size_t)1 << 25));       // the 4096-diagonal window: a block per CU (90 KB of rows)
   // blocks per CU by LDS: rows 9 x CAP x 2 B + queue + range tables + the packed pair
   const uint32_t pc0 = std::max<uint32_t>(1, std::min<uint32_t>(6, (uint32_t)((160 * 1024) / (WPB0 * (11 * 256 * 2 + 1024 + 64 + (size_t)seqw * 4)))));
-  const uint32_t pc1 = std::max<uint32_t>(1, std::min<uint32_t>(8, (uint32_t)((160 * 1024) / (WPB1 * (11 * 1024 * 2 + 4096 + 64 + (size_t)seqw * 4)))));
+  const uint32_t pc1 = std::max<uint32_t>(1, std::min<uint32_t>(8, (uint32_t)((160 * 1024) / (11 * 1024 * 2 + 4096 + 128 + (size_t)seqw * 4))));
   constexpr int NW1 = 4, NW3 = 8, QMW = 256;
   uint32_t grid0 = std::min<uint32_t>(ncu * pc0, (n_tasks + WPB0 - 1) / WPB0), grid1 = std::min<uint32_t>(ncu * pc1, n_tasks), grid2 = 8;
   uint32_t grid3 = std::min<uint32_t>(ncu, n_tasks);
