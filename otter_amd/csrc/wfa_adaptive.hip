@@ -38,6 +38,13 @@ struct Heur { int min_wf_len, max_dist, steps; };
 __device__ __forceinline__ int wave_min_i32(int v) { return -otg_wave_max_i32(-v); }      // |v| <= 2^30 here
 __device__ __forceinline__ int dpp_shr1(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x138, 0xf, 0xf, false); }   // lane i <- lane i-1
 
+// lane masks of comparisons (v_cmp into an SGPR pair; the logic on them runs on the scalar unit) and a select on a lane mask.  Written with bools,
+// hipcc 7.2 turns "does any lane ..." and "or into the flag" into a select, an and and a compare on the vector unit each (see wfa_affine_reg.hip)
+__device__ __forceinline__ unsigned long long mk_eq(int a, int b) { return __builtin_amdgcn_sicmp(a, b, 32); }
+__device__ __forceinline__ unsigned long long mk_sle(int a, int b) { return __builtin_amdgcn_sicmp(a, b, 41); }
+__device__ __forceinline__ unsigned long long mk_ule(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 37); }
+__device__ __forceinline__ int sel(unsigned long long m, int a, int b) { int r; asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m)); return r; }     // lane in m ? a : b
+
 // what is left to align from offset h of diagonal k (the distance the cut compares)
 __device__ __forceinline__ int left_to_align(int h, int k, int pl, int tl, bool ef, int pef, int tef)
 {
@@ -439,12 +446,14 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_adaptive_lds_kernel(
       W += (uint64_t)(hi - lo + 1);
       int carry = NUL;
       int dmin = BIG;
-      bool fin_l = false;
+      // "some cell ends the alignment" is kept as a LANE MASK in scalar registers (the conditions' compare results or-ed on the scalar unit): as a
+      // bool per lane the compiler rebuilt it with two selects, an and and a compare per chunk
+      unsigned long long finm = 0ull;
       int qn = 0;
-      auto finished = [&](int h, int k) {
+      auto finished = [&](int h, int k) -> bool {          // (the caller collects the lanes' answers: it may be called under a lane condition)
         dmin = imin(dmin, left_to_align(h, k, pl, tl, ef, pef, tef));
-        if (ef) { const int v = h - k; fin_l = fin_l || (h >= tl && pl - v <= pef) || (v >= pl && tl - h <= tef); }
-        else fin_l = fin_l || (k == kend && h >= tl);
+        if (ef) { const int v = h - k; return (h >= tl && pl - v <= pef) || (v >= pl && tl - h <= tef); }
+        return k == kend && h >= tl;
       };
       auto drain = [&]() {
         int pass = 0;
@@ -456,7 +465,7 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_adaptive_lds_kernel(
               const int v = h - k;
               h += otg_wave_match(P, T, v, h, imin(pl - v, tl - h), lane);
               wf[k & MASK] = (int16_t)h;              // the same value from every lane
-              finished(h, k);
+              if (finished(h, k)) finm = ~0ull;
             }
             qn = 0;
             break;
@@ -465,7 +474,7 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_adaptive_lds_kernel(
           for (int q0 = 0; q0 < qn; q0 += 64) {
             const bool act = q0 + lane < qn;
             int k = 0, h = 0, v = 0;
-            bool more = false;
+            bool more = false, fin = false;
             if (act) {
               k = lo + (int)queue[q0 + lane];
               h = wf[k & MASK];
@@ -474,8 +483,9 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_adaptive_lds_kernel(
               v += m; h += m;
               more = (m == 32) && v < pl && h < tl;
               wf[k & MASK] = (int16_t)h;
-              if (!more) finished(h, k);
+              if (!more) fin = finished(h, k);
             }
+            finm |= __ballot(fin);
             const unsigned long long mm = __ballot(more);
             if (more) {
               const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
@@ -496,7 +506,7 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_adaptive_lds_kernel(
         const int mx = imax(imax(l + 1, o + 1), r);
         const int v = mx - k;
         const int t1 = tl - mx, t2 = pl - v;                              // what is left of the text / the pattern
-        const bool valid = (uint32_t)mx <= (uint32_t)tl && (uint32_t)v <= (uint32_t)pl && k <= hi;
+        const unsigned long long vm = mk_ule((uint32_t)mx, (uint32_t)tl) & mk_ule((uint32_t)v, (uint32_t)pl) & mk_sle(k, hi);      // valid cells
         // the probe, wherever the offsets point
         int pm;
         {
@@ -514,21 +524,20 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_adaptive_lds_kernel(
           pm = (int)((a < 64u ? a : 64u) >> 1);
         }
         const int m = imin(imin(pm, t1), t2);                            // the run, limited by the sequence ends
-        const bool more = valid && imin(imin(pm, t1 - 1), t2 - 1) == 32;  // a full probe with more than 32 bases left of both sequences
+        const unsigned long long mm = vm & mk_eq(imin(imin(pm, t1 - 1), t2 - 1), 32);  // more: a full probe with more than 32 bases left of both sequences
         const int h2 = mx + m;
-        wf[k & MASK] = (int16_t)(valid ? h2 : NUL);                      // every lane stores (see the head of the kernel)
-        const bool here = valid && !more;
+        wf[k & MASK] = (int16_t)sel(vm, h2, NUL);                        // every lane stores (see the head of the kernel)
+        const unsigned long long hm = vm & ~mm;                          // cells that are final here
         const int lh = t1 - m, lv = t2 - m;
         int d;
-        if (!ef) { d = imax(lh, lv); fin_l = fin_l || (here && k == kend && lh <= 0); }      // the end diagonal has reached the end of the text
+        if (!ef) { d = imax(lh, lv); finm |= hm & mk_eq(k, kend) & mk_sle(lh, 0); }      // the end diagonal has reached the end of the text
         else {
           d = imin(imax(lh, lv - pef), imax(lv, lh - tef));
-          fin_l = fin_l || (here && ((lh <= 0 && lv <= pef) || (lv <= 0 && lh <= tef)));
+          finm |= hm & ((mk_sle(lh, 0) & mk_sle(lv, pef)) | (mk_sle(lv, 0) & mk_sle(lh, tef)));
         }
-        dmin = imin(dmin, here ? d : BIG);
-        const unsigned long long mm = __ballot(more);
+        dmin = imin(dmin, sel(hm, d, BIG));
         if (mm) {
-          if (more) {
+          if (sel(mm, 1, 0)) {
             const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
             queue[qn + rank] = (uint16_t)(k - lo);
           }
@@ -538,7 +547,7 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_adaptive_lds_kernel(
       }
       if (qn) drain();
       // ---- end test on the fully extended wavefront
-      if (__ballot(fin_l) != 0ull) { done = true; break; }
+      if (finm != 0ull) { done = true; break; }
       // ---- the cut; what it drops is nulled (the invariant above)
       const int olo = lo, ohi = hi;
       const int mind = wave_min_i32(dmin);
