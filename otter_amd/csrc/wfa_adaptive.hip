@@ -997,7 +997,7 @@ __global__ __launch_bounds__(WPB * 64) void wfa_affine_adaptive_lds_kernel(
       const int width = hi - lo + 1, padded = ((width + 63) >> 6) << 6;
       if (width + PAD > CAP || slab_top + (size_t)padded > ws.slab_bytes) { fail = true; break; }
       null_quarters(sm, omlo, imin(omhi, lo - 1), imax(omlo, hi + 1), omhi, ROW_I + si, ROW_D + si, oilo, imin(oihi, lo - 1), imax(oilo, hi + 1), oihi);
-      uint8_t* btrow = slab + slab_top - lo;     // btrow[k]; the row is padded to whole chunks
+      uint8_t* btbase = slab + slab_top;         // provenance byte of diagonal k: btbase[k - lo]; the row is padded to whole chunks
       rowtab[s] = (int64_t)slab_top - lo;        // wave-uniform store
       slab_top += (size_t)padded;
       W += 3ull * (uint64_t)width;
@@ -1062,10 +1062,12 @@ __global__ __launch_bounds__(WPB * 64) void wfa_affine_adaptive_lds_kernel(
         const int mx = imax(imax(delv, mis), insv);
         const uint32_t org = mx == mis ? 0u : (mx == delv ? 1u : 2u);      // mismatch wins ties over deletion over insertion
         const uint32_t bits = org | (ext_i ? 4u : 0u) | (ext_d ? 8u : 0u);
+        // per-lane conditions as lane masks on the scalar unit from here on (see mk_eq)
         const bool inr = k <= hi;
+        const unsigned long long inrm = __builtin_amdgcn_ballot_w64(inr);
         const int v = mx - k;
         const int t1 = tl - mx, t2 = pl - v;
-        const bool valid = inr && (uint32_t)mx <= (uint32_t)tl && (uint32_t)v <= (uint32_t)pl;
+        const unsigned long long vm = inrm & mk_ule((uint32_t)mx, (uint32_t)tl) & mk_ule((uint32_t)v, (uint32_t)pl);      // valid cells
         int pm;
         {
           const int wp = (v >> 2) & ~3, wt = offT4 + ((mx >> 2) & ~3);
@@ -1082,25 +1084,24 @@ __global__ __launch_bounds__(WPB * 64) void wfa_affine_adaptive_lds_kernel(
           pm = (int)((a < 64u ? a : 64u) >> 1);
         }
         const int m = imin(imin(pm, t1), t2);
-        const bool more = valid && imin(imin(pm, t1 - 1), t2 - 1) == 32;
+        const unsigned long long mq = vm & mk_eq(imin(imin(pm, t1 - 1), t2 - 1), 32);      // more: a full probe with more than 32 bases left of both sequences
         const int h2 = mx + m;
         if (!MASKED || inr) {       // MASKED: lanes behind the range do not store, the window is usable up to CAP - 4 diagonals (one execution-mask region per chunk)
-          *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + bm + a0) = (int16_t)(valid ? h2 : NUL);
-          *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + bI + a0) = (int16_t)((inr && insv >= 0) ? insv : NUL);
-          *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + bD + a0) = (int16_t)((inr && delv >= 0) ? delv : NUL);
+          *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + bm + a0) = (int16_t)sel(vm, h2, NUL);
+          *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + bI + a0) = (int16_t)sel(inrm & mk_sle(0, insv), insv, NUL);
+          *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + bD + a0) = (int16_t)sel(inrm & mk_sle(0, delv), delv, NUL);
         }
-        btrow[k] = (uint8_t)bits;                                        // every lane stores: the row is padded
-        const bool here = valid && !more;
+        btbase[(uint32_t)(k - lo)] = (uint8_t)bits;                      // every lane stores: the row is padded (uniform base + unsigned lane offset)
+        const unsigned long long hm = vm & ~mq;                          // cells that are final here
         const int lh = t1 - m, lv = t2 - m;
         int d;
-        bool fin;
-        if (!ef) { d = imax(lh, lv); fin = here && k == kend && lh <= 0; }
-        else { d = imin(imax(lh, lv - pef), imax(lv, lh - tef)); fin = here && ((lh <= 0 && lv <= pef) || (lv <= 0 && lh <= tef)); }
-        kfin = imin(kfin, fin ? k : BIG);
-        dmin = imin(dmin, here ? d : BIG);
-        const unsigned long long mq = __ballot(more);
+        unsigned long long fm;
+        if (!ef) { d = imax(lh, lv); fm = hm & mk_eq(k, kend) & mk_sle(lh, 0); }
+        else { d = imin(imax(lh, lv - pef), imax(lv, lh - tef)); fm = hm & ((mk_sle(lh, 0) & mk_sle(lv, pef)) | (mk_sle(lv, 0) & mk_sle(lh, tef))); }
+        if (fm) kfin = imin(kfin, sel(fm, k, BIG));
+        dmin = imin(dmin, sel(hm, d, BIG));
         if (mq) {
-          if (more) {
+          if (sel(mq, 1, 0)) {
             const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mq, 0u));
             queue[qn + rank] = (uint32_t)(k - lo);
           }
@@ -1309,7 +1310,7 @@ __global__ __launch_bounds__(NW * 64) void wfa_affine_adaptive_mw_kernel(
       const int width = hi - lo + 1, padded = ((width + 63) >> 6) << 6;
       if (width + PAD > CAP || slab_top + (size_t)padded > ws.slab_bytes) { fail = true; break; }
       if (ww == 0) null_quarters(sm, omlo, imin(omhi, lo - 1), imax(omlo, hi + 1), omhi, ROW_I + si, ROW_D + si, oilo, imin(oihi, lo - 1), imax(oilo, hi + 1), oihi);
-      uint8_t* btrow = slab + slab_top - lo;
+      uint8_t* btbase = slab + slab_top;         // provenance byte of diagonal k: btbase[k - lo]
       if (tid == 0) rowtab[s] = (int64_t)slab_top - lo;
       slab_top += (size_t)padded;
       W += 3ull * (uint64_t)width;
@@ -1374,10 +1375,12 @@ __global__ __launch_bounds__(NW * 64) void wfa_affine_adaptive_mw_kernel(
         const int mx = imax(imax(delv, mis), insv);
         const uint32_t org = mx == mis ? 0u : (mx == delv ? 1u : 2u);      // mismatch wins ties over deletion over insertion
         const uint32_t bits = org | (ext_i ? 4u : 0u) | (ext_d ? 8u : 0u);
+        // per-lane conditions as lane masks on the scalar unit from here on (see mk_eq)
         const bool inr = k <= hi;
+        const unsigned long long inrm = __builtin_amdgcn_ballot_w64(inr);
         const int v = mx - k;
         const int t1 = tl - mx, t2 = pl - v;
-        const bool valid = inr && (uint32_t)mx <= (uint32_t)tl && (uint32_t)v <= (uint32_t)pl;
+        const unsigned long long vm = inrm & mk_ule((uint32_t)mx, (uint32_t)tl) & mk_ule((uint32_t)v, (uint32_t)pl);      // valid cells
         int pm;
         {
           const int wp = (v >> 2) & ~3, wt = offT4 + ((mx >> 2) & ~3);
@@ -1394,25 +1397,24 @@ __global__ __launch_bounds__(NW * 64) void wfa_affine_adaptive_mw_kernel(
           pm = (int)((a < 64u ? a : 64u) >> 1);
         }
         const int m = imin(imin(pm, t1), t2);
-        const bool more = valid && imin(imin(pm, t1 - 1), t2 - 1) == 32;
+        const unsigned long long mq = vm & mk_eq(imin(imin(pm, t1 - 1), t2 - 1), 32);      // more: a full probe with more than 32 bases left of both sequences
         const int h2 = mx + m;
         if (inr) {            // lanes behind the range do not store: the window is usable up to CAP - 4 diagonals
-          *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + bm + a0) = (int16_t)(valid ? h2 : NUL);
-          *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + bI + a0) = (int16_t)(insv >= 0 ? insv : NUL);
-          *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + bD + a0) = (int16_t)(delv >= 0 ? delv : NUL);
+          *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + bm + a0) = (int16_t)sel(vm, h2, NUL);
+          *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + bI + a0) = (int16_t)sel(mk_sle(0, insv), insv, NUL);
+          *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + bD + a0) = (int16_t)sel(mk_sle(0, delv), delv, NUL);
         }
-        btrow[k] = (uint8_t)bits;                                        // every lane stores: the row is padded to whole chunks
-        const bool here = valid && !more;
+        btbase[(uint32_t)(k - lo)] = (uint8_t)bits;                      // every lane stores: the row is padded to whole chunks
+        const unsigned long long hm = vm & ~mq;                          // cells that are final here
         const int lh = t1 - m, lv = t2 - m;
         int d;
-        bool fin;
-        if (!ef) { d = imax(lh, lv); fin = here && k == kend && lh <= 0; }
-        else { d = imin(imax(lh, lv - pef), imax(lv, lh - tef)); fin = here && ((lh <= 0 && lv <= pef) || (lv <= 0 && lh <= tef)); }
-        kfin = imin(kfin, fin ? k : BIG);
-        dmin = imin(dmin, here ? d : BIG);
-        const unsigned long long mq = __ballot(more);
+        unsigned long long fm;
+        if (!ef) { d = imax(lh, lv); fm = hm & mk_eq(k, kend) & mk_sle(lh, 0); }
+        else { d = imin(imax(lh, lv - pef), imax(lv, lh - tef)); fm = hm & ((mk_sle(lh, 0) & mk_sle(lv, pef)) | (mk_sle(lv, 0) & mk_sle(lh, tef))); }
+        if (fm) kfin = imin(kfin, sel(fm, k, BIG));
+        dmin = imin(dmin, sel(hm, d, BIG));
         if (mq) {
-          if (more) {
+          if (sel(mq, 1, 0)) {
             const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mq, 0u));
             queue[qn + rank] = (uint32_t)(k - lo);
           }
