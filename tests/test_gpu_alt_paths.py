@@ -36,6 +36,7 @@ CASES = [
     ("OTG_ADAPTIVE_EDIT_TIERS=2", ["tests/test_gpu_adaptive.py::test_adaptive_edit_small", "tests/test_gpu_adaptive.py::test_adaptive_edit_long"]),
     ("OTG_ADAPTIVE_AFFINE_TIERS=2", ["tests/test_gpu_adaptive.py::test_adaptive_affine_small", "tests/test_gpu_adaptive.py::test_adaptive_affine_long", "tests/test_gpu_adaptive.py::test_adaptive_pipeline"]),
     ("OTG_ADAPTIVE_AFFINE_TIERS=8", ["tests/test_gpu_adaptive.py::test_adaptive_affine_small", "tests/test_gpu_adaptive.py::test_adaptive_affine_long", "tests/test_gpu_adaptive.py::test_adaptive_affine_parameters", "tests/test_gpu_adaptive.py::test_adaptive_pipeline"]),
+    ("OTG_ADAPTIVE_AFFINE_TIERS=10", ["tests/test_gpu_adaptive.py::test_adaptive_affine_small", "tests/test_gpu_adaptive.py::test_adaptive_affine_long", "tests/test_gpu_adaptive.py::test_adaptive_affine_other_penalties_and_wide", "tests/test_gpu_adaptive.py::test_adaptive_pipeline_hifi_and_haps"]),
     ("OTG_ADAPTIVE_AFFINE_TIERS=18", ["tests/test_gpu_adaptive.py::test_adaptive_affine_small", "tests/test_gpu_adaptive.py::test_adaptive_affine_long", "tests/test_gpu_adaptive.py::test_adaptive_pipeline"]),
     ("OTG_ADAPTIVE_AFFINE_TIERS=0", ["tests/test_gpu_adaptive.py::test_adaptive_affine_small", "tests/test_gpu_adaptive.py::test_adaptive_affine_other_penalties_and_wide"]),
 ]
