@@ -507,11 +507,10 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_adaptive_lds_kernel(
         const int v = mx - k;
         const int t1 = tl - mx, t2 = pl - v;                              // what is left of the text / the pattern
         const unsigned long long vm = mk_ule((uint32_t)mx, (uint32_t)tl) & mk_ule((uint32_t)v, (uint32_t)pl) & mk_sle(k, hi);      // valid cells
-        // the probe, wherever the offsets point
-        int pm;
-        {
-          const int wp = (v >> 2) & ~3, wt = offT4 + ((mx >> 2) & ~3);     // byte addresses of the first word of each 32-base window
-          const uint32_t sp = (uint32_t)(v & 15) * 2u, st = (uint32_t)(mx & 15) * 2u;
+        // the probe, wherever the offsets point: equal leading bases of pattern[pv ..] and text[ph ..], at most 32
+        auto probe = [&](int pv, int ph) -> int {
+          const int wp = (pv >> 2) & ~3, wt = offT4 + ((ph >> 2) & ~3);    // byte addresses of the first word of each 32-base window
+          const uint32_t sp = (uint32_t)(pv & 15) * 2u, st = (uint32_t)(ph & 15) * 2u;
           const volatile lds_u32* pp = (const volatile lds_u32*)((const volatile __attribute__((address_space(3))) char*)SQ + wp);
           const volatile lds_u32* pt = (const volatile lds_u32*)((const volatile __attribute__((address_space(3))) char*)SQ + wt);
           const uint32_t p0 = pp[0], p1 = pp[1], p2 = pp[2], q0 = pt[0], q1 = pt[1], q2 = pt[2];
@@ -521,10 +520,20 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_adaptive_lds_kernel(
           asm("v_ffbl_b32 %0, %1" : "=v"(flo) : "v"(xl));
           asm("v_ffbl_b32 %0, %1" : "=v"(fhi) : "v"(xh));
           const uint32_t a = flo < (fhi | 32u) ? flo : (fhi | 32u);
-          pm = (int)((a < 64u ? a : 64u) >> 1);
+          return (int)((a < 64u ? a : 64u) >> 1);
+        };
+        const int pm = probe(v, mx);
+        int m = imin(imin(pm, t1), t2);                                  // the run, limited by the sequence ends
+        unsigned long long mm = vm & mk_eq(imin(imin(pm, t1 - 1), t2 - 1), 32);        // more: a full probe with more than 32 bases left of both sequences
+        // A run that outlives its probe (one cell in 120 at ONT divergence, i.e. four chunks in ten) gets a second probe right here, by the whole
+        // wave: the queue, its drain and their loops — a fixed cost of ~40 vector and as many scalar instructions per score — are then left to runs
+        // beyond 64 bases (one score in a hundred)
+        if (mm) {
+          const int pm2 = probe(v + 32, mx + 32);
+          const int m2 = imin(imin(pm2, t1 - 32), t2 - 32);
+          m = sel(mm, m2 + 32, m);
+          mm &= mk_eq(imin(imin(pm2, t1 - 33), t2 - 33), 32);
         }
-        const int m = imin(imin(pm, t1), t2);                            // the run, limited by the sequence ends
-        const unsigned long long mm = vm & mk_eq(imin(imin(pm, t1 - 1), t2 - 1), 32);  // more: a full probe with more than 32 bases left of both sequences
         const int h2 = mx + m;
         wf[k & MASK] = (int16_t)sel(vm, h2, NUL);                        // every lane stores (see the head of the kernel)
         const unsigned long long hm = vm & ~mm;                          // cells that are final here
@@ -1068,10 +1077,9 @@ __global__ __launch_bounds__(WPB * 64) void wfa_affine_adaptive_lds_kernel(
         const int v = mx - k;
         const int t1 = tl - mx, t2 = pl - v;
         const unsigned long long vm = inrm & mk_ule((uint32_t)mx, (uint32_t)tl) & mk_ule((uint32_t)v, (uint32_t)pl);      // valid cells
-        int pm;
-        {
-          const int wp = (v >> 2) & ~3, wt = offT4 + ((mx >> 2) & ~3);
-          const uint32_t sp = (uint32_t)(v & 15) * 2u, st = (uint32_t)(mx & 15) * 2u;
+        auto probe = [&](int pv, int ph) -> int {      // equal leading bases of pattern[pv ..] and text[ph ..], at most 32
+          const int wp = (pv >> 2) & ~3, wt = offT4 + ((ph >> 2) & ~3);
+          const uint32_t sp = (uint32_t)(pv & 15) * 2u, st = (uint32_t)(ph & 15) * 2u;
           const volatile lds_u32* pp = (const volatile lds_u32*)(SQB + wp);
           const volatile lds_u32* pt = (const volatile lds_u32*)(SQB + wt);
           const uint32_t p0 = pp[0], p1 = pp[1], p2 = pp[2], q0 = pt[0], q1 = pt[1], q2 = pt[2];
@@ -1081,10 +1089,17 @@ __global__ __launch_bounds__(WPB * 64) void wfa_affine_adaptive_lds_kernel(
           asm("v_ffbl_b32 %0, %1" : "=v"(flo) : "v"(xl));
           asm("v_ffbl_b32 %0, %1" : "=v"(fhi) : "v"(xh));
           const uint32_t a = flo < (fhi | 32u) ? flo : (fhi | 32u);
-          pm = (int)((a < 64u ? a : 64u) >> 1);
+          return (int)((a < 64u ? a : 64u) >> 1);
+        };
+        const int pm = probe(v, mx);
+        int m = imin(imin(pm, t1), t2);
+        unsigned long long mq = vm & mk_eq(imin(imin(pm, t1 - 1), t2 - 1), 32);            // more: a full probe with more than 32 bases left of both sequences
+        if (mq) {             // a second probe by the whole wave where a run outlives the first (as in the edit tier): the queue is for runs beyond 64 bases
+          const int pm2 = probe(v + 32, mx + 32);
+          const int m2 = imin(imin(pm2, t1 - 32), t2 - 32);
+          m = sel(mq, m2 + 32, m);
+          mq &= mk_eq(imin(imin(pm2, t1 - 33), t2 - 33), 32);
         }
-        const int m = imin(imin(pm, t1), t2);
-        const unsigned long long mq = vm & mk_eq(imin(imin(pm, t1 - 1), t2 - 1), 32);      // more: a full probe with more than 32 bases left of both sequences
         const int h2 = mx + m;
         if (!MASKED || inr) {       // MASKED: lanes behind the range do not store, the window is usable up to CAP - 4 diagonals (one execution-mask region per chunk)
           *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + bm + a0) = (int16_t)sel(vm, h2, NUL);
@@ -1381,10 +1396,9 @@ __global__ __launch_bounds__(NW * 64) void wfa_affine_adaptive_mw_kernel(
         const int v = mx - k;
         const int t1 = tl - mx, t2 = pl - v;
         const unsigned long long vm = inrm & mk_ule((uint32_t)mx, (uint32_t)tl) & mk_ule((uint32_t)v, (uint32_t)pl);      // valid cells
-        int pm;
-        {
-          const int wp = (v >> 2) & ~3, wt = offT4 + ((mx >> 2) & ~3);
-          const uint32_t sp = (uint32_t)(v & 15) * 2u, st = (uint32_t)(mx & 15) * 2u;
+        auto probe = [&](int pv, int ph) -> int {      // equal leading bases of pattern[pv ..] and text[ph ..], at most 32
+          const int wp = (pv >> 2) & ~3, wt = offT4 + ((ph >> 2) & ~3);
+          const uint32_t sp = (uint32_t)(pv & 15) * 2u, st = (uint32_t)(ph & 15) * 2u;
           const volatile lds_u32* pp = (const volatile lds_u32*)(SQB + wp);
           const volatile lds_u32* pt = (const volatile lds_u32*)(SQB + wt);
           const uint32_t p0 = pp[0], p1 = pp[1], p2 = pp[2], q0 = pt[0], q1 = pt[1], q2 = pt[2];
@@ -1394,10 +1408,17 @@ __global__ __launch_bounds__(NW * 64) void wfa_affine_adaptive_mw_kernel(
           asm("v_ffbl_b32 %0, %1" : "=v"(flo) : "v"(xl));
           asm("v_ffbl_b32 %0, %1" : "=v"(fhi) : "v"(xh));
           const uint32_t a = flo < (fhi | 32u) ? flo : (fhi | 32u);
-          pm = (int)((a < 64u ? a : 64u) >> 1);
+          return (int)((a < 64u ? a : 64u) >> 1);
+        };
+        const int pm = probe(v, mx);
+        int m = imin(imin(pm, t1), t2);
+        unsigned long long mq = vm & mk_eq(imin(imin(pm, t1 - 1), t2 - 1), 32);            // more: a full probe with more than 32 bases left of both sequences
+        if (mq) {             // a second probe by the whole wave where a run outlives the first (as in the edit tier): the queue is for runs beyond 64 bases
+          const int pm2 = probe(v + 32, mx + 32);
+          const int m2 = imin(imin(pm2, t1 - 32), t2 - 32);
+          m = sel(mq, m2 + 32, m);
+          mq &= mk_eq(imin(imin(pm2, t1 - 33), t2 - 33), 32);
         }
-        const int m = imin(imin(pm, t1), t2);
-        const unsigned long long mq = vm & mk_eq(imin(imin(pm, t1 - 1), t2 - 1), 32);      // more: a full probe with more than 32 bases left of both sequences
         const int h2 = mx + m;
         if (inr) {            // lanes behind the range do not store: the window is usable up to CAP - 4 diagonals
           *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + bm + a0) = (int16_t)sel(vm, h2, NUL);
