@@ -552,7 +552,7 @@ def run_rank(args):
                    "allele_records": info.get("records"), "synthetic_input_generation_s": round(gen_s, 1),
                    "host_to_host": {"regions_per_s": round(regions_ok / r["h2h_s"], 2), "ms": round(r["h2h_s"] * 1000.0, 2),
                                     "what": "SURVEY 8(d): otg_assemble_submit (H2D) + run + collect (D2H), mean of %d passes" % min(3, max(1, args.steps))}},
-        "roofline": roofline(r["kstats"], cfg, n_regions),
+        "roofline": roofline(r["kstats"], cfg, n_regions, adaptive=args.heuristic != "none"),
     }
     if leg4_multi is not None:
         out["config"]["legs"] = {"configs[4]": leg4_multi}
