@@ -77,6 +77,17 @@ struct HeurScope {                                           /* otg_params.heuri
 static int g_width_stats_on = 0;
 static uint64_t g_width_hist[4][16];
 static uint64_t g_width_n[4], g_width_scores[4];
+/* ... and, for the edit alignments whose wavefront ever exceeds 1020 diagonals (the fast adaptive tier's window): how many there are, in how many of
+ * their scores the wavefront is that wide, the last such score + 1, and their scores in all — is the wide phase a prefix of the alignment? */
+static uint64_t g_width_phase[2][4];
+static void width_phase(int kind, int wide_scores, int last_wide, int scores)
+{
+  if (!g_width_stats_on || wide_scores == 0) return;
+  __atomic_fetch_add(&g_width_phase[kind][0], 1, __ATOMIC_RELAXED);
+  __atomic_fetch_add(&g_width_phase[kind][1], (uint64_t)wide_scores, __ATOMIC_RELAXED);
+  __atomic_fetch_add(&g_width_phase[kind][2], (uint64_t)(last_wide + 1), __ATOMIC_RELAXED);
+  __atomic_fetch_add(&g_width_phase[kind][3], (uint64_t)scores + 1, __ATOMIC_RELAXED);
+}
 static void width_stat(int kind, int maxw, int scores)
 {
   if (!g_width_stats_on) return;
@@ -137,10 +148,11 @@ int wfa_edit(const uint8_t* p, int pl, const uint8_t* t, int tl, const Form& f, 
   const int B = pl + 1;
   for (int k = lo; k <= hi; ++k) cur[k + B] = k > 0 ? k : 0;
   uint64_t W = 0;
-  int steps_wait = 0, maxw = 0;
+  int steps_wait = 0, maxw = 0, wide_scores = 0, last_wide = -1;
   for (int s = 0;; ++s) {
     W += (uint64_t)(hi - lo + 1);
     maxw = std::max(maxw, hi - lo + 1);
+    if (hi - lo + 1 > 1020) { ++wide_scores; last_wide = s; }
     for (int k = lo; k <= hi; ++k) {
       int h = cur[k + B];
       if (h < 0) continue;
@@ -150,14 +162,14 @@ int wfa_edit(const uint8_t* p, int pl, const uint8_t* t, int tl, const Form& f, 
       if (f.endsfree) {
         if ((h >= tl && pl - v <= f.pef) || (v >= pl && tl - h <= f.tef)) {
           if (cells) *cells = W;
-          width_stat(1, maxw, s);
+          width_stat(1, maxw, s); width_phase(1, wide_scores, last_wide, s);
           return s;
         }
       }
     }
     if (!f.endsfree && kend >= lo && kend <= hi && cur[kend + B] >= tl) {
       if (cells) *cells = W;
-      width_stat(0, maxw, s);
+      width_stat(0, maxw, s); width_phase(0, wide_scores, last_wide, s);
       return s;
     }
     if (g_heur.on) {
@@ -1669,9 +1681,11 @@ void oto_set_heuristic(int on, int min_wf_len, int max_dist, int steps)
 void oto_width_stats(int on, uint64_t* out)
 {
   if (out) for (int k = 0; k < 4; ++k) { memcpy(out + k * 18, oto::g_width_hist[k], 16 * 8); out[k * 18 + 16] = oto::g_width_n[k]; out[k * 18 + 17] = oto::g_width_scores[k]; }
-  if (on) { memset(oto::g_width_hist, 0, sizeof(oto::g_width_hist)); memset(oto::g_width_n, 0, sizeof(oto::g_width_n)); memset(oto::g_width_scores, 0, sizeof(oto::g_width_scores)); }
+  if (on) { memset(oto::g_width_phase, 0, sizeof(oto::g_width_phase)); memset(oto::g_width_hist, 0, sizeof(oto::g_width_hist)); memset(oto::g_width_n, 0, sizeof(oto::g_width_n)); memset(oto::g_width_scores, 0, sizeof(oto::g_width_scores)); }
   oto::g_width_stats_on = on;
 }
+/* out = 2 kinds (edit end-to-end, edit ends-free) x (alignments ever wider than 1020 diagonals, their wide scores, last wide score + 1 summed, all their scores) */
+void oto_width_phase(uint64_t* out) { memcpy(out, oto::g_width_phase, sizeof(oto::g_width_phase)); }
 void oto_set_poa_hook(void* fn) { oto::g_poa_hook = (oto::oto_poa_hook_t)fn; }
 uint32_t oto_result_n_alleles(oto_result* R) { return R->alleles.size(); }
 uint64_t oto_result_seq_bytes(oto_result* R) { return R->seqs.size(); }

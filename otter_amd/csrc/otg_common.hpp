@@ -60,6 +60,8 @@ int otg_fail(otg_ctx* ctx, int code, const char* fmt, ...);
 // Grow-only device allocation slot; returns nullptr on failure (error recorded).
 void* otg_slot(otg_ctx* ctx, int slot, size_t bytes);
 
+// words of SLOT_COUNTERS every aligner chain asks for (one size: the slot is never re-allocated between two chains of a batch)
+constexpr size_t OTG_COUNTER_WORDS = 160;
 enum {
   SLOT_ARENA = 0, SLOT_TASKS, SLOT_SCORES, SLOT_CELLS, SLOT_COUNTERS, SLOT_WF_WS, SLOT_CIG_OFF, SLOT_CIG_LEN,
   SLOT_CIG_ARENA, SLOT_BT_POOL, SLOT_ROWTAB, SLOT_REVOPS, SLOT_TASKSTATE, SLOT_TODO, SLOT_AUX0, SLOT_AUX1,

@@ -335,6 +335,34 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_adaptive_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The packed pair of PackedPair below written by a whole block (the multi-wave tiers): thread `tid` of `nt` packs words tid, tid + nt, ...; returns
+// whether THIS thread met a byte outside ACGT.
+__device__ __forceinline__ bool pack_pair_block(volatile lds_u32* SQ, const uint8_t* P, int pl, const uint8_t* T, int tl, int offT, int tid, int nt)
+{
+  bool bad = false;
+  auto pack = [&](const uint8_t* S, int len, int woff) {
+    for (int q = tid; q < (len + 15) / 16 + 3; q += nt) {
+      uint32_t w = 0;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int b0 = 16 * q + 8 * j;
+        const uint64_t x = b0 < len ? otg_load8(S + b0) : 0ull;        // (the arena has 64 bytes of slack behind its last sequence)
+#pragma unroll
+        for (int t2 = 0; t2 < 8; ++t2) {
+          const uint32_t c = (uint32_t)(x >> (8 * t2)) & 0xffu;
+          const uint32_t code = (c >> 1) & 3u;
+          if (b0 + t2 < len && c != ((0x47544341u >> (8 * code)) & 0xffu)) bad = true;
+          w |= code << (2 * (8 * j + t2));
+        }
+      }
+      SQ[woff + q] = w;
+    }
+  };
+  pack(P, pl, 0);
+  pack(T, tl, offT);
+  return __ballot(bad) != 0ull;
+}
+
 // Both sequences of a pair packed to 2 bits per base in LDS (word q = bases 16 q .. 16 q + 15, code (byte >> 1) & 3; pattern at word 0,
 // text at word offT): a probe compares 32 bases with six LDS reads instead of two HBM round trips — under the cut a wave advances one
 // score at a time and every score ends in a probe, so the probe latency IS the kernel's speed.  A pair with a byte outside ACGT, or too
@@ -396,12 +424,32 @@ struct PackedPair {
 // lane probes wherever its offset points (LDS reads outside the allocation return zero, inside it harmless words) and stores NULL, which is what a
 // slot outside the live range holds anyway — and the only branches left are wave-uniform: "did any lane's run outlive its probe" and the loop.
 // Score 0 runs through the same sweep: the start diagonals are seeded with their offset MINUS ONE, as if by a score -1.
+// Where the fast edit tier keeps its wavefront: the modular LDS window, or — while a pair's wavefront is wider than the window — a row in HBM / L2.
+// On long reads three ends-free pairs in ten START wider than 1 024 diagonals (the free begin seeds thousands of diagonals) and are cut below that
+// within one or two scores (scripts/heuristic_widths.py: 1.5 wide scores of 394 on the 1-10 kb shard); sent to the 4 096-diagonal tier for that, they
+// ran their whole alignment at its 2.5 waves per SIMD.  Now the same sweep runs those first scores on the global row and moves into the window as
+// soon as the range fits.
+template <int CAP>
+struct EdWfLds {
+  volatile lds_i16* wf;
+  __device__ __forceinline__ int ld(int k) const { return wf[k & (CAP - 1)]; }
+  __device__ __forceinline__ void st(int k, int v) const { wf[k & (CAP - 1)] = (int16_t)v; }
+  __device__ __forceinline__ void sync() const {}
+};
+struct EdWfGlobal {
+  volatile int16_t* g;      // g[k] for -pl - 2 <= k <= tl + 66 (the pointer is already biased)
+  __device__ __forceinline__ int ld(int k) const { return g[k]; }
+  __device__ __forceinline__ void st(int k, int v) const { g[k] = (int16_t)v; }
+  __device__ __forceinline__ void sync() const { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+};
+
 template <int CAP, int QCAP, int WPB>
 __global__ __launch_bounds__(WPB * 64) void wfa_edit_adaptive_lds_kernel(
     const uint8_t* __restrict__ arena, const otg_align_task* __restrict__ tasks,
     const uint32_t* __restrict__ todo, const uint32_t* __restrict__ n_todo_ptr, uint32_t n_todo_imm,
     int32_t* __restrict__ scores, uint64_t* __restrict__ cells,
-    uint32_t* __restrict__ ticket, uint32_t* __restrict__ n_overflow, uint32_t* __restrict__ overflow_list, Heur H, int seqw)
+    uint32_t* __restrict__ ticket, uint32_t* __restrict__ n_overflow, uint32_t* __restrict__ overflow_list, Heur H, int seqw,
+    int16_t* __restrict__ gscratch, int gcap)        // gscratch: gcap offsets per wave for the wide start of a pair (null: such pairs go to the next tier)
 {
   __shared__ __attribute__((aligned(16))) int16_t s_wf[WPB][CAP];
   __shared__ uint16_t s_q[WPB][QCAP];
@@ -430,19 +478,28 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_adaptive_lds_kernel(
     if (lo < -pl) lo = -pl;
     if (hi > tl) hi = tl;
     // (the last chunk of a sweep stores 64 lanes whatever the range: the slots behind hi must not alias the live range)
-    bool overflow = pl > 32766 || tl > 32766 || hi - lo + 68 > CAP;
+    bool wide = hi - lo + 68 > CAP;             // the pair starts wider than the window: its first scores run on the global row
+    bool overflow = pl > 32766 || tl > 32766 || (wide && (!gscratch || pl + tl + 72 > gcap));
     PackedPair pk{(volatile lds_u32*)(s_dyn + (size_t)wib * seqw), 0, false};
     if (!overflow) { pk.init(P, pl, T, tl, lane, seqw); overflow = !pk.ok; }
     int s = 0, steps_wait = 0;
     uint64_t W = 0;
     bool done = false;
+    volatile int16_t* grow = gscratch ? gscratch + (size_t)(blockIdx.x * WPB + wib) * (size_t)gcap + (pl + 2) : nullptr;      // grow[k], k >= -pl - 2
+    int gnlo = 0, gnhi = -1;                    // the span of the global row that has been written (nulls or offsets) for this pair
     if (!overflow) {
       for (int q = lane; q < CAP / 2; q += 64) wf32[q] = 0x80008000u;
-      for (int c = lo; c <= hi; c += 64) { const int k = c + lane; if (k <= hi) wf[k & MASK] = (int16_t)((k > 0 ? k : 0) - 1); }      // "score -1"
+      if (!wide) { for (int c = lo; c <= hi; c += 64) { const int k = c + lane; if (k <= hi) wf[k & MASK] = (int16_t)((k > 0 ? k : 0) - 1); } }      // "score -1"
+      else {
+        gnlo = lo - 2; gnhi = hi + 66;
+        for (int c = gnlo; c <= gnhi; c += 64) { const int k = c + lane; if (k <= gnhi) grow[k] = (int16_t)((k >= lo && k <= hi) ? (k > 0 ? k : 0) - 1 : NUL); }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      }
     }
     const int offT4 = pk.offT * 4;
-    while (!overflow) {
-      if (hi - lo + 68 > CAP) { overflow = true; break; }
+    // one score on the wavefront kept in `wfs`: 0 = go on, 1 = done, 2 = the range outgrew `cap_here`, 3 = no alignment within pl + tl + 2
+    auto one_score = [&](auto wfs, int cap_here) -> int {
+      if (hi - lo + 68 > cap_here) return 2;
       W += (uint64_t)(hi - lo + 1);
       int carry = NUL;
       int dmin = BIG;
@@ -458,13 +515,14 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_adaptive_lds_kernel(
       auto drain = [&]() {
         int pass = 0;
         while (qn > 0) {
+          wfs.sync();              // (global row: a queued cell is extended by another lane than the one that stored it)
           if (qn <= 4 && pass > 0) {
             for (int q = 0; q < qn; ++q) {
               const int k = lo + __builtin_amdgcn_readfirstlane((int)queue[q]);
-              int h = __builtin_amdgcn_readfirstlane((int)wf[k & MASK]);
+              int h = __builtin_amdgcn_readfirstlane(wfs.ld(k));
               const int v = h - k;
               h += otg_wave_match(P, T, v, h, imin(pl - v, tl - h), lane);
-              wf[k & MASK] = (int16_t)h;              // the same value from every lane
+              wfs.st(k, h);                            // the same value from every lane
               if (finished(h, k)) finm = ~0ull;
             }
             qn = 0;
@@ -477,12 +535,12 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_adaptive_lds_kernel(
             bool more = false, fin = false;
             if (act) {
               k = lo + (int)queue[q0 + lane];
-              h = wf[k & MASK];
+              h = wfs.ld(k);
               v = h - k;
               const int m = pk.match32(v, h, imin(pl - v, tl - h));
               v += m; h += m;
               more = (m == 32) && v < pl && h < tl;
-              wf[k & MASK] = (int16_t)h;
+              wfs.st(k, h);
               if (!more) fin = finished(h, k);
             }
             finm |= __ballot(fin);
@@ -500,7 +558,7 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_adaptive_lds_kernel(
       const volatile lds_u32* SQ = pk.SQ;
       for (int c = lo; c <= hi; c += 64) {
         const int k = c + lane;
-        const int o = wf[k & MASK], r = wf[(k + 1) & MASK];            // null outside the live range: no range tests
+        const int o = wfs.ld(k), r = wfs.ld(k + 1);            // null outside the live range: no range tests
         const int l = __builtin_amdgcn_update_dpp(carry, o, 0x138, 0xf, 0xf, false);      // lane i <- lane i-1, lane 0 <- the previous chunk's lane 63
         carry = __builtin_amdgcn_readlane(o, 63);
         const int mx = imax(imax(l + 1, o + 1), r);
@@ -535,7 +593,7 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_adaptive_lds_kernel(
           mm &= mk_eq(imin(imin(pm2, t1 - 33), t2 - 33), 32);
         }
         const int h2 = mx + m;
-        wf[k & MASK] = (int16_t)sel(vm, h2, NUL);                        // every lane stores (see the head of the kernel)
+        wfs.st(k, sel(vm, h2, NUL));                        // every lane stores (see the head of the kernel)
         const unsigned long long hm = vm & ~mm;                          // cells that are final here
         const int lh = t1 - m, lv = t2 - m;
         int d;
@@ -555,19 +613,39 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_adaptive_lds_kernel(
         }
       }
       if (qn) drain();
+      wfs.sync();
       // ---- end test on the fully extended wavefront
-      if (finm != 0ull) { done = true; break; }
+      if (finm != 0ull) return 1;
       // ---- the cut; what it drops is nulled (the invariant above)
       const int olo = lo, ohi = hi;
       const int mind = wave_min_i32(dmin);
-      wfadaptive_cut32(H, steps_wait, mind, pl, tl, ef, pef, tef, lo, hi, lane, [&](int k) { const int x = wf[k & MASK]; return x < 0 ? OTG_NULL_OFF : x; });
-      for (int c = olo; c < lo; c += 64) if (c + lane < lo) wf[(c + lane) & MASK] = (int16_t)NUL;
-      for (int c = hi + 1; c <= ohi; c += 64) if (c + lane <= ohi) wf[(c + lane) & MASK] = (int16_t)NUL;
+      wfadaptive_cut32(H, steps_wait, mind, pl, tl, ef, pef, tef, lo, hi, lane, [&](int k) { const int x = wfs.ld(k); return x < 0 ? OTG_NULL_OFF : x; });
+      for (int c = olo; c < lo; c += 64) if (c + lane < lo) wfs.st(c + lane, NUL);
+      for (int c = hi + 1; c <= ohi; c += 64) if (c + lane <= ohi) wfs.st(c + lane, NUL);
+      wfs.sync();
       lo = lo - 1 < -pl ? -pl : lo - 1;
       hi = hi + 1 > tl ? tl : hi + 1;
       ++s;
-      if (s > pl + tl + 2) break;
+      return s > pl + tl + 2 ? 3 : 0;
+    };
+    // two loops, so that the window's loop is as tight as when it was the only one: first the scores on the global row (pairs that start wide) ...
+    int rc = overflow ? 2 : 0;
+    while (rc == 0 && wide) {
+      rc = one_score(EdWfGlobal{grow}, 32767 + 68);
+      if (rc != 0) break;
+      if (hi - lo + 68 <= CAP) {               // the range fits the window: move in (the window is all null) and stay
+        for (int c = lo; c <= hi; c += 64) { const int k = c + lane; if (k <= hi) wf[k & MASK] = grow[k]; }
+        wide = false;
+      } else {                                // the slots a score may read or store beyond what has been written so far are nulled first
+        if (lo - 2 < gnlo) { for (int c = lo - 2; c < gnlo; c += 64) if (c + lane < gnlo) grow[c + lane] = (int16_t)NUL; gnlo = lo - 2; }
+        if (hi + 66 > gnhi) { for (int c = gnhi + 1; c <= hi + 66; c += 64) if (c + lane <= hi + 66) grow[c + lane] = (int16_t)NUL; gnhi = hi + 66; }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      }
     }
+    // ... then the scores in the window
+    while (rc == 0) rc = one_score(EdWfLds<CAP>{wf}, CAP);
+    if (rc == 1) done = true;
+    if (rc == 2) overflow = true;
     // wave-uniform tail: every lane stores the same value to the same address
     if (done) {
       scores[ti] = s;
@@ -577,6 +655,235 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_adaptive_lds_kernel(
       overflow_list[q] = ti;
     } else {
       scores[ti] = -1;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The widest packed edit tier: NW waves on ONE pair (16 384 diagonals: the ends-free pairs of long reads whose wavefront outgrows 4 096 — they went
+// through the byte-probe tiers before).  Same plan as the wide gap-affine tiers further down: chunks of a score dealt to the
+// waves, ranges / cut / step counter replicated in every wave's scalar registers, ONE LDS-only barrier per score.  The in-place sweep of the
+// one-wave tier (left neighbour carried, right neighbour not yet overwritten) does not survive waves working side by side, so the wavefront
+// alternates between TWO rows — score s reads row s & 1 and writes the other — with the null discipline per row: what the write row still holds
+// of the wavefront two scores back is nulled outside the new range when the row is taken over (wave 0), what the cut drops right after the
+// cut (every wave; a late wave's cut reads nulls exactly where it would have cut).
+template <int CAP, int QCAP, int NW>
+__global__ __launch_bounds__(NW * 64) void wfa_edit_adaptive_mw_kernel(
+    const uint8_t* __restrict__ arena, const otg_align_task* __restrict__ tasks,
+    const uint32_t* __restrict__ todo, const uint32_t* __restrict__ n_todo_ptr, uint32_t n_todo_imm,
+    int32_t* __restrict__ scores, uint64_t* __restrict__ cells,
+    uint32_t* __restrict__ ticket, uint32_t* __restrict__ n_overflow, uint32_t* __restrict__ overflow_list, Heur H, int seqw)
+{
+  constexpr int MASK = CAP - 1, NUL = -32768, PAD = 4, NT = NW * 64;
+  __shared__ __attribute__((aligned(16))) int16_t s_wf[2][CAP];
+  __shared__ uint16_t s_q[NW][QCAP];
+  __shared__ int s_x[2][NW][2];
+  __shared__ uint32_t s_tk;
+  __shared__ int s_bad;
+  extern __shared__ uint32_t s_dyn[];                         // [seqw]: the packed pair of the block's alignment
+  using lds_char = __attribute__((address_space(3))) char;
+  const int tid = threadIdx.x, lane = tid & 63;
+  auto U = [](int x) { return __builtin_amdgcn_readfirstlane(x); };
+  const int ww = U(tid >> 6);
+  volatile lds_char* ROWS = (volatile lds_char*)&s_wf[0][0];
+  volatile lds_u32* ROWS32 = (volatile lds_u32*)&s_wf[0][0];
+  volatile lds_u16* queue = (volatile lds_u16*)&s_q[ww][0];
+  volatile lds_u32* SQ = (volatile lds_u32*)s_dyn;
+  const uint32_t n_todo = n_todo_ptr ? *n_todo_ptr : n_todo_imm;
+  auto rd = [&](int row, int k) -> int { return *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + row * (CAP * 2) + ((k & MASK) << 1)); };
+  auto wr = [&](int row, int k, int v) { *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + row * (CAP * 2) + ((k & MASK) << 1)) = (int16_t)v; };
+  auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  auto null_wave = [&](int row, int a, int b) { for (int c = a + lane; c <= b; c += 64) wr(row, c, NUL); };
+  // both ends of a row's nulling in one pass (lanes 0-31 the low interval, 32-63 the high one; wider intervals: the loops)
+  auto null_halves = [&](int row, int a0, int b0, int a1, int b1) {
+    const int n0 = b0 - a0 + 1, n1 = b1 - a1 + 1;
+    if (imax(n0, n1) <= 0) return;
+    if (imax(n0, n1) > 32) { null_wave(row, a0, b0); null_wave(row, a1, b1); return; }
+    const bool low = lane < 32;
+    const int a = low ? a0 : a1, n = low ? n0 : n1, jj = lane & 31;
+    if (jj < n) wr(row, a + jj, NUL);
+  };
+
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) { s_tk = atomicAdd(ticket, 1u); s_bad = 0; }
+    __syncthreads();
+    const uint32_t tk = (uint32_t)U((int)s_tk);
+    if (tk >= n_todo) break;
+    const uint32_t ti = todo ? todo[tk] : tk;
+    const otg_align_task t = tasks[ti];
+    const uint8_t* P = arena + t.pattern_off;
+    const uint8_t* T = arena + t.text_off;
+    const int pl = (int)t.pattern_len, tl = (int)t.text_len;
+    const bool ef = t.endsfree != 0;
+    const int pef = ef ? t.pattern_end_free : 0, tef = ef ? t.text_end_free : 0;
+    const int kend = tl - pl;
+    int lo = ef ? -t.pattern_begin_free : 0, hi = ef ? t.text_begin_free : 0;
+    if (lo < -pl) lo = -pl;
+    if (hi > tl) hi = tl;
+    const int offT = (pl + 15) / 16 + 3;
+    bool overflow = pl > 32766 || tl > 32766 || hi - lo + PAD > CAP || offT + (tl + 15) / 16 + 3 > seqw;
+    if (!overflow) {
+      if (pack_pair_block(SQ, P, pl, T, tl, offT, tid, NT) && lane == 0) s_bad = 1;
+      for (int q = tid; q < CAP; q += NT) ROWS32[q] = 0x80008000u;                  // both rows
+    }
+    __syncthreads();
+    if (!overflow) {
+      overflow = U(s_bad) != 0;
+      if (!overflow) for (int k = lo + tid; k <= hi; k += NT) wr(0, k, (k > 0 ? k : 0) - 1);       // "score -1" in the row score 0 reads
+    }
+    __syncthreads();
+    const PackedPair pk{SQ, offT, true};
+    const int offT4 = offT * 4;
+    const volatile lds_char* SQB = (const volatile lds_char*)SQ;
+    int s = 0, steps_wait = 0;
+    uint64_t W = 0;
+    bool done = false;
+    int r2lo = 1, r2hi = 0;                // what the write row still holds (the wavefront two scores back; null elsewhere)
+    int r1lo = lo, r1hi = hi;              // what the read row holds
+    while (!overflow) {
+      if (hi - lo + PAD > CAP) { overflow = true; break; }
+      W += (uint64_t)(hi - lo + 1);
+      const int rr = s & 1, rw = rr ^ 1;
+      if (ww == 0) null_halves(rw, r2lo, imin(r2hi, lo - 1), imax(r2lo, hi + 1), r2hi);
+      int dmin = BIG;
+      unsigned long long finm = 0ull;
+      int qn = 0;
+      auto finished = [&](int h, int k) -> bool {
+        dmin = imin(dmin, left_to_align(h, k, pl, tl, ef, pef, tef));
+        if (ef) { const int v = h - k; return (h >= tl && pl - v <= pef) || (v >= pl && tl - h <= tef); }
+        return k == kend && h >= tl;
+      };
+      auto drain = [&]() {
+        int pass = 0;
+        while (qn > 0) {
+          if (qn <= 4 && pass > 0) {
+            for (int q = 0; q < qn; ++q) {
+              const int k = lo + U((int)queue[q]);
+              int h = U(rd(rw, k));
+              const int v = h - k;
+              h += otg_wave_match(P, T, v, h, imin(pl - v, tl - h), lane);
+              wr(rw, k, h);                           // the same value from every lane
+              if (finished(h, k)) finm = ~0ull;
+            }
+            qn = 0;
+            break;
+          }
+          int wq = 0;
+          for (int q0 = 0; q0 < qn; q0 += 64) {
+            const bool act = q0 + lane < qn;
+            int k = 0, h = 0, v = 0;
+            bool more = false, fin = false;
+            if (act) {
+              k = lo + (int)queue[q0 + lane];
+              h = rd(rw, k);
+              v = h - k;
+              const int m = pk.match32(v, h, imin(pl - v, tl - h));
+              v += m; h += m;
+              more = (m == 32) && v < pl && h < tl;
+              wr(rw, k, h);
+              if (!more) fin = finished(h, k);
+            }
+            finm |= __ballot(fin);
+            const unsigned long long mm = __ballot(more);
+            if (more) {
+              const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+              queue[wq + rank] = (uint16_t)(k - lo);
+            }
+            wq += __builtin_popcountll(mm);
+          }
+          qn = wq; ++pass;
+        }
+      };
+      // ---- sweep of this wave's chunks (branch-free per lane)
+      const int br = rr * (CAP * 2), bw = rw * (CAP * 2);
+      for (int c = lo + 64 * ww; c <= hi; c += 64 * NW) {
+        const int k = c + lane;
+        const int a0 = (k & MASK) << 1, am = ((k - 1) & MASK) << 1, ap = ((k + 1) & MASK) << 1;
+        const int o = *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + br + a0);
+        const int l = *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + br + am);
+        const int r = *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + br + ap);
+        const int mx = imax(imax(l, o) + 1, r);
+        const int v = mx - k;
+        const int t1 = tl - mx, t2 = pl - v;
+        const bool inr = k <= hi;
+        const unsigned long long inrm = __builtin_amdgcn_ballot_w64(inr);
+        const unsigned long long vm = inrm & mk_ule((uint32_t)mx, (uint32_t)tl) & mk_ule((uint32_t)v, (uint32_t)pl);
+        auto probe = [&](int pv, int ph) -> int {
+          const int wp = (pv >> 2) & ~3, wt = offT4 + ((ph >> 2) & ~3);
+          const uint32_t sp = (uint32_t)(pv & 15) * 2u, st = (uint32_t)(ph & 15) * 2u;
+          const volatile lds_u32* pp = (const volatile lds_u32*)(SQB + wp);
+          const volatile lds_u32* pt = (const volatile lds_u32*)(SQB + wt);
+          const uint32_t p0 = pp[0], p1 = pp[1], p2 = pp[2], q0 = pt[0], q1 = pt[1], q2 = pt[2];
+          const uint32_t xl = __builtin_amdgcn_alignbit(p1, p0, sp) ^ __builtin_amdgcn_alignbit(q1, q0, st);
+          const uint32_t xh = __builtin_amdgcn_alignbit(p2, p1, sp) ^ __builtin_amdgcn_alignbit(q2, q1, st);
+          uint32_t flo, fhi;
+          asm("v_ffbl_b32 %0, %1" : "=v"(flo) : "v"(xl));
+          asm("v_ffbl_b32 %0, %1" : "=v"(fhi) : "v"(xh));
+          const uint32_t a = flo < (fhi | 32u) ? flo : (fhi | 32u);
+          return (int)((a < 64u ? a : 64u) >> 1);
+        };
+        const int pm = probe(v, mx);
+        int m = imin(imin(pm, t1), t2);
+        unsigned long long mm = vm & mk_eq(imin(imin(pm, t1 - 1), t2 - 1), 32);
+        if (mm) {
+          const int pm2 = probe(v + 32, mx + 32);
+          const int m2 = imin(imin(pm2, t1 - 32), t2 - 32);
+          m = sel(mm, m2 + 32, m);
+          mm &= mk_eq(imin(imin(pm2, t1 - 33), t2 - 33), 32);
+        }
+        const int h2 = mx + m;
+        if (inr) *(volatile __attribute__((address_space(3))) int16_t*)(ROWS + bw + a0) = (int16_t)sel(vm, h2, NUL);      // lanes behind the range do not store
+        const unsigned long long hm = vm & ~mm;
+        const int lh = t1 - m, lv = t2 - m;
+        int d;
+        if (!ef) { d = imax(lh, lv); finm |= hm & mk_eq(k, kend) & mk_sle(lh, 0); }
+        else {
+          d = imin(imax(lh, lv - pef), imax(lv, lh - tef));
+          finm |= hm & ((mk_sle(lh, 0) & mk_sle(lv, pef)) | (mk_sle(lv, 0) & mk_sle(lh, tef)));
+        }
+        dmin = imin(dmin, sel(hm, d, BIG));
+        if (mm) {
+          if (sel(mm, 1, 0)) {
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+            queue[qn + rank] = (uint16_t)(k - lo);
+          }
+          qn += __builtin_popcountll(mm);
+          if (qn + 64 > QCAP) drain();
+        }
+      }
+      if (qn) drain();
+      // ---- the one barrier of the score, then every wave reduces the NW (minimum, end flag) pairs
+      {
+        const int wd = wave_min_i32(dmin);
+        if (lane == 0) { s_x[s & 1][ww][0] = wd; s_x[s & 1][ww][1] = finm != 0ull ? 1 : 0; }
+      }
+      lds_barrier();
+      int mind = BIG, anyfin = 0;
+#pragma unroll
+      for (int w2 = 0; w2 < NW; ++w2) { mind = imin(mind, U(s_x[s & 1][w2][0])); anyfin |= U(s_x[s & 1][w2][1]); }
+      if (anyfin) { done = true; break; }
+      // ---- the cut on the row just written (every wave: same inputs, same result); what it drops is nulled by every wave
+      int clo = lo, chi = hi;
+      wfadaptive_cut32(H, steps_wait, mind, pl, tl, ef, pef, tef, clo, chi, lane, [&](int k) { const int x = rd(rw, k); return x < 0 ? OTG_NULL_OFF : x; });
+      clo = U(clo); chi = U(chi);
+      null_halves(rw, lo, clo - 1, chi + 1, hi);
+      r2lo = r1lo; r2hi = r1hi; r1lo = clo; r1hi = chi;
+      lo = clo - 1 < -pl ? -pl : clo - 1;
+      hi = chi + 1 > tl ? tl : chi + 1;
+      ++s;
+      if (s > pl + tl + 2) break;
+    }
+    if (ww == 0) {        // wave-uniform tail: every lane of wave 0 stores the same value to the same address
+      if (done) {
+        scores[ti] = s;
+        if (cells) cells[ti] = W;
+      } else if (overflow && overflow_list) {
+        const uint32_t q = otg_wave_atomic_add(n_overflow, 1u);
+        overflow_list[q] = ti;
+      } else {
+        scores[ti] = -1;
+      }
     }
   }
 }
@@ -1259,29 +1566,7 @@ __global__ __launch_bounds__(NW * 64) void wfa_affine_adaptive_mw_kernel(
     const int lo0 = ef ? imax(-t.pattern_begin_free, -pl) : 0, hi0 = ef ? imin(t.text_begin_free, tl) : 0;
     if (hi0 - lo0 + PAD > CAP) fail = true;
     if (!fail) {
-      // the pair, packed by the whole block (PackedPair::init, one word per thread and round)
-      bool bad = false;
-      auto pack = [&](const uint8_t* S, int len, int woff) {
-        for (int q = tid; q < (len + 15) / 16 + 3; q += NT) {
-          uint32_t w = 0;
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int b0 = 16 * q + 8 * j;
-            const uint64_t x = b0 < len ? otg_load8(S + b0) : 0ull;
-#pragma unroll
-            for (int t2 = 0; t2 < 8; ++t2) {
-              const uint32_t c = (uint32_t)(x >> (8 * t2)) & 0xffu;
-              const uint32_t code = (c >> 1) & 3u;
-              if (b0 + t2 < len && c != ((0x47544341u >> (8 * code)) & 0xffu)) bad = true;
-              w |= code << (2 * (8 * j + t2));
-            }
-          }
-          SQ[woff + q] = w;
-        }
-      };
-      pack(P, pl, 0);
-      pack(T, tl, offT);
-      if (__ballot(bad) != 0ull && lane == 0) s_bad = 1;
+      if (pack_pair_block(SQ, P, pl, T, tl, offT, tid, NT) && lane == 0) s_bad = 1;
       for (int q = tid; q < NROWS * CAP / 2; q += NT) ROWS32[q] = 0x80008000u;
     }
     __syncthreads();
@@ -1486,44 +1771,68 @@ int gcd3(int a, int b, int c)
 
 // ---------------------------------------------------------------------------------------------------
 // Launch chains.  Same contracts as otg_launch_edit_todo / otg_launch_affine_todo (which hand over to these when the context's heuristic is
-// wfadaptive).  Counters: SLOT_COUNTERS words 108..127 (free of the exact chains' words).
+// wfadaptive).  Counters: SLOT_COUNTERS words 108..129 (free of the exact chains' words).
 int otg_launch_edit_adaptive_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align_task* d_tasks, const uint32_t* d_todo,
                                   const uint32_t* d_n_todo, uint32_t n_tasks, int32_t* d_scores, uint64_t* d_cells,
                                   float* kernel_ms, uint64_t* launches)
 {
   if (n_tasks == 0) return OTG_OK;
-  if (ctx->pool[SLOT_COUNTERS].cap < 128 * sizeof(uint32_t)) ctx->affine_visited = nullptr;      // (it points into this slot; the exact chain sets it up again)
-  uint32_t* cnt = (uint32_t*)otg_slot(ctx, SLOT_COUNTERS, 128 * sizeof(uint32_t));
-  uint32_t* lists = (uint32_t*)otg_slot(ctx, SLOT_TODO, 4 * (size_t)n_tasks * sizeof(uint32_t));
+  if (ctx->pool[SLOT_COUNTERS].cap < OTG_COUNTER_WORDS * sizeof(uint32_t)) ctx->affine_visited = nullptr;      // (it points into this slot; the exact chain sets it up again)
+  uint32_t* cnt = (uint32_t*)otg_slot(ctx, SLOT_COUNTERS, OTG_COUNTER_WORDS * sizeof(uint32_t));
+  uint32_t* lists = (uint32_t*)otg_slot(ctx, SLOT_TODO, 5 * (size_t)n_tasks * sizeof(uint32_t));
   if (!cnt || !lists) return OTG_ERR_HIP;
   uint32_t* c = cnt + 108;                    // c[0..3] tickets of the first four tiers, c[4..7] lengths of their overflow lists, c[8..9] the last tier's
+  uint32_t* c16 = cnt + 128;                  // ticket and overflow length of the packed 16384-diagonal tier
   HIP_TRY(ctx, hipMemsetAsync(c, 0, 10 * sizeof(uint32_t), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(c16, 0, 2 * sizeof(uint32_t), ctx->stream));
   const Heur H{ctx->heur_min_wf_len, ctx->heur_max_dist, ctx->heur_steps < 1 ? 1 : ctx->heur_steps};
   const uint32_t ncu = (uint32_t)ctx->n_cu;
-  static const int only = getenv("OTG_ADAPTIVE_EDIT_TIERS") ? atoi(getenv("OTG_ADAPTIVE_EDIT_TIERS")) : 15;      // bit t = tier t runs (packed 1024, packed 4096, bytes 2048, bytes 16384); the HBM tier always does      // test switch: bit t = tier t runs (the last one always does)
+  // test switch, bit t = tier t runs: 1 packed 1024, 2 packed 4096, 4 bytes 2048, 8 bytes 16384, 16 packed 16384 (eight waves per pair, behind the packed
+  // 4096 one: what outgrew that went through the byte-probe tiers before); the HBM tier always runs
+  static const int only = getenv("OTG_ADAPTIVE_EDIT_TIERS") ? atoi(getenv("OTG_ADAPTIVE_EDIT_TIERS")) : 31;
   if (kernel_ms) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   const uint32_t* in = d_todo; const uint32_t* in_n = d_n_todo; uint32_t in_imm = n_tasks;
   uint32_t* l0 = lists; uint32_t* l1 = lists + n_tasks; uint32_t* l2 = lists + 2 * (size_t)n_tasks;
   uint32_t* l3 = lists + 3 * (size_t)n_tasks;
+  uint32_t* l4 = lists + 4 * (size_t)n_tasks;
   // words of LDS per wave for the packed pair: two reads of the batch's longest length (at most 32 KB: 2 x 32766 bases is what 16-bit offsets hold anyway)
   const int seqw = (int)std::min<size_t>(2 * (((size_t)ctx->max_seq_len + 15) / 16 + 3) + 2, 8192);
+  // SLOT_WF_WS serves the first tier (a global row of 16-bit offsets per wave, for pairs that START wider than the window) and the last one (int32
+  // rows): asked for once, for the larger of the two, so that the slot is not re-allocated between two kernels of the chain
+  constexpr int WPB0 = 4, WPBL = 4;
+  const size_t dyn0 = (size_t)WPB0 * seqw * 4;
+  const uint32_t per_cu0 = std::max<uint32_t>(1, std::min<uint32_t>(8, (uint32_t)((160 * 1024) / (WPB0 * 3072 + dyn0))));
+  const uint32_t grid0 = std::min<uint32_t>(ncu * per_cu0, (n_tasks + WPB0 - 1) / WPB0);
+  const int gcap0 = (int)((2 * (size_t)ctx->max_seq_len + 128) & ~(size_t)1);
+  const int gcapL = (int)(2 * (size_t)ctx->max_seq_len + 4);
+  static const bool wide_start = getenv("OTG_ADAPTIVE_NO_WIDE_START") == nullptr;
+  const size_t need0 = (only & 1) && wide_start ? (size_t)grid0 * WPB0 * (size_t)gcap0 * sizeof(int16_t) : 0;
+  const size_t needL = (size_t)ncu * WPBL * (size_t)gcapL * sizeof(int32_t);
+  uint8_t* wsp = (uint8_t*)otg_slot(ctx, SLOT_WF_WS, std::max(need0, needL));
+  if (!wsp) return OTG_ERR_HIP;
   if (only & 1) {       // fast tier: window of 1024 diagonals (3 KB of LDS per wave) + the packed pair
-    constexpr int WPB = 4;
-    const size_t dyn = (size_t)WPB * seqw * 4;
-    const uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(8, (uint32_t)((160 * 1024) / (WPB * 3072 + dyn))));
-    const uint32_t grid = std::min<uint32_t>(ncu * per_cu, (n_tasks + WPB - 1) / WPB);
-    hipLaunchKernelGGL((wfa_edit_adaptive_lds_kernel<1024, 512, WPB>), dim3(grid), dim3(WPB * 64), dyn, ctx->stream, d_arena, d_tasks, in, in_n, in_imm,
-                       d_scores, d_cells, c + 0, c + 4, l0, H, seqw);
+    hipLaunchKernelGGL((wfa_edit_adaptive_lds_kernel<1024, 512, WPB0>), dim3(grid0), dim3(WPB0 * 64), dyn0, ctx->stream, d_arena, d_tasks, in, in_n, in_imm,
+                       d_scores, d_cells, c + 0, c + 4, l0, H, seqw, need0 ? (int16_t*)wsp : (int16_t*)nullptr, gcap0);
     in = l0; in_n = c + 4; in_imm = 0;
   }
-  if (only & 2) {       // fast tier, 4096 diagonals: 10 KB per wave + the packed pair
+  if (only & 2) {       // 4096 diagonals, one wave per pair: 10 KB per wave + the packed pair.  (Measured and not kept: this window on the multi-wave kernel below —
+                        // the reassignment pass sends it 437 000 pairs on the 1-10 kb shard, work enough for one wave each: 4 waves per pair 388 ms, 2 waves 363, one 322)
     constexpr int WPB = 2;
     const size_t dyn = (size_t)WPB * seqw * 4;
     const uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(8, (uint32_t)((160 * 1024) / (WPB * 10240 + dyn))));
     const uint32_t grid = std::min<uint32_t>(ncu * per_cu, (n_tasks + WPB - 1) / WPB);
     hipLaunchKernelGGL((wfa_edit_adaptive_lds_kernel<4096, 1024, WPB>), dim3(grid), dim3(WPB * 64), dyn, ctx->stream, d_arena, d_tasks, in, in_n, in_imm,
-                       d_scores, d_cells, c + 1, c + 5, l1, H, seqw);
+                       d_scores, d_cells, c + 1, c + 5, l1, H, seqw, (int16_t*)nullptr, 0);
     in = l1; in_n = c + 5; in_imm = 0;
+  }
+  if (only & 16) {                       // 16384 diagonals, eight waves per pair: two rows of 32 KB, two blocks per CU
+    constexpr int NW = 8;
+    const size_t dyn = (size_t)seqw * 4;
+    const uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(2, (uint32_t)((160 * 1024) / (2 * 16384 * 2 + NW * 256 * 2 + 256 + dyn))));
+    const uint32_t grid = std::min<uint32_t>(ncu * per_cu, n_tasks);
+    hipLaunchKernelGGL((wfa_edit_adaptive_mw_kernel<16384, 256, NW>), dim3(grid), dim3(NW * 64), dyn, ctx->stream, d_arena, d_tasks, in, in_n, in_imm,
+                       d_scores, d_cells, c16 + 0, c16 + 1, l4, H, seqw);
+    in = l4; in_n = c16 + 1; in_imm = 0;
   }
   if (only & 4) {       // byte probes (pairs with bytes outside ACGT, pairs too long to pack), 2048 diagonals
     constexpr int WPB = 2;
@@ -1540,22 +1849,18 @@ int otg_launch_edit_adaptive_todo(otg_ctx* ctx, const uint8_t* d_arena, const ot
     in = l3; in_n = c + 7; in_imm = 0;
   }
   {                     // int32 wavefront in HBM, sized for the longest pair of the batch
-    constexpr int WPB = 4;
-    const uint32_t grid = ncu;
-    const int gcap = (int)(2 * (size_t)ctx->max_seq_len + 4);
-    int32_t* ws = (int32_t*)otg_slot(ctx, SLOT_WF_WS, (size_t)grid * WPB * (size_t)gcap * sizeof(int32_t));
-    if (!ws) return OTG_ERR_HIP;
-    hipLaunchKernelGGL((wfa_edit_adaptive_kernel<0, 2048, WPB>), dim3(grid), dim3(WPB * 64), 0, ctx->stream, d_arena, d_tasks, in, in_n, in_imm,
-                       d_scores, d_cells, c + 8, c + 9, (uint32_t*)nullptr, H, ws, gcap);
+    hipLaunchKernelGGL((wfa_edit_adaptive_kernel<0, 2048, WPBL>), dim3(ncu), dim3(WPBL * 64), 0, ctx->stream, d_arena, d_tasks, in, in_n, in_imm,
+                       d_scores, d_cells, c + 8, c + 9, (uint32_t*)nullptr, H, (int32_t*)wsp, gcapL);
   }
   if (kernel_ms) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   HIP_TRY(ctx, hipGetLastError());
   if (getenv("OTG_DEBUG")) {
     hipError_t er = hipStreamSynchronize(ctx->stream);
-    uint32_t h[10];
+    uint32_t h[10], h16[2];
     (void)hipMemcpy(h, c, sizeof(h), hipMemcpyDeviceToHost);
-    fprintf(stderr, "[otg] edit, wfadaptive(%d,%d,%d): %s; the packed 1024-diagonal tier passes on %u pairs, the packed 4096 one %u, the byte-probe 2048 one %u, the 16384 one %u\n",
-            H.min_wf_len, H.max_dist, H.steps, hipGetErrorString(er), h[4], h[5], h[6], h[7]);
+    (void)hipMemcpy(h16, c16, sizeof(h16), hipMemcpyDeviceToHost);
+    fprintf(stderr, "[otg] edit, wfadaptive(%d,%d,%d): %s; the packed 1024-diagonal tier passes on %u pairs, the packed 4096 one %u, the packed 16384 one %u, the byte-probe 2048 one %u, the 16384 one %u\n",
+            H.min_wf_len, H.max_dist, H.steps, hipGetErrorString(er), h[4], h[5], h16[1], h[6], h[7]);
   }
   if (kernel_ms) {
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
@@ -1577,8 +1882,8 @@ int otg_launch_affine_adaptive_todo(otg_ctx* ctx, const uint8_t* d_arena, const 
   const int g = gcd3(x, o + e, e);
   const int xs = x / g, oes = (o + e) / g, es = e / g;
   if (std::max(xs, oes) + 1 > 64 || es + 1 > 64) return otg_fail(ctx, OTG_ERR_ARG, "affine penalties too large after gcd reduction");
-  if (ctx->pool[SLOT_COUNTERS].cap < 128 * sizeof(uint32_t)) ctx->affine_visited = nullptr;
-  uint32_t* cnt = (uint32_t*)otg_slot(ctx, SLOT_COUNTERS, 128 * sizeof(uint32_t));
+  if (ctx->pool[SLOT_COUNTERS].cap < OTG_COUNTER_WORDS * sizeof(uint32_t)) ctx->affine_visited = nullptr;
+  uint32_t* cnt = (uint32_t*)otg_slot(ctx, SLOT_COUNTERS, OTG_COUNTER_WORDS * sizeof(uint32_t));
   uint32_t* lists = (uint32_t*)otg_slot(ctx, SLOT_TODO, 2 * (size_t)n_tasks * sizeof(uint32_t));
   if (!cnt || !lists) return OTG_ERR_HIP;
   uint32_t* c = cnt + 120;                    // c[0..2] tickets, c[3..4] lengths of the overflow lists, c[6..7] the byte tier's pair, c[-2..-1] the 4096 window's

@@ -857,8 +857,8 @@ int otg_launch_affine_todo(otg_ctx* ctx, const uint8_t* d_arena, const otg_align
   const int g = gcd3(x, o + e, e);
   const int xs = x / g, oes = (o + e) / g, es = e / g;
   if (std::max(xs, oes) + 1 > 64 || es + 1 > 64) return otg_fail(ctx, OTG_ERR_ARG, "affine penalties too large after gcd reduction");
-  const bool fresh_cnt = ctx->pool[SLOT_COUNTERS].cap < 128 * sizeof(uint32_t);
-  uint32_t* cnt = (uint32_t*)otg_slot(ctx, SLOT_COUNTERS, 128 * sizeof(uint32_t));
+  const bool fresh_cnt = ctx->pool[SLOT_COUNTERS].cap < OTG_COUNTER_WORDS * sizeof(uint32_t);
+  uint32_t* cnt = (uint32_t*)otg_slot(ctx, SLOT_COUNTERS, OTG_COUNTER_WORDS * sizeof(uint32_t));
   uint32_t* todo = (uint32_t*)otg_slot(ctx, SLOT_TODO, 4 * (size_t)n_tasks * sizeof(uint32_t));
   if (!cnt || !todo) return OTG_ERR_HIP;
   HIP_TRY(ctx, hipMemsetAsync(cnt + 8, 0, 8 * sizeof(uint32_t), ctx->stream));        // tickets / overflow counters of the tiers behind the register tiers

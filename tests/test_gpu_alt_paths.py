@@ -33,7 +33,9 @@ CASES = [
     ("OTG_AFFINE_CONCURRENT=0", ["tests/test_gpu_affine.py::test_affine_small_mixed", "tests/test_gpu_pipeline.py::test_ont_kb"]),   # ... and one after the other on a small batch
     # the adaptive mode's tier chains (wfa_adaptive.hip): byte-probe tiers only; the wide packed tier first; the 1024-diagonal LDS tier / the int32 tier alone for the gap-affine aligner
     ("OTG_ADAPTIVE_EDIT_TIERS=12", ["tests/test_gpu_adaptive.py::test_adaptive_edit_small", "tests/test_gpu_adaptive.py::test_adaptive_edit_long", "tests/test_gpu_adaptive.py::test_adaptive_edit_wide_and_huge"]),
-    ("OTG_ADAPTIVE_EDIT_TIERS=2", ["tests/test_gpu_adaptive.py::test_adaptive_edit_small", "tests/test_gpu_adaptive.py::test_adaptive_edit_long"]),
+    ("OTG_ADAPTIVE_NO_WIDE_START", ["tests/test_gpu_adaptive.py::test_adaptive_edit_small", "tests/test_gpu_adaptive.py::test_adaptive_edit_wide_and_huge", "tests/test_gpu_adaptive.py::test_adaptive_pipeline_hifi_and_haps"]),
+    ("OTG_ADAPTIVE_EDIT_TIERS=16", ["tests/test_gpu_adaptive.py::test_adaptive_edit_small", "tests/test_gpu_adaptive.py::test_adaptive_edit_long", "tests/test_gpu_adaptive.py::test_adaptive_edit_parameters", "tests/test_gpu_adaptive.py::test_adaptive_edit_wide_and_huge", "tests/test_gpu_adaptive.py::test_adaptive_pipeline"]),
+    ("OTG_ADAPTIVE_EDIT_TIERS=2", ["tests/test_gpu_adaptive.py::test_adaptive_edit_small", "tests/test_gpu_adaptive.py::test_adaptive_edit_long", "tests/test_gpu_adaptive.py::test_adaptive_edit_parameters", "tests/test_gpu_adaptive.py::test_adaptive_pipeline_hifi_and_haps"]),
     ("OTG_ADAPTIVE_AFFINE_TIERS=2", ["tests/test_gpu_adaptive.py::test_adaptive_affine_small", "tests/test_gpu_adaptive.py::test_adaptive_affine_long", "tests/test_gpu_adaptive.py::test_adaptive_pipeline"]),
     ("OTG_ADAPTIVE_AFFINE_TIERS=8", ["tests/test_gpu_adaptive.py::test_adaptive_affine_small", "tests/test_gpu_adaptive.py::test_adaptive_affine_long", "tests/test_gpu_adaptive.py::test_adaptive_affine_parameters", "tests/test_gpu_adaptive.py::test_adaptive_pipeline"]),
     ("OTG_ADAPTIVE_AFFINE_TIERS=10", ["tests/test_gpu_adaptive.py::test_adaptive_affine_small", "tests/test_gpu_adaptive.py::test_adaptive_affine_long", "tests/test_gpu_adaptive.py::test_adaptive_affine_other_penalties_and_wide", "tests/test_gpu_adaptive.py::test_adaptive_pipeline_hifi_and_haps"]),
