@@ -628,22 +628,35 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_adaptive_lds_kernel(
       ++s;
       return s > pl + tl + 2 ? 3 : 0;
     };
-    // two loops, so that the window's loop is as tight as when it was the only one: first the scores on the global row (pairs that start wide) ...
+    // two loops, so that the window's loop is as tight as when it was the only one: the scores on the global row (a pair that starts wide, or whose
+    // wavefront outgrew the window on the way: 2 % of the pairs of the 1-10 kb shard, for ~80 of their ~2 400 scores — restarted in the 4 096 tier they
+    // cost an eighth of that shard's step), then the scores in the window; a range that outgrows the window is spilled to the row, one that has
+    // shrunk well below the window (128 diagonals of hysteresis) moves back in.
+    const bool can_spill = gscratch != nullptr && pl + tl + 72 <= gcap;
     int rc = overflow ? 2 : 0;
-    while (rc == 0 && wide) {
-      rc = one_score(EdWfGlobal{grow}, 32767 + 68);
-      if (rc != 0) break;
-      if (hi - lo + 68 <= CAP) {               // the range fits the window: move in (the window is all null) and stay
-        for (int c = lo; c <= hi; c += 64) { const int k = c + lane; if (k <= hi) wf[k & MASK] = grow[k]; }
-        wide = false;
-      } else {                                // the slots a score may read or store beyond what has been written so far are nulled first
-        if (lo - 2 < gnlo) { for (int c = lo - 2; c < gnlo; c += 64) if (c + lane < gnlo) grow[c + lane] = (int16_t)NUL; gnlo = lo - 2; }
-        if (hi + 66 > gnhi) { for (int c = gnhi + 1; c <= hi + 66; c += 64) if (c + lane <= hi + 66) grow[c + lane] = (int16_t)NUL; gnhi = hi + 66; }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    for (;;) {
+      while (rc == 0 && wide) {
+        rc = one_score(EdWfGlobal{grow}, 32767 + 68);
+        if (rc != 0) break;
+        if (hi - lo + 68 + 128 <= CAP) {         // move in: the window is all null
+          for (int c = lo; c <= hi; c += 64) { const int k = c + lane; if (k <= hi) wf[k & MASK] = grow[k]; }
+          wide = false;
+        } else {                                // the slots a score may read or store beyond what has been written so far are nulled first
+          if (lo - 2 < gnlo) { for (int c = lo - 2; c < gnlo; c += 64) if (c + lane < gnlo) grow[c + lane] = (int16_t)NUL; gnlo = lo - 2; }
+          if (hi + 66 > gnhi) { for (int c = gnhi + 1; c <= hi + 66; c += 64) if (c + lane <= hi + 66) grow[c + lane] = (int16_t)NUL; gnhi = hi + 66; }
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        }
       }
+      while (rc == 0) rc = one_score(EdWfLds<CAP>{wf}, CAP);
+      if (rc != 2 || wide || !can_spill) break;
+      // spill: the window holds the wavefront (nulls outside its range; hi - lo + 1 < CAP, so no two diagonals share a slot); the row gets it with
+      // nulls around it, the window goes back to all null
+      gnlo = lo - 2; gnhi = hi + 66;
+      for (int c = gnlo; c <= gnhi; c += 64) { const int k = c + lane; if (k <= gnhi) grow[k] = (int16_t)((k >= lo && k <= hi) ? wf[k & MASK] : NUL); }
+      for (int q = lane; q < CAP / 2; q += 64) wf32[q] = 0x80008000u;
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      wide = true; rc = 0;
     }
-    // ... then the scores in the window
-    while (rc == 0) rc = one_score(EdWfLds<CAP>{wf}, CAP);
     if (rc == 1) done = true;
     if (rc == 2) overflow = true;
     // wave-uniform tail: every lane stores the same value to the same address
