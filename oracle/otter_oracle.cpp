@@ -79,7 +79,7 @@ static uint64_t g_width_hist[4][16];
 static uint64_t g_width_n[4], g_width_scores[4];
 /* ... and, for the edit alignments whose wavefront ever exceeds 1020 diagonals (the fast adaptive tier's window): how many there are, in how many of
  * their scores the wavefront is that wide, the last such score + 1, and their scores in all — is the wide phase a prefix of the alignment? */
-static uint64_t g_width_phase[2][4];
+static uint64_t g_width_phase[4][4];        /* kinds 2, 3: the gap-affine alignments whose window (see width_stat) ever exceeds 252 diagonals */
 static void width_phase(int kind, int wide_scores, int last_wide, int scores)
 {
   if (!g_width_stats_on || wide_scores == 0) return;
@@ -221,7 +221,7 @@ int wfa_affine(const uint8_t* p, int pl, const uint8_t* t, int tl, int x, int o,
   const int kend = tl - pl;
   uint64_t W = 0;
   int s_end = -1, k_end = 0;
-  int steps_wait = 0, maxw = 0;
+  int steps_wait = 0, maxw = 0, wide_scores = 0, last_wide = -1;
   for (int s = 0;; ++s) {
     M.emplace_back(); I.emplace_back(); D.emplace_back(); BT.emplace_back();
     WF& m = M[s]; WF& iw = I[s]; WF& dw = D[s];
@@ -279,6 +279,7 @@ int wfa_affine(const uint8_t* p, int pl, const uint8_t* t, int tl, int x, int o,
       int wlo = m.lo, whi = m.hi;
       for (int b = 1; b <= o + e && s - b >= 0; ++b) if (!M[s - b].null()) { wlo = std::min(wlo, M[s - b].lo); whi = std::max(whi, M[s - b].hi); }
       maxw = std::max(maxw, whi - wlo + 1);
+      if (whi - wlo + 1 > 252) { ++wide_scores; last_wide = s; }
     }
     /* extend + termination */
     bool done = false;
@@ -312,7 +313,7 @@ int wfa_affine(const uint8_t* p, int pl, const uint8_t* t, int tl, int x, int o,
     }
   }
   if (cells) *cells = W;
-  width_stat(f.endsfree ? 3 : 2, maxw, s_end);
+  width_stat(f.endsfree ? 3 : 2, maxw, s_end); width_phase(f.endsfree ? 3 : 2, wide_scores, last_wide, s_end);
   if (!cigar) return s_end;
   /* backtrace: reverse op list with 'c' = gap close marker (WFA2's fake X) */
   std::string rev;
@@ -1684,7 +1685,7 @@ void oto_width_stats(int on, uint64_t* out)
   if (on) { memset(oto::g_width_phase, 0, sizeof(oto::g_width_phase)); memset(oto::g_width_hist, 0, sizeof(oto::g_width_hist)); memset(oto::g_width_n, 0, sizeof(oto::g_width_n)); memset(oto::g_width_scores, 0, sizeof(oto::g_width_scores)); }
   oto::g_width_stats_on = on;
 }
-/* out = 2 kinds (edit end-to-end, edit ends-free) x (alignments ever wider than 1020 diagonals, their wide scores, last wide score + 1 summed, all their scores) */
+/* out = 4 kinds x (alignments ever wider than the fast tier's window — 1020 diagonals edit, 252 gap-affine —, their wide scores, last wide score + 1 summed, all their scores) */
 void oto_width_phase(uint64_t* out) { memcpy(out, oto::g_width_phase, sizeof(oto::g_width_phase)); }
 void oto_set_poa_hook(void* fn) { oto::g_poa_hook = (oto::oto_poa_hook_t)fn; }
 uint32_t oto_result_n_alleles(oto_result* R) { return R->alleles.size(); }
