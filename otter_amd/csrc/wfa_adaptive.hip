@@ -1816,7 +1816,7 @@ int otg_launch_edit_adaptive_todo(otg_ctx* ctx, const uint8_t* d_arena, const ot
   const size_t dyn0 = (size_t)WPB0 * seqw * 4;
   const uint32_t per_cu0 = std::max<uint32_t>(1, std::min<uint32_t>(8, (uint32_t)((160 * 1024) / (WPB0 * 3072 + dyn0))));
   const uint32_t grid0 = std::min<uint32_t>(ncu * per_cu0, (n_tasks + WPB0 - 1) / WPB0);
-  const int gcap0 = (int)((2 * (size_t)ctx->max_seq_len + 128) & ~(size_t)1);
+  const int gcap0 = (int)std::min<size_t>((2 * (size_t)ctx->max_seq_len + 128) & ~(size_t)1, 65664);      // (the tier takes pairs of two sequences below 32 767 bases: pl + tl + 72 never needs more)
   const int gcapL = (int)(2 * (size_t)ctx->max_seq_len + 4);
   static const bool wide_start = getenv("OTG_ADAPTIVE_NO_WIDE_START") == nullptr;
   const size_t need0 = (only & 1) && wide_start ? (size_t)grid0 * WPB0 * (size_t)gcap0 * sizeof(int16_t) : 0;
