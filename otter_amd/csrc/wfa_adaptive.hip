@@ -633,7 +633,7 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_adaptive_lds_kernel(
     // cost an eighth of that shard's step), then the scores in the window; a range that outgrows the window is spilled to the row, one that has
     // shrunk well below the window (128 diagonals of hysteresis) moves back in.
     const bool can_spill = gscratch != nullptr && pl + tl + 72 <= gcap;
-    int rc = overflow ? 2 : 0;
+    int rc = overflow ? 4 : 0;              // 4: not a pair for this tier (too long, does not pack, starts wide without a row to start on)
     for (;;) {
       while (rc == 0 && wide) {
         rc = one_score(EdWfGlobal{grow}, 32767 + 68);
@@ -658,7 +658,7 @@ __global__ __launch_bounds__(WPB * 64) void wfa_edit_adaptive_lds_kernel(
       wide = true; rc = 0;
     }
     if (rc == 1) done = true;
-    if (rc == 2) overflow = true;
+    if (rc == 2 || rc == 4) overflow = true;
     // wave-uniform tail: every lane stores the same value to the same address
     if (done) {
       scores[ti] = s;
