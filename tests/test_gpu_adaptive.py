@@ -126,6 +126,44 @@ def test_adaptive_edit_wide_and_huge(gpu, oracle, adaptive):
     assert np.array_equal(cells, ecells)
 
 
+@pytest.mark.parametrize("params", [(10, 50, 1), (10, 400, 1), (10, 3000, 1), (200, 50, 2)])
+def test_adaptive_edit_window_and_global_row(gpu, oracle, adaptive, params):
+    """the fast edit tier's storage changes: pairs that START wider than the 1024-diagonal window (free begins of thousands of bases) run their first
+    scores on a global row and move in; wavefronts that outgrow the window on the way (a loose threshold never cuts much) are spilled and come back;
+    pairs with bytes outside ACGT, empty and one-base sequences among them must be passed on, not spilled"""
+    adaptive(True, *params)
+    rng = np.random.default_rng(47)
+    pairs, forms = [], []
+    for i in range(40):
+        L = int(rng.integers(1500, 5000))
+        a = mutate(rng, tr_seq(rng, L), 0.08)
+        kind = i % 5
+        if kind == 0:            # text = a suffix of the pattern, free begin as long as what is missing (wide start, narrow afterwards)
+            cut = int(rng.integers(1200, L - 200))
+            b = mutate(rng, a[cut:], 0.05); f = (cut, 0, 0, 0)
+        elif kind == 1:          # text = a prefix, free end
+            cut = int(rng.integers(200, L - 1200))
+            b = mutate(rng, a[:cut], 0.05); f = (0, L - cut, 0, 0)
+        elif kind == 2:          # both ends free, text from the middle
+            x0 = int(rng.integers(600, L // 2)); x1 = int(rng.integers(L // 2 + 100, L - 600))
+            b = mutate(rng, a[x0:x1], 0.05); f = (x0, L - x1, 0, 0)
+        elif kind == 3:          # end to end, divergent: under a loose threshold the wavefront grows past the window and stays there
+            b = mutate(rng, a, 0.15); f = None
+        else:                    # unrelated sequences
+            b = rand_seq(rng, int(rng.integers(1200, 3000))); f = None
+        if f is None and len(b) > len(a):
+            a, b = b, a
+        pairs.append((a, b)); forms.append(f)
+    n = rand_seq(rng, 2600)
+    pairs += [(n[:1300] + b"N" + n[1300:], n[900:]), (n.lower(), n[1500:]), (b"", n[:1500]), (n[:1500], b""), (b"A", n[:1200]), (n, n[2000:])]
+    forms += [(900, 0, 0, 0), (1500, 0, 0, 0), None, None, None, (2000, 0, 0, 0)]
+    arena, tasks = pair_tasks(pairs, forms)
+    got, cells = gpu.edit_distance_batch(arena, tasks, want_cells=True)
+    exp, ecells = oracle.edit_distance_batch(arena, tasks, want_cells=True)
+    assert np.array_equal(got, exp)
+    assert np.array_equal(cells, ecells)
+
+
 def _check_affine(gpu, oracle, arena, tasks, x=4, o=6, e=2):
     got, gc, gcells = gpu.affine_align_batch(arena, tasks, x, o, e, want_cells=True)
     exp, ec, ecells = oracle.affine_align_batch(arena, tasks, x, o, e, want_cells=True)
