@@ -543,6 +543,7 @@ int otg_genotype_files(const otg_genotype_job* job, otg_write_fn write, void* us
     std::thread next;
     const bool overlap = with_ref && f + per < n_beds;            // (the two-length table without -r reads the BAM handle's sample list while it formats: kept in sequence)
     if (overlap) next = std::thread([&, f, idx] { ingest_into(bufs[(idx + 1) & 1], f + per); });
+    auto join_next = [&] { if (next.joinable()) next.join(); };       // before every return: the ingest thread writes into bufs[] and reads the handles cleanup() closes
     struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{next};
     const uint32_t n = B.n, na = B.na; const uint64_t used = B.used;
     std::vector<uint32_t>& first = B.first; std::vector<otg_allele>& alleles = B.alleles; std::vector<uint8_t>& arena = B.arena;
@@ -558,7 +559,7 @@ int otg_genotype_files(const otg_genotype_job* job, otg_write_fn write, void* us
       if (na) {
         rc = otg_genotype_cluster_batch(ctx, &job->params, arena.data(), used + 64, seq_off.data(), seq_len.data(), first.data(), n_al.data(), n,
                                         gt.data(), gtl.data(), gtk.data(), hsd.data(), ngt.data(), reps.data());      // anallele_cluster (src/genotype.cpp:138)
-        if (rc != OTG_OK) { const std::string e = otg_last_error(ctx) ? otg_last_error(ctx) : ""; joiner.~Joiner(); cleanup(); return otg_fail(nullptr, rc, "otg_genotype_files: %s", e.c_str()); }
+        if (rc != OTG_OK) { const std::string e = otg_last_error(ctx) ? otg_last_error(ctx) : ""; join_next(); cleanup(); return otg_fail(nullptr, rc, "otg_genotype_files: %s", e.c_str()); }
       } else std::fill(ngt.begin(), ngt.end(), 0);
       st.ms_hot_path += ms_since(t0);
       t0 = Clock::now();
@@ -594,7 +595,7 @@ int otg_genotype_files(const otg_genotype_job* job, otg_write_fn write, void* us
       }
       text.clear();
       for (uint32_t sidx = 0; sidx < nslice; ++sidx) {
-        if (prc[sidx] != OTG_OK) { rc = prc[sidx]; const std::string e = perr[sidx]; joiner.~Joiner(); cleanup(); return otg_fail(nullptr, rc, "otg_genotype_files: %s", e.c_str()); }
+        if (prc[sidx] != OTG_OK) { rc = prc[sidx]; const std::string e = perr[sidx]; join_next(); cleanup(); return otg_fail(nullptr, rc, "otg_genotype_files: %s", e.c_str()); }
         text += parts[sidx];
       }
       rc = OTG_OK;
@@ -604,11 +605,11 @@ int otg_genotype_files(const otg_genotype_job* job, otg_write_fn write, void* us
       text.resize(need);
       rc = otg_emit_genotype_lengths(bam, beds.data() + f, chr_arena.data(), n, first.data(), alleles.data(), n_samples, need ? &text[0] : nullptr, need, &need);
     }
-    if (rc != OTG_OK) { joiner.~Joiner(); cleanup(); return rc; }
+    if (rc != OTG_OK) { join_next(); cleanup(); return rc; }
     st.ms_emit += ms_since(t0);
     for (uint32_t r = 0; r < n; ++r) { if (first[r + 1] > first[r]) ++st.n_regions_ok; }
     st.n_alleles += na;
-    if (!text.empty() && write(user, text.data(), text.size()) != 0) { joiner.~Joiner(); cleanup(); return otg_fail(nullptr, OTG_ERR_ARG, "otg_genotype_files: the writer failed"); }
+    if (!text.empty() && write(user, text.data(), text.size()) != 0) { join_next(); cleanup(); return otg_fail(nullptr, OTG_ERR_ARG, "otg_genotype_files: the writer failed"); }
     st.output_bytes += text.size();
     if (next.joinable()) next.join();
     if (!overlap && f + per < n_beds) ingest_into(bufs[(idx + 1) & 1], f + per);
