@@ -1,6 +1,6 @@
 """File-to-text rate of otg_assemble_files for several batch sizes (0 = the library's own batch plan) and numbers of hot-path contexts per device
 (OTG_DISPATCH_CONTEXTS).
-usage: python scripts/dispatch_probe.py [loci] [ingest_threads]"""
+usage: [OTG_PROBE_BATCHES=0,2048 OTG_PROBE_CONTEXTS=2,3 OTG_PROBE_LEN=1000,10000] python scripts/dispatch_probe.py [loci] [ingest_threads]"""
 import os
 import sys
 import tempfile
@@ -15,7 +15,8 @@ R = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 tmp = tempfile.mkdtemp(prefix="otg_dp_")
 t0 = time.perf_counter()
-fx = bamwrite.make_tr_fixture(tmp, R, depth=30, len_range=(1000, 5000), seed=7)
+LEN = tuple(int(x) for x in os.environ.get("OTG_PROBE_LEN", "1000,5000").split(","))       # locus length range of the fixture
+fx = bamwrite.make_tr_fixture(tmp, R, depth=30, len_range=LEN, seed=7)
 print("fixture: %d loci in %.0f s" % (R, time.perf_counter() - t0), flush=True)
 for batch in (int(b) for b in os.environ.get("OTG_PROBE_BATCHES", "250,500,1000").split(",")):
     for nctx in (int(c) for c in os.environ.get("OTG_PROBE_CONTEXTS", "1,2,3,4").split(",")):
