@@ -21,7 +21,15 @@
 // the wavefronts live in LDS in a MODULAR window (slot = k mod CAP: the live range drifts across the diagonals as the alignment
 // proceeds, a fixed window would have to span the whole drift), 16-bit offsets; tiers by window size, the last one keeps int32 rows in
 // HBM and takes any length and any penalties.  The smallest `left` is gathered while the diagonals finish their extension (per-lane
-// minimum + one wave reduction per score); the cut itself is two ballots over the end chunks.
+// minimum + one wave reduction per score); the cut itself is one ballot over the 32 diagonals at either end.
+//
+// The tiers as they stand (r04):
+//   edit        wfa_edit_adaptive_lds_kernel<1024> (packed pair in LDS, lane masks, two probes per sweep; a wavefront wider than the window — the
+//               start of an ends-free pair, a wide stretch on the way — runs on a global row and moves back in) -> <4096> -> the packed 16 384
+//               window with eight waves per pair (wfa_edit_adaptive_mw_kernel) -> byte probes 2 048 / 16 384 -> int32 row in HBM;
+//   gap-affine  wfa_affine_adaptive_lds_kernel<256> (eleven i16 rows per wave, null discipline per row) -> the 1 024 window with four waves per
+//               alignment and the 4 096 one with eight (wfa_affine_adaptive_mw_kernel: chunks dealt to the waves, one LDS barrier per score) ->
+//               byte probes 1 024 -> int32 rings in HBM.
 #include "wfa_affine_common.hpp"
 #include <algorithm>
 #include <cstdlib>
