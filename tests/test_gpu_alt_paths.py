@@ -14,10 +14,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 AFFINE_CORE = ["tests/test_gpu_affine.py::test_affine_small_mixed", "tests/test_gpu_affine.py::test_affine_long_ont",
                "tests/test_gpu_affine.py::test_affine_probe_boundaries", "tests/test_gpu_affine.py::test_affine_packed_sequence_capacity_sweep"]
 
+# test_gpu_affine.py without the admission sweep of the HBM-row tiers (11 s of oracle work; kept where those tiers are what the switch forces)
+AFFINE_ALL_BUT_ADMISSION = ["tests/test_gpu_affine.py::" + t for t in (
+    "test_affine_small_mixed", "test_affine_other_penalties", "test_affine_long_ont", "test_affine_cigar_valid_full_size", "test_affine_bounded_tandem_repeats",
+    "test_affine_non_acgt_bytes", "test_affine_packed_sequence_capacity_sweep", "test_affine_probe_boundaries", "test_affine_wide_free_begin")]
+
 CASES = [
     ("OTG_NO_AFFINE_BOUND", ["tests/test_gpu_affine.py"]),                               # no score bound: everything on the HBM-row tiers, un-pruned
     ("OTG_AFFINE_REG=0", ["tests/test_gpu_affine.py"]),                                  # bound + HBM-row tiers only (what the register tiers fall back to)
-    ("OTG_AFFINE_REG=25", ["tests/test_gpu_affine.py", "tests/test_gpu_poa.py"]),        # register tiers 1024 / 4096 / 8192 only: the 1536 / 2048 windows on the multi-wave tier
+    ("OTG_AFFINE_REG=25", AFFINE_ALL_BUT_ADMISSION + ["tests/test_gpu_poa.py"]),        # register tiers 1024 / 4096 / 8192 only: the 1536 / 2048 windows on the multi-wave tier
     ("OTG_NO_AFFINE_V3", AFFINE_CORE),                                                   # generic kernel only
     ("OTG_NO_MYERS", ["tests/test_gpu_edit.py::test_edit_small_mixed", "tests/test_gpu_edit.py::test_edit_long_ont"]),
     ("OTG_NO_EDIT_ROUTE OTG_NO_EDIT_SORT", ["tests/test_gpu_edit.py"]),
@@ -34,12 +39,12 @@ CASES = [
     # the adaptive mode's tier chains (wfa_adaptive.hip): byte-probe tiers only; the wide packed tier first; the 1024-diagonal LDS tier / the int32 tier alone for the gap-affine aligner
     ("OTG_ADAPTIVE_EDIT_TIERS=12", ["tests/test_gpu_adaptive.py::test_adaptive_edit_small", "tests/test_gpu_adaptive.py::test_adaptive_edit_long", "tests/test_gpu_adaptive.py::test_adaptive_edit_wide_and_huge"]),
     ("OTG_ADAPTIVE_NO_WIDE_START", ["tests/test_gpu_adaptive.py::test_adaptive_edit_small", "tests/test_gpu_adaptive.py::test_adaptive_edit_wide_and_huge", "tests/test_gpu_adaptive.py::test_adaptive_pipeline_hifi_and_haps"]),
-    ("OTG_ADAPTIVE_EDIT_TIERS=16", ["tests/test_gpu_adaptive.py::test_adaptive_edit_small", "tests/test_gpu_adaptive.py::test_adaptive_edit_long", "tests/test_gpu_adaptive.py::test_adaptive_edit_parameters", "tests/test_gpu_adaptive.py::test_adaptive_edit_wide_and_huge", "tests/test_gpu_adaptive.py::test_adaptive_pipeline"]),
+    ("OTG_ADAPTIVE_EDIT_TIERS=16", ["tests/test_gpu_adaptive.py::test_adaptive_edit_small", "tests/test_gpu_adaptive.py::test_adaptive_edit_long", "tests/test_gpu_adaptive.py::test_adaptive_edit_parameters", "tests/test_gpu_adaptive.py::test_adaptive_edit_wide_and_huge", "tests/test_gpu_adaptive.py::test_adaptive_pipeline[0]"]),
     ("OTG_ADAPTIVE_EDIT_TIERS=2", ["tests/test_gpu_adaptive.py::test_adaptive_edit_small", "tests/test_gpu_adaptive.py::test_adaptive_edit_long", "tests/test_gpu_adaptive.py::test_adaptive_edit_parameters", "tests/test_gpu_adaptive.py::test_adaptive_pipeline_hifi_and_haps"]),
-    ("OTG_ADAPTIVE_AFFINE_TIERS=2", ["tests/test_gpu_adaptive.py::test_adaptive_affine_small", "tests/test_gpu_adaptive.py::test_adaptive_affine_long", "tests/test_gpu_adaptive.py::test_adaptive_pipeline"]),
-    ("OTG_ADAPTIVE_AFFINE_TIERS=8", ["tests/test_gpu_adaptive.py::test_adaptive_affine_small", "tests/test_gpu_adaptive.py::test_adaptive_affine_long", "tests/test_gpu_adaptive.py::test_adaptive_affine_parameters", "tests/test_gpu_adaptive.py::test_adaptive_pipeline"]),
+    ("OTG_ADAPTIVE_AFFINE_TIERS=2", ["tests/test_gpu_adaptive.py::test_adaptive_affine_small", "tests/test_gpu_adaptive.py::test_adaptive_affine_long", "tests/test_gpu_adaptive.py::test_adaptive_pipeline[0]"]),
+    ("OTG_ADAPTIVE_AFFINE_TIERS=8", ["tests/test_gpu_adaptive.py::test_adaptive_affine_small", "tests/test_gpu_adaptive.py::test_adaptive_affine_long", "tests/test_gpu_adaptive.py::test_adaptive_affine_parameters", "tests/test_gpu_adaptive.py::test_adaptive_pipeline[0]"]),
     ("OTG_ADAPTIVE_AFFINE_TIERS=10", ["tests/test_gpu_adaptive.py::test_adaptive_affine_small", "tests/test_gpu_adaptive.py::test_adaptive_affine_long", "tests/test_gpu_adaptive.py::test_adaptive_affine_other_penalties_and_wide", "tests/test_gpu_adaptive.py::test_adaptive_pipeline_hifi_and_haps"]),
-    ("OTG_ADAPTIVE_AFFINE_TIERS=18", ["tests/test_gpu_adaptive.py::test_adaptive_affine_small", "tests/test_gpu_adaptive.py::test_adaptive_affine_long", "tests/test_gpu_adaptive.py::test_adaptive_pipeline"]),
+    ("OTG_ADAPTIVE_AFFINE_TIERS=18", ["tests/test_gpu_adaptive.py::test_adaptive_affine_small", "tests/test_gpu_adaptive.py::test_adaptive_affine_long", "tests/test_gpu_adaptive.py::test_adaptive_pipeline[0]"]),
     ("OTG_ADAPTIVE_AFFINE_TIERS=0", ["tests/test_gpu_adaptive.py::test_adaptive_affine_small", "tests/test_gpu_adaptive.py::test_adaptive_affine_other_penalties_and_wide"]),
 ]
 
