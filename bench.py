@@ -257,12 +257,12 @@ def e2e_leg(tmp, proc, n_regions, threads):
 
 
 # ------------------------------------------------------------------------------------------------ roofline of an assemble workload
-def pmc_for(cfg, n_regions):
-    """PMC-derived figures of profiles/pmc_summary.json, only when it was measured on exactly this workload."""
+def pmc_for(cfg, n_regions, adaptive=False):
+    """PMC-derived figures of profiles/pmc_summary.json, only when it was measured on exactly this workload (and aligner mode)."""
     if not os.path.exists(PMC_SUMMARY):
         return None
     try:
-        pm = json.load(open(PMC_SUMMARY)).get("config%d" % cfg)
+        pm = json.load(open(PMC_SUMMARY)).get("config%d%s" % (cfg, "_adaptive" if adaptive else ""))
         if pm and int(pm.get("regions", -1)) == n_regions:
             return pm
     except Exception:
@@ -316,7 +316,7 @@ def roofline(kstats, cfg, n_regions, adaptive=False):
     if ceil:
         out["peak"] = round(ceil["slots_per_s"] / 1e9, 2)
         out["peak_source"] = ceil["source"]
-    pm = None if adaptive else pmc_for(cfg, n_regions)
+    pm = pmc_for(cfg, n_regions, adaptive)
     if pm:
         ph = pm.get("physical", {}).get(kname, {})
         out["traffic"] = pm.get("traffic_bytes_per_launch", {}).get(kname)

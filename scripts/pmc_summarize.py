@@ -30,6 +30,8 @@ from otter_amd import synth  # noqa: E402
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 regions = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2] else (synth.CONFIGS[cfg]["n_regions"] // 8 if cfg == 4 else synth.CONFIGS[cfg]["n_regions"])
 tag = sys.argv[3] if len(sys.argv) > 3 else "r04"
+mode = sys.argv[4] if len(sys.argv) > 4 else ""          # "adaptive": the passes were taken with PMC_EXTRA="--heuristic wfadaptive"; kept under its own key / directory
+sfx = "_adaptive" if mode == "adaptive" else ""
 src = os.path.join(ROOT, "gpurun_out", "pmc_bench_c%d" % cfg)
 
 
@@ -118,7 +120,8 @@ def n_of(name, default):
         if k.startswith(name):
             return max(1, kernels[k]["launches"])
     return default
-chain_launches = {"wfa_edit_kernel": n_of("edit_route_kernel", 2), "wfa_affine_kernel": n_of("wfa_affine_bound1_kernel", 1), "poa": n_of("poa_count_kernel", 1),
+chain_launches = {"wfa_edit_kernel": n_of("wfa_edit_adaptive_lds_kernel<1024" if sfx else "edit_route_kernel", 2),
+                  "wfa_affine_kernel": n_of("wfa_affine_adaptive_lds_kernel<256" if sfx else "wfa_affine_bound1_kernel", 1), "poa": n_of("poa_count_kernel", 1),
                   "cluster": n_of("cluster_kernel", 1)}
 # cells the exact gap-affine tiers visited per chain launch: the device counter in the bench line of the profiled process (pass 1)
 visited = None
@@ -142,12 +145,12 @@ for g, c in groups.items():
         traffic[g] = d["traffic_bytes"] / chain_launches[g]
 path = os.path.join(ROOT, "profiles", "pmc_summary.json")
 allc = json.load(open(path)) if os.path.exists(path) else {}
-allc["config%d" % cfg] = {
-    "regions": regions, "workload": synth.config_workload(cfg, regions),
-    "source": "profiles/%s_pmc_c%d/ (scripts/pmc_bench.sh: rocprofv3 --kernel-trace --pmc <set> over bench.py --config %d --steps 1 --warmup 0)" % (tag, cfg, cfg),
+allc["config%d%s" % (cfg, sfx)] = {
+    "regions": regions, "workload": synth.config_workload(cfg, regions) + (" under wfadaptive(10,50,1)" if sfx else ""),
+    "source": "profiles/%s_pmc_c%d%s/ (scripts/pmc_bench.sh: rocprofv3 --kernel-trace --pmc <set> over bench.py --config %d --steps 1 --warmup 0%s)" % (tag, cfg, sfx, cfg, " --heuristic wfadaptive" if sfx else ""),
     "traffic_bytes_per_launch": traffic, "physical": physical, "kernels": kernels}
 json.dump(allc, open(path, "w"), indent=1, sort_keys=True)
-dst = os.path.join(ROOT, "profiles", "%s_pmc_c%d" % (tag, cfg))
+dst = os.path.join(ROOT, "profiles", "%s_pmc_c%d%s" % (tag, cfg, sfx))
 os.makedirs(dst, exist_ok=True)
 json.dump({k: dict(v) for k, v in agg.items()}, open(os.path.join(dst, "counters_by_kernel.json"), "w"), indent=1, sort_keys=True)
 lines = ["%-48s %5s %9s %9s %8s %7s %7s %7s %8s %9s" % ("kernel", "n", "valu_busy", "salu_busy", "fast_shr", "salu/v", "lds_bc", "wait", "waves/S", "traffic")]
